@@ -1,0 +1,211 @@
+"""Synthetic FT8 frame generator (host/numpy): the workload source for tests and bench.
+
+This is the build's own generator for BASELINE.json configs 1-4;
+it models what the reference transmitter does (reference: PyFT8/transmitter.py:41-70
+GFSK BT=2.0 waveform, :97-124 standard-message packing, :181-223 CRC-14 / LDPC(174,91)
+encode / Gray map / Costas framing) but is written from the FT8 protocol definition,
+not translated.  Known-answer check (tests/test_synth.py): "CQ G1OJS IO90" must give
+the 79-tone string printed by the reference's self-test.
+
+Recipe for one frame (config 1): 50 signals, standard i3=1 messages with plausible
+callsigns, f0 ~ U[200,2800] Hz, start = 0.5 s + U[-0.5,+1.0] s, SNR ~ U[lo,hi] dB in
+2500 Hz (WSJT-X convention), unit-variance white noise scaled to sigma = 1000 counts,
+clipped to int16.  RNG = numpy Philox keyed on (seed_base + frame index).
+"""
+import numpy as np
+
+from .ft8_tables import GEN_HEX
+
+FS = 12000
+NSPS = 1920                    # samples per symbol at 12 kHz (6.25 baud)
+NFRAME = 180000
+COSTAS = (3, 1, 4, 0, 6, 5, 2)
+GRAY = (0, 1, 3, 2, 5, 6, 4, 7)
+SEED_BASE = 0x46543800
+
+_A0 = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+_A1 = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+_A2 = "0123456789"
+_A3 = " ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+NTOKENS, MAX22 = 2063592, 4194304
+
+_GEN = [int(h, 16) >> 1 for h in GEN_HEX]   # 83 rows x 91 bits
+
+
+# ----------------------------------------------------------------------------- packing
+def pack_c28(call):
+    """Standard callsign or token -> 28-bit integer (FT8 protocol, i3=1)."""
+    if call in ("DE", "QRZ", "CQ"):
+        return ("DE", "QRZ", "CQ").index(call)
+    c = call
+    if len(c) < 3 or len(c) > 6:
+        raise ValueError(f"not a standard call: {call!r}")
+    if not c[2].isdigit():
+        c = " " + c
+    c = (c + "      ")[:6]
+    if not c[2].isdigit():
+        raise ValueError(f"not a standard call: {call!r}")
+    n = _A0.index(c[0])
+    n = n * 36 + _A1.index(c[1])
+    n = n * 10 + _A2.index(c[2])
+    n = n * 27 + _A3.index(c[3])
+    n = n * 27 + _A3.index(c[4])
+    n = n * 27 + _A3.index(c[5])
+    return n + NTOKENS + MAX22
+
+
+def pack_g15(txt):
+    """Grid / report / RRR / RR73 / 73 -> (g15, ir)."""
+    if txt == "RRR":
+        return 32402, 0
+    if txt == "RR73":
+        return 32403, 0
+    if txt == "73":
+        return 32404, 0
+    ir = 0
+    t = txt
+    if t.startswith("R") and len(t) > 1 and t[1] in "+-":
+        ir, t = 1, t[1:]
+    if t[0] in "+-":
+        return 32400 + 35 + int(t), ir
+    if len(txt) == 4:
+        v = (ord(txt[0]) - 65) * 18 + (ord(txt[1]) - 65)
+        return (v * 10 + int(txt[2])) * 10 + int(txt[3]), 0
+    raise ValueError(txt)
+
+
+def pack77(call_a, call_b, extra):
+    """Standard message (i3=1, or 2 if a '/P' is present) -> 77-bit int."""
+    def split(c):
+        if c.endswith("/P") or c.endswith("/R"):
+            return c[:-2], 1
+        return c, 0
+    a, pa = split(call_a)
+    b, pb = split(call_b)
+    i3 = 2 if (call_a.endswith("/P") or call_b.endswith("/P")) else 1
+    g15, ir = pack_g15(extra)
+    v = pack_c28(a)
+    v = (v << 1) | pa
+    v = (v << 28) | pack_c28(b)
+    v = (v << 1) | pb
+    v = (v << 1) | ir
+    v = (v << 15) | g15
+    v = (v << 3) | i3
+    return v
+
+
+def crc14(bits77):
+    """CRC-14 (poly 0x2757) of the 77-bit message zero-extended to 82 bits."""
+    r = 0
+    for i in range(96):
+        b = (bits77 >> (76 - i)) & 1 if i < 77 else 0
+        top = (r >> 13) & 1
+        r = ((r << 1) & 0x3FFF) | b
+        if top:
+            r ^= 0x2757
+    return r
+
+
+def encode174(bits77):
+    """77 bits -> 174-bit LDPC codeword (int, MSB = codeword bit 0)."""
+    m91 = (bits77 << 14) | crc14(bits77)
+    par = 0
+    for row in _GEN:
+        par = (par << 1) | (bin(m91 & row).count("1") & 1)
+    return (m91 << 83) | par
+
+
+def tones79(bits77):
+    cw = encode174(bits77)
+    syms = [GRAY[(cw >> (171 - 3 * i)) & 7] for i in range(58)]
+    return list(COSTAS) + syms[:29] + list(COSTAS) + syms[29:] + list(COSTAS)
+
+
+# ----------------------------------------------------------------------------- waveform
+def _gfsk_pulse(bt=2.0):
+    from math import erf, log, pi, sqrt
+    k = pi * sqrt(2.0 / log(2.0)) * bt
+    t = (np.arange(3 * NSPS) - 1.5 * NSPS) / NSPS
+    return np.array([0.5 * (erf(k * (x + 0.5)) - erf(k * (x - 0.5))) for x in t])
+
+
+_PULSE = None
+
+
+def tones_to_wave(tones, f0):
+    """79 tones -> real GFSK waveform, 79*1920 samples, unit amplitude."""
+    global _PULSE
+    if _PULSE is None:
+        _PULSE = _gfsk_pulse()
+    n = len(tones)
+    ext = [tones[0]] + list(tones) + [tones[-1]]          # dummy edge symbols
+    dphi = np.zeros((n + 2) * NSPS + 2 * NSPS)
+    for i, t in enumerate(ext):
+        dphi[i * NSPS:i * NSPS + 3 * NSPS] += t * _PULSE
+    dphi = dphi[int(1.5 * NSPS) + NSPS // 2: int(1.5 * NSPS) + NSPS // 2 + n * NSPS]
+    dphi = 2 * np.pi * (f0 + 6.25 * dphi) / FS
+    phi = np.cumsum(dphi) - dphi
+    w = np.sin(phi)
+    nr = NSPS // 8
+    ramp = 0.5 * (1 - np.cos(np.pi * np.arange(nr) / nr))
+    w[:nr] *= ramp
+    w[-nr:] *= ramp[::-1]
+    return w
+
+
+# ----------------------------------------------------------------------------- messages
+_PFX1 = "ACDEHJLOPSTUVXYZ"       # one-letter prefixes valid as <L><digit> without the BFGIKMNRW 3rd-digit trap
+_PFX2 = ["DL", "EA", "ON", "OK", "OZ", "PA", "SP", "SV", "UA", "UR", "YO", "YU", "HB", "HA", "LZ", "LY",
+         "ES", "OH", "SM", "LA", "EI", "GM", "GW", "IK", "IZ", "JA", "VK", "ZL", "VE", "WA", "KB", "KC"]
+
+
+def random_call(rng):
+    L = "ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+    if rng.random() < 0.35:
+        p = _PFX1[rng.integers(len(_PFX1))]
+        # keep first char a valid 1-char prefix, 2nd a digit
+        call = p + str(rng.integers(10))
+        nsuf = rng.integers(2, 4)
+    else:
+        call = _PFX2[rng.integers(len(_PFX2))] + str(rng.integers(10))
+        nsuf = rng.integers(1, 4)
+    call += "".join(L[rng.integers(26)] for _ in range(nsuf))
+    return call
+
+
+def random_message(rng):
+    a, b = random_call(rng), random_call(rng)
+    k = rng.integers(4)
+    L = "ABCDEFGHIJKLMNOPQR"
+    if k == 0:
+        grid = L[rng.integers(18)] + L[rng.integers(18)] + str(rng.integers(10)) + str(rng.integers(10))
+        return ("CQ", b, grid)
+    if k == 1:
+        return (a, b, f"{int(rng.integers(-24, 20)):+03d}")
+    if k == 2:
+        return (a, b, "R" + f"{int(rng.integers(-24, 20)):+03d}")
+    return (a, b, ("RR73", "73", "RRR")[rng.integers(3)])
+
+
+def make_frame(index, n_signals=50, snr_range=(-10.0, 10.0), seed_base=SEED_BASE, return_truth=False):
+    """One synthetic 15-s frame -> int16[180000] (and the truth list if asked)."""
+    rng = np.random.Generator(np.random.Philox(key=seed_base + int(index)))
+    x = rng.standard_normal(NFRAME)
+    truth = []
+    for _ in range(n_signals):
+        msg = random_message(rng)
+        f0 = rng.uniform(200.0, 2800.0)
+        t0 = 0.5 + rng.uniform(-0.5, 1.0)
+        snr = rng.uniform(*snr_range)
+        amp = np.sqrt(2.0 * (2500.0 / 6000.0) * 10.0 ** (snr / 10.0))
+        w = tones_to_wave(tones79(pack77(*msg)), f0)
+        i0 = int(round(t0 * FS))
+        n = min(len(w), NFRAME - i0)
+        x[i0:i0 + n] += amp * w[:n]
+        truth.append(dict(msg=" ".join(msg), f0=float(f0), t0=float(t0), snr=float(snr)))
+    y = np.clip(np.rint(x * 1000.0), -32768, 32767).astype(np.int16)
+    return (y, truth) if return_truth else y
+
+
+def make_batch(start, count, **kw):
+    return np.stack([make_frame(start + i, **kw) for i in range(count)])
