@@ -1,0 +1,901 @@
+/* ft8_oracle.c -- CPU restatement of PyFT8's receive hot path (receiver.py + decoders.py).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product (pyft8_amd/) never does.  It is a from-scratch,
+ * single-threaded, plain-C statement of WHAT the reference computes, pinned against golden
+ * vectors captured from the real reference (tests/golden/, oracle/gen_golden.py):
+ *   - integer / bit work (CRC-14, GF(2) elimination, message validity, unpack, hashes,
+ *     candidate ordering, the ipass ladder) is exact;
+ *   - floating-point stages follow the reference's fp32 data flow; numpy primitives that
+ *     cannot be bit-matched (pocketfft, BLAS sdot, SIMD tanh/log10) are replaced by an
+ *     explicitly ordered IEEE-754 "arithmetic contract" that the HIP kernels repeat
+ *     operation for operation, so GPU-vs-oracle comparisons can be bit-exact while
+ *     oracle-vs-reference agrees to ~1e-6 relative (tests assert <= 1e-4).
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (no FMA contraction, no reassociation).
+ *
+ * Reference line citations are to /root/reference/PyFT8/.
+ */
+#include "ft8_oracle.h"
+#include "ft8_tables.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+typedef struct { float re, im; } cpx;
+
+static const int COSTAS[7] = {3, 1, 4, 0, 6, 5, 2};             /* receiver.py:13 */
+
+void ft8o_default_config(ft8o_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->sync_score_min = 85.0f; c->max_cands = 200;               /* receiver.py:311 */
+    c->f0_lo = 32; c->f0_hi = 960;                               /* receiver.py:234-235 */
+    c->h0_lo = -37; c->h0_hi = 87;                               /* receiver.py:319 */
+    c->bp_nc0_a = 35; c->bp_iters_a = 5;                         /* receiver.py:78,91 */
+    c->bp_nc0_b = 90; c->bp_iters_b = 20;                        /* receiver.py:95 */
+    c->osd_single = 30; c->osd_double = 2;                       /* decoders.py:223 */
+    c->llr_sd_min = 5.0f;                                        /* receiver.py:30 */
+    int p1920[] = {8, 8, 5, 3, 2, 0}, p3200[] = {8, 4, 4, 5, 5, 0}, p300[] = {5, 5, 4, 3, 0}, p320[] = {8, 8, 5, 0};
+    memcpy(c->plan1920, p1920, sizeof(p1920)); memcpy(c->plan3200, p3200, sizeof(p3200));
+    memcpy(c->plan300, p300, sizeof(p300));    memcpy(c->plan320, p320, sizeof(p320));
+}
+
+/* ------------------------------------------------------------------ arithmetic contract */
+static inline float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t bits_from_f(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* log10 for x > 0: exponent split + atanh series, ~1e-7 absolute on the dB-scale inputs.
+ * Replaces np.log10 (receiver.py:170,292). */
+float ft8o_log10f(float x) {
+    if (!(x > 0.0f)) return (x == 0.0f) ? -INFINITY : NAN;
+    if (x > 3.0e38f) return INFINITY;
+    uint32_t ix = bits_from_f(x);
+    int e = 0;
+    if (ix < 0x00800000u) { x = x * 8388608.0f; ix = bits_from_f(x); e = -23; }
+    e += (int)(ix >> 23) - 127;
+    float m = f_from_bits((ix & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.11111111f;
+    p = p * s2 + 0.14285715f;
+    p = p * s2 + 0.2f;
+    p = p * s2 + 0.33333334f;
+    p = p * s2 + 1.0f;
+    float lnm = (2.0f * s) * p;
+    float fe = (float)e;
+    return fe * 0.301025390625f + (fe * 4.6050390e-6f + lnm * 0.4342945f);
+}
+
+/* tanh: Pade(7,6) below 1, 1-2/(exp(2|x|)+1) above.  Replaces np.tanh (decoders.py:142). */
+float ft8o_tanhf(float x) {
+    if (x != x) return x;
+    float ax = fabsf(x), r;
+    if (ax < 1.0f) {
+        float x2 = ax * ax;
+        float num = ((x2 + 378.0f) * x2 + 17325.0f) * x2 + 135135.0f;
+        float den = ((28.0f * x2 + 3150.0f) * x2 + 62370.0f) * x2 + 135135.0f;
+        r = (ax * num) / den;
+    } else {
+        float y = 2.0f * ax;
+        if (y > 20.0f) y = 20.0f;
+        int k = (int)(y * 1.442695041f + 0.5f);
+        float fk = (float)k;
+        float t = (y - fk * 0.693359375f) - fk * (-2.12194440e-4f);
+        float p = 1.9841270e-4f;            /* 1/5040 */
+        p = p * t + 1.3888889e-3f;          /* 1/720 */
+        p = p * t + 8.3333333e-3f;          /* 1/120 */
+        p = p * t + 4.1666667e-2f;          /* 1/24 */
+        p = p * t + 1.6666667e-1f;          /* 1/6 */
+        p = p * t + 0.5f;
+        p = p * t + 1.0f;
+        p = p * t + 1.0f;
+        float E = p * f_from_bits((uint32_t)(k + 127) << 23);
+        r = 1.0f - 2.0f / (E + 1.0f);
+    }
+    return (x < 0.0f) ? -r : r;
+}
+
+static inline cpx cmul(cpx a, cpx w) { cpx r; r.re = a.re * w.re - a.im * w.im; r.im = a.re * w.im + a.im * w.re; return r; }
+static inline cpx cadd(cpx a, cpx b) { cpx r = {a.re + b.re, a.im + b.im}; return r; }
+static inline cpx csub(cpx a, cpx b) { cpx r = {a.re - b.re, a.im - b.im}; return r; }
+static inline cpx mulnegi(cpx a) { cpx r = {a.im, -a.re}; return r; }       /* a * (-i) */
+
+/* forward DFT primitives (sign -1) -- canonical operation order */
+static inline void dft2(cpx* a) { cpx t = a[0]; a[0] = cadd(t, a[1]); a[1] = csub(t, a[1]); }
+static inline void dft3(cpx* a) {
+    cpx t1 = cadd(a[1], a[2]), t2 = csub(a[1], a[2]);
+    cpx m = {a[0].re + (-0.5f) * t1.re, a[0].im + (-0.5f) * t1.im};
+    cpx n = {0.86602540f * t2.re, 0.86602540f * t2.im};
+    a[0] = cadd(a[0], t1);
+    a[1].re = m.re + n.im; a[1].im = m.im - n.re;
+    a[2].re = m.re - n.im; a[2].im = m.im + n.re;
+}
+static inline void dft4(cpx* a) {
+    cpx t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]), t2 = cadd(a[1], a[3]), t3 = csub(a[1], a[3]);
+    a[0] = cadd(t0, t2); a[2] = csub(t0, t2);
+    a[1].re = t1.re + t3.im; a[1].im = t1.im - t3.re;
+    a[3].re = t1.re - t3.im; a[3].im = t1.im + t3.re;
+}
+static inline void dft5(cpx* a) {
+    const float c1 = 0.30901699f, c2 = -0.80901699f, s1 = 0.95105652f, s2 = 0.58778525f;
+    cpx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+    cpx m1 = {(a[0].re + c1 * t1.re) + c2 * t2.re, (a[0].im + c1 * t1.im) + c2 * t2.im};
+    cpx m2 = {(a[0].re + c2 * t1.re) + c1 * t2.re, (a[0].im + c2 * t1.im) + c1 * t2.im};
+    cpx n1 = {s1 * t3.re + s2 * t4.re, s1 * t3.im + s2 * t4.im};
+    cpx n2 = {s2 * t3.re - s1 * t4.re, s2 * t3.im - s1 * t4.im};
+    cpx t5 = cadd(t1, t2);
+    a[0] = cadd(a[0], t5);
+    a[1].re = m1.re + n1.im; a[1].im = m1.im - n1.re;
+    a[4].re = m1.re - n1.im; a[4].im = m1.im + n1.re;
+    a[2].re = m2.re + n2.im; a[2].im = m2.im - n2.re;
+    a[3].re = m2.re - n2.im; a[3].im = m2.im + n2.re;
+}
+static inline void dft8(cpx* a) {
+    const float h = 0.70710678f;
+    cpx e[4] = {a[0], a[2], a[4], a[6]}, o[4] = {a[1], a[3], a[5], a[7]};
+    dft4(e); dft4(o);
+    cpx o1 = {h * (o[1].re + o[1].im), h * (o[1].im - o[1].re)};
+    cpx o2 = mulnegi(o[2]);
+    cpx o3 = {h * (o[3].im - o[3].re), -(h * (o[3].re + o[3].im))};
+    a[0] = cadd(e[0], o[0]); a[4] = csub(e[0], o[0]);
+    a[1] = cadd(e[1], o1);   a[5] = csub(e[1], o1);
+    a[2] = cadd(e[2], o2);   a[6] = csub(e[2], o2);
+    a[3] = cadd(e[3], o3);   a[7] = csub(e[3], o3);
+}
+
+/* twiddle table W_N^t = (cos 2pi t/N, -sin 2pi t/N), double -> float */
+static void make_twiddle(int n, cpx* w) {
+    for (int t = 0; t < n; t++) {
+        double ang = (2.0 * M_PI * (double)t) / (double)n;
+        w[t].re = (float)cos(ang); w[t].im = (float)(-sin(ang));
+    }
+}
+
+typedef struct { int n; cpx* w; } twtab;
+static twtab g_tw[8];
+static const cpx* get_twiddle(int n) {
+    for (int i = 0; i < 8; i++) if (g_tw[i].n == n) return g_tw[i].w;
+    for (int i = 0; i < 8; i++) if (g_tw[i].n == 0) {
+        g_tw[i].w = (cpx*)malloc(sizeof(cpx) * (size_t)n); make_twiddle(n, g_tw[i].w); g_tw[i].n = n; return g_tw[i].w;
+    }
+    return NULL;
+}
+
+/* Stockham autosort, decimation in frequency, radix list `plan` (product == n).
+ * pass(r): m = n_cur/r; for p<m, q<s: a_j = x[q + s(p + j m)]; b = DFT_r(a);
+ *          y[q + s(r p + j)] = b_j * W_N^{j p s}   (multiply skipped when j p == 0). */
+static void fft_core(cpx* x, cpx* y, int N, const int32_t* plan, const cpx* W) {
+    int n = N, s = 1;
+    cpx* src = x; cpx* dst = y;
+    for (int ip = 0; plan[ip]; ip++) {
+        int r = plan[ip], m = n / r;
+        for (int p = 0; p < m; p++) for (int q = 0; q < s; q++) {
+            cpx a[8];
+            for (int j = 0; j < r; j++) a[j] = src[q + s * (p + j * m)];
+            switch (r) { case 2: dft2(a); break; case 3: dft3(a); break; case 4: dft4(a); break;
+                         case 5: dft5(a); break; case 8: dft8(a); break; default: abort(); }
+            for (int j = 0; j < r; j++) {
+                cpx v = a[j];
+                if (j * p != 0) v = cmul(v, W[(size_t)j * p * s]);
+                dst[q + s * (r * p + j)] = v;
+            }
+        }
+        cpx* t = src; src = dst; dst = t;
+        n = m; s *= r;
+    }
+    if (src != x) memcpy(x, src, sizeof(cpx) * (size_t)N);
+}
+
+void ft8o_fft(float* data, int n, const int32_t* plan, float* scratch) {
+    fft_core((cpx*)data, (cpx*)scratch, n, plan, get_twiddle(n));
+}
+
+/* ------------------------------------------------------------------ spectrogram (receiver.py:288-306) */
+static float g_win[3840];
+static int g_win_ok = 0;
+static void make_window(void) {
+    /* np.hanning(3840).astype(float32): 0.5 + 0.5 cos(pi (2i+1-M)/(M-1)) (receiver.py:236) */
+    for (int i = 0; i < 3840; i++)
+        g_win[i] = (float)(0.5 + 0.5 * cos(M_PI * (double)(2 * i + 1 - 3840) / 3839.0));
+    g_win_ok = 1;
+}
+
+void ft8o_spectrogram(const int16_t* audio, const ft8o_config* c, float* grid) {
+    if (!g_win_ok) make_window();
+    const cpx* W = get_twiddle(1920);
+    const cpx* WR = get_twiddle(3840);
+    cpx* z = (cpx*)malloc(sizeof(cpx) * 1920 * 2);
+    cpx* y = z + 1920;
+    for (int k = 0; k < FT8O_GRID_COLS; k++) grid[k] = 1.0f;       /* row 0 never written (receiver.py:240,300) */
+    for (int r = 1; r <= 375; r++) {
+        int base = 480 * r - 3840;                                   /* window = last 3840 samples after hop r */
+        for (int m = 0; m < 1920; m++) {
+            int i0 = base + 2 * m, i1 = i0 + 1;
+            float x0 = (i0 >= 0) ? (float)audio[i0] * g_win[2 * m] : 0.0f * g_win[2 * m];
+            float x1 = (i1 >= 0) ? (float)audio[i1] * g_win[2 * m + 1] : 0.0f * g_win[2 * m + 1];
+            z[m].re = x0; z[m].im = x1;
+        }
+        fft_core(z, y, 1920, c->plan1920, W);
+        float* out = grid + (size_t)r * FT8O_GRID_COLS;
+        for (int k = 0; k < FT8O_GRID_COLS; k++) {
+            cpx a = z[k], b = z[(1920 - k) % 1920];
+            float er = 0.5f * (a.re + b.re), ei = 0.5f * (a.im - b.im);
+            float orr = 0.5f * (a.im + b.im), oi = 0.5f * (b.re - a.re);
+            cpx w = WR[k];
+            float xr = er + (w.re * orr - w.im * oi);
+            float xi = ei + (w.re * oi + w.im * orr);
+            float mag = sqrtf(xr * xr + xi * xi);
+            out[k] = 20.0f * ft8o_log10f(mag + 1e-12f);
+        }
+    }
+    free(z);
+}
+
+/* grid row accessor with the reference's modulo-750 wrap (receiver.py:240,347,360): rows that were
+ * never written in an isolated frame (0, 376..749) hold 1.0 */
+static inline float grid_at(const float* grid, int row, int col) {
+    row %= 750; if (row < 0) row += 750;
+    if (row >= 1 && row <= 375) return grid[(size_t)row * FT8O_GRID_COLS + col];
+    return 1.0f;
+}
+
+/* ------------------------------------------------------------------ sync search (receiver.py:338-367) */
+static const double W6 = (double)(-0.16666667163372040f);          /* np.float32(-1/6), receiver.py:323 */
+
+int ft8o_sync_search(const float* grid, const ft8o_config* c, ft8o_cand* out) {
+    int n = 0;
+    for (int f0 = c->f0_lo; f0 < c->f0_hi; f0++) {
+        float best = 0.0f; int best_h0 = 0;
+        for (int h0 = c->h0_lo; h0 < c->h0_hi; h0++) {
+            double s1 = 0.0, tsum = 0.0;
+            for (int s = 0; s < 7; s++) {
+                int row = h0 + 148 + 4 * s;                         /* h0 + base_search_hops + search_hps */
+                double t = 0.0;
+                for (int b = 0; b < 14; b++) t += (double)grid_at(grid, row, f0 + b);
+                tsum += t;
+                s1 += (double)grid_at(grid, row, f0 + 2 * COSTAS[s]) + (double)grid_at(grid, row, f0 + 2 * COSTAS[s] + 1);
+            }
+            float score = (float)(s1 + W6 * (tsum - s1));
+            if (score > best) { best = score; best_h0 = h0; }       /* first strict maximum */
+        }
+        if (best > c->sync_score_min) {
+            memset(&out[n], 0, sizeof(out[n]));
+            out[n].f0_idx = f0; out[n].h0_idx = best_h0; out[n].score = best; out[n].ipass = -1;
+            n++;
+        }
+    }
+    /* stable sort, score descending (receiver.py:366): insertion sort keeps f0 order on ties */
+    for (int i = 1; i < n; i++) {
+        ft8o_cand t = out[i]; int j = i - 1;
+        while (j >= 0 && out[j].score < t.score) { out[j + 1] = out[j]; j--; }
+        out[j + 1] = t;
+    }
+    return n < c->max_cands ? n : c->max_cands;
+}
+
+static const int PAYLOAD_SYM[58] = {7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,
+    43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71};   /* receiver.py:14 */
+
+void ft8o_payload(const float* grid, int f0_idx, int h0_idx, float* p) {
+    for (int i = 0; i < 58; i++)
+        for (int t = 0; t < 8; t++)
+            p[i * 8 + t] = grid_at(grid, h0_idx + 4 + 4 * PAYLOAD_SYM[i], f0_idx + 1 + 2 * t);   /* receiver.py:358-362 */
+}
+
+/* numpy's float32 pairwise summation (np.mean on a contiguous f32 vector) */
+static float pairwise_sum(const float* a, int n) {
+    if (n < 8) { float r = 0.0f; for (int i = 0; i < n; i++) r += a[i]; return r; }
+    if (n <= 128) {
+        float r[8]; int i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2; n2 -= n2 % 8;
+    return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
+}
+
+static inline float max4(float a, float b, float c, float d) {
+    float m = a; if (b > m) m = b; if (c > m) m = c; if (d > m) m = d; return m;
+}
+
+/* receiver.py:208-222.  Returns 1 if the sd gate passes (sd > 5), 0 => 'stop'. */
+int ft8o_db_to_llr(const float* p, float* llr, float* sd_out, int32_t* snr_out) {
+    float pmax = p[0], pmin = p[0];
+    for (int i = 1; i < 464; i++) { if (p[i] > pmax) pmax = p[i]; if (p[i] < pmin) pmin = p[i]; }
+    float d = (pmax - pmin) - 58.0f;
+    int snr = (int)d; if (snr < -24) snr = -24; if (snr > 24) snr = 24;
+    float sq[174];
+    for (int i = 0; i < 58; i++) {
+        const float* q = p + 8 * i;
+        llr[3 * i + 0] = max4(q[4], q[5], q[6], q[7]) - max4(q[0], q[1], q[2], q[3]);
+        llr[3 * i + 1] = max4(q[2], q[3], q[4], q[7]) - max4(q[0], q[1], q[5], q[6]);
+        llr[3 * i + 2] = max4(q[1], q[2], q[6], q[7]) - max4(q[0], q[3], q[4], q[5]);
+    }
+    for (int i = 0; i < 174; i++) sq[i] = llr[i] * llr[i];
+    float mean = pairwise_sum(llr, 174) / 174.0f;
+    float var = pairwise_sum(sq, 174) / 174.0f - mean * mean;
+    float sd = sqrtf(var);
+    for (int i = 0; i < 174; i++) llr[i] = (2.83f * llr[i]) / sd;
+    *sd_out = sd; *snr_out = snr;
+    return !(sd <= 5.0f);
+}
+
+/* ------------------------------------------------------------------ cycle spectrum (receiver.py:280-286) */
+void ft8o_cycle_spectrum(const int16_t* audio, const ft8o_config* c, float* spec_out) {
+    const int N = 96000, N1 = 300, N2 = 320;
+    const cpx* W = get_twiddle(N);
+    const cpx* W1 = get_twiddle(N1);
+    const cpx* W2 = get_twiddle(N2);
+    cpx* A = (cpx*)malloc(sizeof(cpx) * (size_t)N);       /* A[k1][n2] */
+    cpx* Z = (cpx*)malloc(sizeof(cpx) * (size_t)N);
+    cpx col[320], scr[320];
+    for (int n2 = 0; n2 < N2; n2++) {
+        for (int n1 = 0; n1 < N1; n1++) {
+            int m = N2 * n1 + n2;
+            col[n1].re = (2 * m < FT8O_NSAMP) ? (float)audio[2 * m] : 0.0f;
+            col[n1].im = (2 * m + 1 < FT8O_NSAMP) ? (float)audio[2 * m + 1] : 0.0f;
+        }
+        fft_core(col, scr, N1, c->plan300, W1);
+        for (int k1 = 0; k1 < N1; k1++) {
+            cpx v = col[k1];
+            if (n2 * k1 != 0) v = cmul(v, W[(size_t)n2 * k1]);
+            A[(size_t)k1 * N2 + n2] = v;
+        }
+    }
+    for (int k1 = 0; k1 < N1; k1++) {
+        memcpy(col, A + (size_t)k1 * N2, sizeof(cpx) * N2);
+        fft_core(col, scr, N2, c->plan320, W2);
+        for (int k2 = 0; k2 < N2; k2++) Z[k1 + N1 * k2] = col[k2];
+    }
+    cpx* X = (cpx*)spec_out;
+    for (int k = 0; k < FT8O_SPEC_BINS; k++) {
+        cpx a = Z[k], b = Z[(N - k) % N];
+        float er = 0.5f * (a.re + b.re), ei = 0.5f * (a.im - b.im);
+        float orr = 0.5f * (a.im + b.im), oi = 0.5f * (b.re - a.re);
+        double ang = (2.0 * M_PI * (double)k) / 192000.0;
+        float wr = (float)cos(ang), wi = (float)(-sin(ang));
+        X[k].re = er + (wr * orr - wi * oi);
+        X[k].im = ei + (wr * oi + wi * orr);
+    }
+    free(A); free(Z);
+}
+
+/* ------------------------------------------------------------------ fine sync (receiver.py:140-206) */
+static double g_taper[100];
+static int g_taper_ok = 0;
+static void make_taper(void) {
+    /* 0.5*(1+cos(linspace(pi,0,100))) == 0.5*(1+cos(linspace(-pi,0,100))) (receiver.py:183-184): rises 0 -> 1 */
+    double step = (0.0 - M_PI) / 99.0;
+    for (int i = 0; i < 100; i++) {
+        double y = (i == 99) ? 0.0 : (double)i * step + M_PI;
+        g_taper[i] = 0.5 * (1.0 + cos(y));
+    }
+    g_taper_ok = 1;
+}
+
+/* baseband series z[3200] @ 200 S/s for spectrum origin fb (receiver.py:180-186) */
+static void fine_zsig(const float* spec, const ft8o_config* c, int fb, cpx* z) {
+    if (!g_taper_ok) make_taper();
+    const cpx* S = (const cpx*)spec;
+    const cpx* W = get_twiddle(3200);
+    cpx* scr = (cpx*)malloc(sizeof(cpx) * 3200);
+    for (int k = 0; k < 3200; k++) { z[k].re = 0.0f; z[k].im = 0.0f; }
+    for (int k = 0; k < 850; k++) {
+        cpx v = S[fb + k];
+        if (k >= 750) { double t = g_taper[k - 750]; v.re = (float)((double)v.re * t); v.im = (float)((double)v.im * t); }
+        z[k].re = v.re; z[k].im = -v.im;                           /* conj: inverse FFT = conj(FFT(conj)) */
+    }
+    for (int k = 0; k < 150; k++) {
+        cpx v = S[fb - 150 + k];
+        if (k < 100) { double t = g_taper[k]; v.re = (float)((double)v.re * t); v.im = (float)((double)v.im * t); }
+        z[3050 + k].re = v.re; z[3050 + k].im = -v.im;
+    }
+    fft_core(z, scr, 3200, c->plan3200, W);
+    const float inv = 0.0003125f;
+    for (int k = 0; k < 3200; k++) { z[k].re = z[k].re * inv; z[k].im = -(z[k].im * inv); }
+    free(scr);
+}
+
+/* |32-point DFT| tones 0..7 of symbol s starting at tb (receiver.py:189-195) */
+static void fine_symbol(const cpx* z, int tb, int s, float* g8) {
+    static cpx W32[32]; static int ok = 0;
+    if (!ok) { make_twiddle(32, W32); ok = 1; }
+    int i0 = tb + 32 * s; if (i0 < 0) i0 = 0; if (i0 > 3168) i0 = 3168;
+    for (int t = 0; t < 8; t++) {
+        cpx acc = {0.0f, 0.0f};
+        for (int n = 0; n < 32; n++) acc = cadd(acc, cmul(z[i0 + n], W32[(n * t) & 31]));
+        g8[t] = sqrtf(acc.re * acc.re + acc.im * acc.im);
+    }
+}
+
+static float fine_score(const cpx* z, int tb) {                    /* receiver.py:197-206: middle Costas only */
+    double s1 = 0.0, s2 = 0.0;
+    for (int a = 0; a < 7; a++) {
+        float g[8]; fine_symbol(z, tb, 36 + a, g);
+        for (int b = 0; b < 7; b++) { if (b == COSTAS[a]) s1 += (double)g[b]; else s2 += (double)g[b]; }
+    }
+    return (float)(s1 + W6 * s2);
+}
+
+void ft8o_fine_grid(const float* spec, const ft8o_config* c, int fb, int tb, float* grid, float* score) {
+    cpx* z = (cpx*)malloc(sizeof(cpx) * 3200);
+    fine_zsig(spec, c, fb, z);
+    for (int s = 0; s < 79; s++) fine_symbol(z, tb, s, grid + 8 * s);
+    if (score) *score = fine_score(z, tb);
+    free(z);
+}
+
+/* returns 1 continue, 0 stopped by Costas gate (llr untouched), -1 stopped by sd gate */
+int ft8o_fine(const float* spec, const ft8o_config* c, int f0_idx, int h0_idx, int32_t* ttweak, int32_t* ftweak,
+              int32_t* nsync, float* llr, float* sd, int32_t* snr, float* sgrid) {
+    int fb0 = 50 * f0_idx;                                           /* int(0.5 + fHz*16), fHz = 3.125 f0 */
+    int tb0 = 8 * h0_idx + (h0_idx < 0 ? 1 : 0);                     /* int(0.5 + tsec/0.005) truncates toward 0 */
+    cpx* z = (cpx*)malloc(sizeof(cpx) * 3200);
+    fine_zsig(spec, c, fb0, z);
+    int tt = 0; float best = 0.0f;
+    for (int i = 0; i < 8; i++) {                                    /* range(-8,8,2) */
+        float sc = fine_score(z, tb0 + (-8 + 2 * i));
+        if (i == 0 || sc > best) { best = sc; tt = -8 + 2 * i; }
+    }
+    int ft = 0;
+    for (int i = 0; i < 9; i++) {                                    /* range(-32,33,8) */
+        int f = -32 + 8 * i;
+        fine_zsig(spec, c, fb0 + f, z);
+        float sc = fine_score(z, tb0 + tt);
+        if (i == 0 || sc > best) { best = sc; ft = f; }
+    }
+    fine_zsig(spec, c, fb0 + ft, z);
+    float g[79 * 8];
+    for (int s = 0; s < 79; s++) fine_symbol(z, tb0 + tt, s, g + 8 * s);
+    free(z);
+    if (sgrid) memcpy(sgrid, g, sizeof(g));
+    *ttweak = tt; *ftweak = ft;
+    int nm = 0;
+    for (int blk = 0; blk < 3; blk++) for (int a = 0; a < 7; a++) {  /* receiver.py:164-166 */
+        const float* q = g + 8 * (36 * blk + a);
+        int am = 0; for (int t = 1; t < 8; t++) if (q[t] > q[am]) am = t;
+        if (am == COSTAS[a]) nm++;
+    }
+    *nsync = nm;
+    if (nm <= 6) return 0;
+    float p[464];
+    for (int i = 0; i < 58; i++) for (int t = 0; t < 8; t++) p[8 * i + t] = 20.0f * ft8o_log10f(g[8 * PAYLOAD_SYM[i] + t]);
+    return ft8o_db_to_llr(p, llr, sd, snr) ? 1 : -1;
+}
+
+/* ------------------------------------------------------------------ AP masks (receiver.py:21-27,109-117) */
+static const int8_t AP_CQ[29]   = {0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,1,0,0};
+static const int8_t AP_RR73[19] = {0,1, 1,1,1,1,1, 0,0,1,1,1, 0,1,0,1,0, 0,1};
+static const int8_t AP_73[19]   = {0,1, 1,1,1,1,1, 0,1,0,0,1, 0,1,0,0,0, 0,1};
+static const int8_t AP_RRR[19]  = {0,1, 1,1,1,1,1, 0,1,0,0,1, 0,0,1,0,0, 0,1};
+
+void ft8o_set_ap(const float* llr0, int ap, float* llr) {
+    memcpy(llr, llr0, sizeof(float) * 174);
+    const int8_t* pat = NULL; int b0 = 0, n = 0;
+    switch (ap) { case 1: pat = AP_CQ; b0 = 0; n = 29; break; case 2: pat = AP_RR73; b0 = 58; n = 19; break;
+                  case 3: pat = AP_73; b0 = 58; n = 19; break; case 4: pat = AP_RRR; b0 = 58; n = 19; break; default: break; }
+    for (int i = 0; i < n; i++) llr[b0 + i] = pat[i] ? 5.0f : -5.0f;
+    if (ap == 1) { llr[74] = -5.0f; llr[75] = -5.0f; llr[76] = 5.0f; llr[57] = -5.0f; llr[58] = -5.0f; }
+}
+
+/* ------------------------------------------------------------------ CRC + message validity / rendering */
+static unsigned crc14_of77(uint64_t lo, uint64_t hi) {               /* decoders.py:123-129 */
+    unsigned r = 0;
+    for (int i = 0; i < 96; i++) {
+        unsigned b = 0;
+        if (i < 77) { int pos = 76 - i; b = (unsigned)((pos >= 64 ? (hi >> (pos - 64)) : (lo >> pos)) & 1u); }
+        unsigned top = (r >> 13) & 1u;
+        r = ((r << 1) & 0x3FFFu) | b;
+        if (top) r ^= 0x2757u;
+    }
+    return r;
+}
+
+typedef struct { uint32_t h; int m; char call[16]; } hent;
+typedef struct { hent* e; int n, cap; } hashtab;
+void* ft8o_hash_new(void) { return calloc(1, sizeof(hashtab)); }
+void ft8o_hash_free(void* h) { if (h) { free(((hashtab*)h)->e); free(h); } }
+
+static void hash_add(hashtab* ht, const char* call) {               /* databases.py:10-26 */
+    if (!ht) return;
+    static const char* A = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ/";
+    char pad[12]; int L = (int)strlen(call);
+    for (int i = 0; i < 11; i++) pad[i] = (i < L) ? call[i] : ' ';
+    uint64_t x = 0;
+    for (int i = 0; i < 11; i++) { const char* q = strchr(A, pad[i]); int64_t idx = (q && pad[i]) ? (q - A) : -1; x = 38 * x + (uint64_t)idx; }
+    x = x * 47055833459ULL;
+    static const int ms[3] = {10, 12, 22};
+    for (int k = 0; k < 3; k++) {
+        if (ht->n == ht->cap) { ht->cap = ht->cap ? 2 * ht->cap : 64; ht->e = (hent*)realloc(ht->e, sizeof(hent) * (size_t)ht->cap); }
+        hent* e = &ht->e[ht->n++];
+        e->h = (uint32_t)(x >> (64 - ms[k])); e->m = ms[k];
+        strncpy(e->call, call, 15); e->call[15] = 0;
+    }
+}
+static const char* hash_get(hashtab* ht, uint32_t h, int m) {
+    if (ht) for (int i = ht->n - 1; i >= 0; i--) if (ht->e[i].m == m && ht->e[i].h == h) return ht->e[i].call;
+    return "...";
+}
+
+static int alnum36(char ch) { return (ch >= '0' && ch <= '9') ? ch - '0' : (ch >= 'A' && ch <= 'Z') ? ch - 'A' + 10 : -1; }
+
+/* decoders.py:95-115: 28-bit standard call -> text, NULL-equivalent (0) when implausible */
+static int std_call28(uint32_t c28, char* out) {
+    static const char* A0 = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ";
+    static const char* A1 = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ";
+    static const char* A3 = " ABCDEFGHIJKLMNOPQRSTUVWXYZ";
+    char ch[7];
+    int64_t nn = (int64_t)c28 - (2063592 + 4194304);
+    if (nn < 0) { strcpy(ch, "ZZ9ZZZ"); }                             /* python divmod/negative-index quirk at c28 = 6257895 */
+    else {
+        int i0 = (int)(nn / 7085880); nn %= 7085880;                   /* 36*10*27^3 */
+        int i1 = (int)(nn / 196830);  nn %= 196830;                    /* 10*27^3 */
+        int i2 = (int)(nn / 19683);   nn %= 19683;
+        int i3 = (int)(nn / 729);     nn %= 729;
+        int i4 = (int)(nn / 27);      int i5 = (int)(nn % 27);
+        ch[0] = A0[i0]; ch[1] = A1[i1]; ch[2] = (i2 < 10) ? (char)('0' + i2) : ' ';
+        ch[3] = A3[i3]; ch[4] = A3[i4]; ch[5] = A3[i5]; ch[6] = 0;
+    }
+    int a = 0, b = 6;
+    while (a < b && ch[a] == ' ') a++;
+    while (b > a && ch[b - 1] == ' ') b--;
+    int L = b - a;
+    memcpy(out, ch + a, (size_t)L); out[L] = 0;
+    if (L < 3) return 0;
+    for (int i = 0; i < L; i++) if (out[i] == ' ') return 0;
+    int d1 = out[1] >= '0' && out[1] <= '9', d2 = out[2] >= '0' && out[2] <= '9';
+    if (out[0] >= 'A' && out[0] <= 'Z' && ((FT8_PFX1_MASK >> (out[0] - 'A')) & 1u) && d1)
+        if (!(((FT8_PFX1_TRAP >> (out[0] - 'A')) & 1u) && d2)) return 1;
+    int x0 = alnum36(out[0]), x1 = alnum36(out[1]);
+    if (x0 >= 0 && x1 >= 0 && ((FT8_PFX2[x0] >> x1) & 1ULL) && d2) return 1;
+    return 0;
+}
+
+/* decoders.py:70-93.  returns 0 for None */
+static int call_29(hashtab* ht, uint32_t c29, int i3, char* out) {
+    uint32_t pr = c29 & 1u, c28 = c29 >> 1;
+    if (c28 < 3) { strcpy(out, c28 == 0 ? "DE" : c28 == 1 ? "QRZ" : "CQ"); return 1; }
+    if (c28 < 1004) { sprintf(out, "CQ %03u", c28 - 3); return 1; }
+    if (c28 < 21443) {
+        uint32_t x = c28 - 1003; char t[5]; t[4] = 0;
+        for (int i = 3; i >= 0; i--) { t[i] = " ABCDEFGHIJKLMNOPQRSTUVWXYZ"[x % 27]; x /= 27; }
+        int a = 0, b = 4; while (a < b && t[a] == ' ') a++; while (b > a && t[b - 1] == ' ') b--;
+        t[b] = 0; sprintf(out, "CQ %s", t + a); return 1;
+    }
+    if (c28 < 2063592u + 4194303u) { snprintf(out, 16, "<%.13s>", hash_get(ht, c28 - 2063592u, 22)); return 1; }
+    char call[16];
+    if (!std_call28(c28, call)) return 0;
+    if (pr) strcat(call, i3 == 2 ? "/P" : "/R");
+    size_t L = strlen(call);
+    if (L >= 2 && call[L - 2] == '/' && call[L - 1] == 'R' && !(call[0] == 'A' || call[0] == 'K' || call[0] == 'N' || call[0] == 'W')) return 0;
+    hash_add(ht, call);
+    strcpy(out, call);
+    return 1;
+}
+
+/* decoders.py:16-68.  Returns 1 and fills out[3] when unpack() yields a tuple, 0 for None.
+ * With hash == NULL it is the pure validity predicate (no side effects). */
+int ft8o_unpack77(void* hash, uint64_t lo, uint64_t hi, char out[3][16]) {
+    hashtab* ht = (hashtab*)hash;
+    char tmp[3][16];
+    if (!out) out = tmp;
+    out[0][0] = out[1][0] = out[2][0] = 0;
+    if (lo == 0 && hi == 0) return 0;
+    unsigned i3 = (unsigned)(lo & 7u);
+    if (i3 == 1 || i3 == 2) {
+        uint32_t g16 = (uint32_t)((lo >> 3) & 0xFFFFu);
+        uint32_t cb29 = (uint32_t)((lo >> 19) & 0x1FFFFFFFu);
+        uint32_t ca29 = (uint32_t)(((lo >> 48) | (hi << 16)) & 0x1FFFFFFFu);
+        uint32_t g15 = g16 & 0x7FFFu;
+        if (g15 == 0) return 0;
+        char g[16];
+        if (g15 < 32400) {
+            unsigned a = g15 / 1800, nn = g15 % 1800, b = nn / 100; nn %= 100;
+            g[0] = (char)('A' + a); g[1] = (char)('A' + b); g[2] = (char)('0' + nn / 10); g[3] = (char)('0' + nn % 10); g[4] = 0;
+        } else if (g15 - 32400 <= 4) {
+            static const char* T[5] = {"", "", "RRR", "RR73", "73"};
+            strcpy(g, T[g15 - 32400]);
+        } else {
+            int v = (int)g15 - 32435;
+            sprintf(g, "%s%+03d", (g16 >> 15) ? "R" : "", v);
+        }
+        int oka = call_29(ht, ca29, (int)i3, out[0]);
+        int okb = call_29(ht, cb29, (int)i3, out[1]);
+        strcpy(out[2], g);
+        if (!oka || !okb || g[0] == 0) return 0;
+        return 1;
+    }
+    if (i3 == 4) {
+        unsigned cq = (unsigned)((lo >> 3) & 1u), rrr = (unsigned)((lo >> 4) & 3u), swp = (unsigned)((lo >> 6) & 1u);
+        uint64_t c58 = ((lo >> 7) | (hi << 57)) & ((1ULL << 58) - 1);
+        uint32_t hsh = (uint32_t)((hi >> 1) & 0xFFFu);
+        if ((cq && rrr) || (!cq && !rrr)) return 0;
+        char ca[16], cb[16], t[13];
+        if (cq) strcpy(ca, "CQ"); else snprintf(ca, 16, "<%.13s>", hash_get(ht, hsh, 12));
+        for (int i = 11; i >= 0; i--) { t[i] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ/"[c58 % 38]; c58 /= 38; }
+        t[12] = 0;
+        int a = 0, b = 12; while (a < b && t[a] == ' ') a++; while (b > a && t[b - 1] == ' ') b--;
+        t[b] = 0; strcpy(cb, t + a);
+        hash_add(ht, cb);
+        static const char* R[4] = {"", "RRR", "RR73", "73"};
+        strcpy(out[0], swp ? cb : ca); strcpy(out[1], swp ? ca : cb); strcpy(out[2], R[rrr]);
+        return 1;
+    }
+    return 0;
+}
+
+int ft8o_valid77(uint64_t lo, uint64_t hi) { return ft8o_unpack77(NULL, lo, hi, NULL); }
+
+/* acceptance callback: called for every CRC-passing, non-zero 77-bit word in reference call order */
+typedef int (*accept_fn)(void* ctx, uint64_t lo, uint64_t hi);
+static int accept_pure(void* ctx, uint64_t lo, uint64_t hi) { (void)ctx; return ft8o_valid77(lo, hi); }
+
+/* hard bits of 91 values -> (msg, crc); decoders.py:117-131.  0: fail, 1: crc ok but unpack None, 2: accepted */
+static int crc_check_bits(const uint8_t* b91, accept_fn acc, void* ctx, uint64_t* lo_out, uint64_t* hi_out) {
+    uint64_t lo = 0, hi = 0; unsigned crc = 0;
+    for (int k = 0; k < 77; k++) if (b91[k]) { int pos = 76 - k; if (pos >= 64) hi |= 1ULL << (pos - 64); else lo |= 1ULL << pos; }
+    for (int k = 77; k < 91; k++) crc = (crc << 1) | (b91[k] ? 1u : 0u);
+    if (lo == 0 && hi == 0) return 0;
+    if (crc14_of77(lo, hi) != crc) return 0;
+    if (lo_out) { *lo_out = lo; *hi_out = hi; }
+    return acc(ctx, lo, hi) ? 2 : 1;
+}
+
+int ft8o_crc_valid91(const float* llr91, uint64_t* lo, uint64_t* hi) {
+    uint8_t b[91]; for (int k = 0; k < 91; k++) b[k] = llr91[k] > 0.0f;
+    return crc_check_bits(b, accept_pure, NULL, lo, hi);
+}
+
+/* ------------------------------------------------------------------ LDPC BP (decoders.py:140-171) */
+static int ldpc_core(float* llr, int max_nc0, int max_iters, accept_fn acc, void* ctx,
+                     uint64_t* lo, uint64_t* hi, int32_t* n_its, int32_t* has_out) {
+    float mc2v[FT8_NEDGE], newm[FT8_NEDGE], delta[FT8_NEDGE];
+    memset(mc2v, 0, sizeof(mc2v));
+    *n_its = -1; *has_out = 1;
+    for (int it = 0; it < max_iters; it++) {
+        int ncheck = 0;
+        for (int c = 0; c < 83; c++) {
+            int par = 0;
+            for (int j = 0; j < FT8_CHK_N[c]; j++) par ^= (llr[FT8_CHK_V[c][j]] > 0.0f);
+            ncheck += par;
+        }
+        if (it == 0 && ncheck > max_nc0) { *has_out = 0; return 0; }
+        if (ncheck == 0) {
+            uint8_t b[91]; for (int k = 0; k < 91; k++) b[k] = llr[k] > 0.0f;
+            int r = crc_check_bits(b, acc, ctx, lo, hi);
+            if (r == 2) { *n_its = it; *has_out = 0; return 1; }
+            /* reference does nothing this iteration => state is frozen; if the CRC passed (but unpack gave
+             * None) every remaining iteration repeats the same failing unpack call.  The repeat count is
+             * handed to the caller through n_its so the event log mirrors the reference's call sequence. */
+            *n_its = (r == 1) ? -(2 + (max_iters - 1 - it)) : -1;
+            return 0;
+        }
+        for (int c = 0; c < 83; c++) {
+            int e0 = FT8_CHK_E0[c], n = FT8_CHK_N[c];
+            float t[7], P = 0.0f;
+            for (int j = 0; j < n; j++) {
+                float v2c = llr[FT8_CHK_V[c][j]] - mc2v[e0 + j];
+                t[j] = ft8o_tanhf(-v2c);
+                P = (j == 0) ? t[0] : P * t[j];
+            }
+            for (int j = 0; j < n; j++) {
+                float e = P / t[j];
+                float nm = e / ((e - 1.18f) * (1.18f + e));
+                newm[e0 + j] = nm;
+                delta[e0 + j] = nm - mc2v[e0 + j];
+            }
+        }
+        for (int v = 0; v < 174; v++) {
+            float col = 0.0f;
+            col += delta[FT8_VAR_E[v][0]]; col += delta[FT8_VAR_E[v][1]]; col += delta[FT8_VAR_E[v][2]];
+            llr[v] += col;
+        }
+        memcpy(mc2v, newm, sizeof(mc2v));
+    }
+    return 0;
+}
+
+int ft8o_ldpc(float* llr, int max_nc0, int max_iters, uint64_t* lo, uint64_t* hi, int32_t* n_its, int32_t* has_out) {
+    return ldpc_core(llr, max_nc0, max_iters, accept_pure, NULL, lo, hi, n_its, has_out);
+}
+
+/* ------------------------------------------------------------------ OSD (decoders.py:223-272) */
+static void cw91_to_bits(const uint64_t* w, uint8_t* b91) { for (int k = 0; k < 91; k++) b91[k] = (uint8_t)((w[k >> 6] >> (k & 63)) & 1ULL); }
+
+static int osd_core(const float* llr, int singles, int doubles, accept_fn acc, void* ctx,
+                    uint64_t* lo, uint64_t* hi, int32_t* trial_out, int32_t* info_cols) {
+    /* reliability order: |llr| descending, ties (and NaNs, last) by index -- the build's fixed tie rule
+     * for np.argsort(-abs(llr)) (decoders.py:226, unstable in the reference) */
+    int order[174];
+    for (int i = 0; i < 174; i++) order[i] = i;
+    float key[174];
+    for (int i = 0; i < 174; i++) key[i] = fabsf(llr[i]);
+    for (int i = 1; i < 174; i++) {
+        int t = order[i]; float kt = key[t]; int j = i - 1;
+        /* move t before order[j] iff key[t] strictly greater (NaN never moves, non-NaN passes NaN) */
+        while (j >= 0 && ((kt > key[order[j]]) || (kt == kt && key[order[j]] != key[order[j]]))) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = t;
+    }
+    uint64_t G[91][3];
+    memcpy(G, FT8_G0, sizeof(G));
+    uint8_t used[91]; memset(used, 0, sizeof(used));
+    int prow[91], pcol[91], k = 0;
+    for (int ic = 0; ic < 174 && k < 91; ic++) {
+        int col = order[ic], w = col >> 6; uint64_t bit = 1ULL << (col & 63);
+        int piv = -1;
+        for (int r = 0; r < 91; r++) if (!used[r] && (G[r][w] & bit)) { piv = r; break; }
+        if (piv < 0) continue;
+        used[piv] = 1;
+        for (int r = 0; r < 91; r++) if (r != piv && (G[r][w] & bit)) { G[r][0] ^= G[piv][0]; G[r][1] ^= G[piv][1]; G[r][2] ^= G[piv][2]; }
+        prow[k] = piv; pcol[k] = col; k++;
+    }
+    if (info_cols) for (int i = 0; i < 91; i++) info_cols[i] = (i < k) ? pcol[i] : -1;
+    uint64_t cw0[2] = {0, 0};
+    for (int i = 0; i < k; i++) if (llr[pcol[i]] > 0.0f) { cw0[0] ^= G[prow[i]][0]; cw0[1] ^= G[prow[i]][1]; }
+    const uint64_t M1 = (1ULL << 27) - 1;
+    int trial = 0;
+    uint8_t b[91];
+    /* order-0 */
+    { uint64_t w[2] = {cw0[0], cw0[1] & M1}; cw91_to_bits(w, b);
+      if (crc_check_bits(b, acc, ctx, lo, hi) == 2) { *trial_out = trial; return 1; } }
+    trial++;
+    for (int i = 0; i < singles; i++, trial++) {
+        const uint64_t* f = G[prow[90 - i]];
+        uint64_t w[2] = {cw0[0] ^ f[0], (cw0[1] ^ f[1]) & M1}; cw91_to_bits(w, b);
+        if (crc_check_bits(b, acc, ctx, lo, hi) == 2) { *trial_out = trial; return 1; }
+    }
+    for (int i = 0; i < singles; i++) for (int j = 0; j < doubles; j++) if (j < i) {
+        const uint64_t* f = G[prow[90 - i]]; const uint64_t* g = G[prow[90 - j]];
+        uint64_t w[2] = {cw0[0] ^ f[0] ^ g[0], (cw0[1] ^ f[1] ^ g[1]) & M1}; cw91_to_bits(w, b);
+        if (crc_check_bits(b, acc, ctx, lo, hi) == 2) { *trial_out = trial; return 1; }
+        trial++;
+    }
+    *trial_out = -1;
+    return 0;
+}
+
+int ft8o_osd(const float* llr, int singles, int doubles, uint64_t* lo, uint64_t* hi, int32_t* trial, int32_t* info_cols) {
+    return osd_core(llr, singles, doubles, accept_pure, NULL, lo, hi, trial, info_cols);
+}
+
+/* ------------------------------------------------------------------ whole frame (receiver.py:68-107, 338-367, 389-398) */
+typedef struct {
+    hashtab* ht; ft8o_event* log; int32_t cap, n; int cand, ipass;
+    char last[3][16]; int repeat;
+} fctx;
+
+static int accept_frame(void* vctx, uint64_t lo, uint64_t hi) {
+    fctx* f = (fctx*)vctx;
+    int v = ft8o_unpack77(f->ht, lo, hi, f->last);
+    if (f->n < f->cap) { ft8o_event* e = &f->log[f->n]; e->msg_lo = lo; e->msg_hi = hi; e->cand = f->cand; e->ipass = f->ipass; e->valid = v; e->pad = 0; }
+    f->n++;
+    return v;
+}
+
+typedef struct { float llr0[174]; float llr[174]; float saved[5][174]; int saved_ap[5]; int n_saved; float sd_key; int ipass; } cstate;
+
+static int run_ldpc_frame(fctx* fc, float* llr, int nc0, int iters, ft8o_cand* c, int32_t* has_out) {
+    uint64_t lo, hi; int32_t nits;
+    int ok = ldpc_core(llr, nc0, iters, accept_frame, fc, &lo, &hi, &nits, has_out);
+    if (!ok && nits <= -2) {
+        /* frozen all-checks-satisfied state: the reference repeats the failing unpack each remaining iteration */
+        int rep = -nits - 2;
+        if (fc->n > 0 && fc->n <= fc->cap) { ft8o_event last = fc->log[fc->n - 1]; for (int i = 0; i < rep; i++) accept_frame(fc, last.msg_lo, last.msg_hi); }
+        else for (int i = 0; i < rep; i++) fc->n++;
+    }
+    if (ok) { c->msg_lo = lo; c->msg_hi = hi; c->n_its = nits; }
+    return ok;
+}
+
+int ft8o_decode_frame(const int16_t* audio, const ft8o_config* cfg, ft8o_cand* cands, int32_t* n_cands,
+                      ft8o_event* log, int32_t log_cap, int32_t* n_log, ft8o_msg* msgs, int32_t msg_cap, int32_t* n_msgs) {
+    float* grid = (float*)malloc(sizeof(float) * FT8O_GRID_ROWS * FT8O_GRID_COLS);
+    float* spec = NULL;
+    ft8o_cand* all = (ft8o_cand*)malloc(sizeof(ft8o_cand) * 1024);
+    ft8o_spectrogram(audio, cfg, grid);
+    int n = ft8o_sync_search(grid, cfg, all);
+    memcpy(cands, all, sizeof(ft8o_cand) * (size_t)n);
+    free(all);
+    *n_cands = n;
+    cstate* st = (cstate*)calloc((size_t)(n > 0 ? n : 1), sizeof(cstate));
+    fctx fc; memset(&fc, 0, sizeof(fc));
+    fc.ht = (hashtab*)ft8o_hash_new(); fc.log = log; fc.cap = log_cap;
+    int nm = 0;
+    char (*seen)[48] = (char (*)[48])malloc(48 * (size_t)(n > 0 ? n : 1)); int nseen = 0;
+    int* order = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int rnd = 0; rnd < 8; rnd++) {
+        int m = 0;
+        for (int i = 0; i < n; i++) if (cands[i].status == FT8O_ST_NONE) order[m++] = i;
+        for (int i = 1; i < m; i++) {                                  /* stable, llr_sd descending (receiver.py:392) */
+            int t = order[i]; int j = i - 1;
+            while (j >= 0 && st[order[j]].sd_key < st[t].sd_key) { order[j + 1] = order[j]; j--; }
+            order[j + 1] = t;
+        }
+        for (int oi = 0; oi < m; oi++) {
+            int ci = order[oi]; ft8o_cand* c = &cands[ci]; cstate* s = &st[ci];
+            int ip = s->ipass; fc.cand = ci; fc.ipass = ip;
+            int done = 0; int32_t has_out;
+            uint64_t lo, hi;
+            if (ip == 0) {
+                float p[464];
+                ft8o_payload(grid, c->f0_idx, c->h0_idx, p);
+                int ok = ft8o_db_to_llr(p, s->llr, &c->grid_sd, &c->snr_grid);
+                s->sd_key = c->grid_sd;
+                memcpy(s->llr0, s->llr, sizeof(s->llr0));
+                if (!ok) c->status = FT8O_ST_STOP_GRID_SD;
+                else for (int ap = 0; ap < 5 && !done; ap++) {
+                    ft8o_set_ap(s->llr0, ap, s->llr);
+                    uint8_t b[91]; for (int k = 0; k < 91; k++) b[k] = s->llr[k] > 0.0f;
+                    if (crc_check_bits(b, accept_frame, &fc, &lo, &hi) == 2) { done = 1; c->method = FT8O_M_GOOD91; c->ap = ap; c->msg_lo = lo; c->msg_hi = hi; c->n_its = 0; break; }
+                    if (run_ldpc_frame(&fc, s->llr, cfg->bp_nc0_a, cfg->bp_iters_a, c, &has_out)) { done = 1; c->method = FT8O_M_LDPC_A; c->ap = ap; }
+                }
+            } else if (ip == 1) {
+                if (!spec) { spec = (float*)malloc(sizeof(float) * 2 * FT8O_SPEC_BINS); ft8o_cycle_spectrum(audio, cfg, spec); }
+                float sd; int32_t snr;
+                int r = ft8o_fine(spec, cfg, c->f0_idx, c->h0_idx, &c->ttweak, &c->ftweak, &c->nsync, s->llr, &sd, &snr, NULL);
+                if (r == 0) c->status = FT8O_ST_STOP_COSTAS;
+                else { c->fine_sd = sd; c->snr_fine = snr; s->sd_key = sd; if (r < 0) c->status = FT8O_ST_STOP_FINE_SD; }
+            } else if (ip == 2) {
+                memcpy(s->llr0, s->llr, sizeof(s->llr0));
+                for (int ap = 0; ap < 2 && !done; ap++) {
+                    ft8o_set_ap(s->llr0, ap, s->llr);
+                    uint8_t b[91]; for (int k = 0; k < 91; k++) b[k] = s->llr[k] > 0.0f;
+                    if (crc_check_bits(b, accept_frame, &fc, &lo, &hi) == 2) { done = 1; c->method = FT8O_M_GOOD91; c->ap = ap; c->msg_lo = lo; c->msg_hi = hi; c->n_its = 0; }
+                }
+            } else if (ip == 3) {
+                for (int ap = 0; ap < 2 && !done; ap++) {
+                    ft8o_set_ap(s->llr0, ap, s->llr);
+                    if (run_ldpc_frame(&fc, s->llr, cfg->bp_nc0_a, cfg->bp_iters_a, c, &has_out)) { done = 1; c->method = FT8O_M_LDPC_A; c->ap = ap; }
+                }
+            } else if (ip == 4) {
+                for (int ap = 0; ap < 5 && !done; ap++) {
+                    ft8o_set_ap(s->llr0, ap, s->llr);
+                    if (run_ldpc_frame(&fc, s->llr, cfg->bp_nc0_b, cfg->bp_iters_b, c, &has_out)) { done = 1; c->method = FT8O_M_LDPC_B; c->ap = ap; }
+                    else if (has_out) { memcpy(s->saved[s->n_saved], s->llr, sizeof(s->llr)); s->saved_ap[s->n_saved++] = ap; }
+                }
+            } else if (ip == 5) {
+                for (int ap = 0; ap < 5 && !done; ap++) {
+                    ft8o_set_ap(s->llr0, ap, s->llr);
+                    int32_t trial;
+                    if (osd_core(s->llr, cfg->osd_single, cfg->osd_double, accept_frame, &fc, &lo, &hi, &trial, NULL)) {
+                        done = 1; c->method = FT8O_M_OSD; c->ap = ap; c->msg_lo = lo; c->msg_hi = hi; c->n_its = trial; }
+                }
+            } else if (ip == 6) {
+                for (int k = 0; k < s->n_saved && !done; k++) {
+                    int32_t trial;
+                    if (osd_core(s->saved[k], cfg->osd_single, cfg->osd_double, accept_frame, &fc, &lo, &hi, &trial, NULL)) {
+                        done = 1; c->method = FT8O_M_LDPC_B_OSD; c->ap = s->saved_ap[k]; c->msg_lo = lo; c->msg_hi = hi; c->n_its = trial; }
+                }
+            } else {
+                c->status = FT8O_ST_EXHAUSTED;
+            }
+            s->ipass = ip + 1;
+            if (done) {
+                c->status = FT8O_ST_DECODED; c->ipass = ip;
+                char key[48]; snprintf(key, sizeof(key), "%s %s %s", fc.last[0], fc.last[1], fc.last[2]);
+                int dup = 0; for (int i = 0; i < nseen; i++) if (!strcmp(seen[i], key)) { dup = 1; break; }
+                if (!dup) {
+                    strcpy(seen[nseen++], key);
+                    if (nm < msg_cap) {
+                        ft8o_msg* mo = &msgs[nm]; memset(mo, 0, sizeof(*mo));
+                        memcpy(mo->f, fc.last, sizeof(mo->f));
+                        mo->cand = ci; mo->fine = (ip >= 2);
+                        mo->snr = mo->fine ? c->snr_fine : c->snr_grid;
+                        mo->tsec = (double)c->h0_idx / 25.0; mo->fHz = 3.125 * (double)c->f0_idx;
+                        if (mo->fine) { mo->tsec = mo->tsec + (double)c->ttweak / 200.0; mo->fHz = mo->fHz + (double)c->ftweak / 16.0; }
+                        mo->ipass = ip; mo->ap = c->ap; mo->method = c->method;
+                        mo->ttweak = mo->fine ? c->ttweak : 0; mo->ftweak = mo->fine ? c->ftweak : 0;
+                    }
+                    nm++;
+                }
+            }
+        }
+    }
+    *n_log = fc.n; *n_msgs = nm;
+    ft8o_hash_free(fc.ht); free(grid); free(spec); free(st); free(seen); free(order);
+    return 0;
+}

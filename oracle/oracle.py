@@ -1,0 +1,238 @@
+"""ctypes binding of the CPU oracle (oracle/ft8_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libft8oracle.so")
+
+NSAMP, GRID_ROWS, GRID_COLS, SPEC_BINS = 180000, 376, 976, 49152
+
+
+class Config(C.Structure):
+    _fields_ = [("sync_score_min", C.c_float), ("max_cands", C.c_int32),
+                ("f0_lo", C.c_int32), ("f0_hi", C.c_int32), ("h0_lo", C.c_int32), ("h0_hi", C.c_int32),
+                ("bp_nc0_a", C.c_int32), ("bp_iters_a", C.c_int32), ("bp_nc0_b", C.c_int32), ("bp_iters_b", C.c_int32),
+                ("osd_single", C.c_int32), ("osd_double", C.c_int32), ("llr_sd_min", C.c_float),
+                ("plan1920", C.c_int32 * 8), ("plan3200", C.c_int32 * 8), ("plan300", C.c_int32 * 8), ("plan320", C.c_int32 * 8)]
+
+
+class Cand(C.Structure):
+    _fields_ = [("f0_idx", C.c_int32), ("h0_idx", C.c_int32), ("score", C.c_float),
+                ("grid_sd", C.c_float), ("fine_sd", C.c_float), ("snr_grid", C.c_int32), ("snr_fine", C.c_int32),
+                ("ttweak", C.c_int32), ("ftweak", C.c_int32), ("nsync", C.c_int32),
+                ("status", C.c_int32), ("ipass", C.c_int32), ("ap", C.c_int32), ("method", C.c_int32), ("n_its", C.c_int32),
+                ("msg_lo", C.c_uint64), ("msg_hi", C.c_uint64)]
+
+
+class Event(C.Structure):
+    _fields_ = [("msg_lo", C.c_uint64), ("msg_hi", C.c_uint64), ("cand", C.c_int32), ("ipass", C.c_int32),
+                ("valid", C.c_int32), ("pad", C.c_int32)]
+
+
+class Msg(C.Structure):
+    _fields_ = [("f", (C.c_char * 16) * 3), ("cand", C.c_int32), ("snr", C.c_int32), ("tsec", C.c_double), ("fHz", C.c_double),
+                ("ipass", C.c_int32), ("ap", C.c_int32), ("method", C.c_int32), ("ttweak", C.c_int32), ("ftweak", C.c_int32),
+                ("fine", C.c_int32)]
+
+
+AP_NAMES = ["NoAP", "CQ", "RR73", "73", "RRR"]
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or \
+            os.path.getmtime(LIB_PATH) < max(os.path.getmtime(os.path.join(HERE, f)) for f in ("ft8_oracle.c", "ft8_oracle.h", "ft8_tables.h")):
+        subprocess.check_call(["make", "-s", "-C", HERE])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        fp, ip, u64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)
+        L.ft8o_log10f.restype = C.c_float; L.ft8o_log10f.argtypes = [C.c_float]
+        L.ft8o_tanhf.restype = C.c_float; L.ft8o_tanhf.argtypes = [C.c_float]
+        L.ft8o_unpack77.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.ft8o_valid77.argtypes = [C.c_uint64, C.c_uint64]
+        L.ft8o_hash_new.restype = C.c_void_p
+        L.ft8o_hash_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def default_config(**kw):
+    c = Config()
+    lib().ft8o_default_config(C.byref(c))
+    for k, v in kw.items():
+        if k.startswith("plan"):
+            arr = getattr(c, k)
+            for i in range(8):
+                arr[i] = v[i] if i < len(v) else 0
+        else:
+            setattr(c, k, v)
+    return c
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def log10f(x):
+    x = np.asarray(x, np.float32)
+    L = lib()
+    return np.array([L.ft8o_log10f(float(v)) for v in x.ravel()], np.float32).reshape(x.shape)
+
+
+def tanhf(x):
+    x = np.asarray(x, np.float32)
+    L = lib()
+    return np.array([L.ft8o_tanhf(float(v)) for v in x.ravel()], np.float32).reshape(x.shape)
+
+
+def fft(x, plan):
+    x = np.ascontiguousarray(x, np.complex64).copy()
+    scr = np.empty_like(x)
+    pl = (C.c_int32 * 8)(*(list(plan) + [0] * (8 - len(plan))))
+    lib().ft8o_fft(_p(x.view(np.float32)), C.c_int(len(x)), pl, _p(scr.view(np.float32)))
+    return x
+
+
+def spectrogram(audio, cfg=None):
+    cfg = cfg or default_config()
+    audio = np.ascontiguousarray(audio, np.int16)
+    g = np.empty((GRID_ROWS, GRID_COLS), np.float32)
+    lib().ft8o_spectrogram(_p(audio, C.c_int16), C.byref(cfg), _p(g))
+    return g
+
+
+def sync_search(grid, cfg=None):
+    cfg = cfg or default_config()
+    out = (Cand * 1024)()
+    n = lib().ft8o_sync_search(_p(grid), C.byref(cfg), out)
+    return [out[i] for i in range(n)]
+
+
+def payload(grid, f0, h0):
+    p = np.empty((58, 8), np.float32)
+    lib().ft8o_payload(_p(grid), int(f0), int(h0), _p(p))
+    return p
+
+
+def db_to_llr(p):
+    p = np.ascontiguousarray(p, np.float32)
+    llr = np.empty(174, np.float32)
+    sd, snr = C.c_float(), C.c_int32()
+    ok = lib().ft8o_db_to_llr(_p(p), _p(llr), C.byref(sd), C.byref(snr))
+    return llr, sd.value, snr.value, bool(ok)
+
+
+def cycle_spectrum(audio, cfg=None):
+    cfg = cfg or default_config()
+    audio = np.ascontiguousarray(audio, np.int16)
+    s = np.empty(SPEC_BINS, np.complex64)
+    lib().ft8o_cycle_spectrum(_p(audio, C.c_int16), C.byref(cfg), _p(s.view(np.float32)))
+    return s
+
+
+def fine(spec, f0, h0, cfg=None):
+    cfg = cfg or default_config()
+    spec = np.ascontiguousarray(spec, np.complex64)
+    tt, ft, ns, snr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    sd = C.c_float()
+    llr = np.zeros(174, np.float32)
+    sg = np.zeros((79, 8), np.float32)
+    r = lib().ft8o_fine(_p(spec.view(np.float32)), C.byref(cfg), int(f0), int(h0), C.byref(tt), C.byref(ft), C.byref(ns),
+                        _p(llr), C.byref(sd), C.byref(snr), _p(sg))
+    return dict(ret=r, ttweak=tt.value, ftweak=ft.value, nsync=ns.value, llr=llr, sd=sd.value, snr=snr.value, sgrid=sg)
+
+
+def set_ap(llr0, ap):
+    llr0 = np.ascontiguousarray(llr0, np.float32)
+    out = np.empty(174, np.float32)
+    lib().ft8o_set_ap(_p(llr0), int(ap), _p(out))
+    return out
+
+
+def msg_int(lo, hi):
+    return (int(hi) << 64) | int(lo)
+
+
+def ldpc(llr, max_nc0, max_iters):
+    """-> (ok, bits77:int|None, n_its, llr_out|None)"""
+    llr = np.ascontiguousarray(llr, np.float32).copy()
+    lo, hi = C.c_uint64(), C.c_uint64()
+    nits, has = C.c_int32(), C.c_int32()
+    ok = lib().ft8o_ldpc(_p(llr), int(max_nc0), int(max_iters), C.byref(lo), C.byref(hi), C.byref(nits), C.byref(has))
+    return bool(ok), (msg_int(lo.value, hi.value) if ok else None), (nits.value if ok else -1), (llr if has.value else None)
+
+
+def osd(llr, singles=30, doubles=2):
+    llr = np.ascontiguousarray(llr, np.float32)
+    lo, hi = C.c_uint64(), C.c_uint64()
+    trial = C.c_int32()
+    cols = np.zeros(91, np.int32)
+    ok = lib().ft8o_osd(_p(llr), int(singles), int(doubles), C.byref(lo), C.byref(hi), C.byref(trial), _p(cols, C.c_int32))
+    return bool(ok), (msg_int(lo.value, hi.value) if ok else None), trial.value, cols
+
+
+def crc_valid91(llr91):
+    llr91 = np.ascontiguousarray(llr91, np.float32)
+    lo, hi = C.c_uint64(), C.c_uint64()
+    r = lib().ft8o_crc_valid91(_p(llr91), C.byref(lo), C.byref(hi))
+    return r, (msg_int(lo.value, hi.value) if r else None)
+
+
+class HashTable:
+    def __init__(self):
+        self.h = C.c_void_p(lib().ft8o_hash_new())
+
+    def unpack(self, bits77):
+        buf = ((C.c_char * 16) * 3)()
+        ok = lib().ft8o_unpack77(self.h, C.c_uint64(bits77 & (2 ** 64 - 1)), C.c_uint64(bits77 >> 64), C.byref(buf))
+        return tuple(buf[i].value.decode() for i in range(3)) if ok else None
+
+    def __del__(self):
+        try:
+            lib().ft8o_hash_free(self.h)
+        except Exception:
+            pass
+
+
+def valid77(bits77):
+    return bool(lib().ft8o_valid77(C.c_uint64(bits77 & (2 ** 64 - 1)), C.c_uint64(bits77 >> 64)))
+
+
+def decode_frame(audio, cfg=None):
+    """Whole-frame oracle decode -> dict(cands, events, msgs)."""
+    cfg = cfg or default_config()
+    audio = np.ascontiguousarray(audio, np.int16)
+    assert audio.shape == (NSAMP,)
+    cands = (Cand * max(1, cfg.max_cands))()
+    log = (Event * 4096)()
+    msgs = (Msg * 256)()
+    nc, nl, nm = C.c_int32(), C.c_int32(), C.c_int32()
+    lib().ft8o_decode_frame(_p(audio, C.c_int16), C.byref(cfg), cands, C.byref(nc), log, 4096, C.byref(nl), msgs, 256, C.byref(nm))
+    out_msgs = []
+    for i in range(min(nm.value, 256)):
+        m = msgs[i]
+        out_msgs.append(dict(msg_tuple=tuple(m.f[k].value.decode() for k in range(3)), cand=m.cand, snr=m.snr,
+                             tsec=m.tsec, fHz=m.fHz, ipass=m.ipass, ap=m.ap, method=m.method,
+                             ttweak=m.ttweak, ftweak=m.ftweak, fine=bool(m.fine)))
+    return dict(cands=[cands[i] for i in range(nc.value)],
+                events=[log[i] for i in range(min(nl.value, 4096))], n_events=nl.value, msgs=out_msgs)
+
+
+def notes_of(m):
+    """decode_notes + tweaks string exactly as the reference formats them (receiver.py:42,57,121,126,133,162)."""
+    src = "fine" if m["fine"] else "grid"
+    ap = AP_NAMES[m["ap"]]
+    meth = {0: "GOOD91 ", 1: "LDPC5", 2: "LDPC20", 3: "OSD", 4: "LDPC20_OSD"}[m["method"]]
+    tw = (" " if m["fine"] else "") + f"t:{m['ttweak']:+03d} f:{m['ftweak']:+03d}"
+    return f"{src}_{ap}_{meth}" + tw

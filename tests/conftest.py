@@ -1,0 +1,53 @@
+import json
+import os
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN_FRAMES = ["test_08", "test_09", "synth_000000", "synth_100000", "synth_200000"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ref: needs /root/reference (build container only)")
+
+
+def read_wav_i16(path):
+    with wave.open(path, "rb") as w:
+        assert w.getnchannels() == 1 and w.getsampwidth() == 2 and w.getframerate() == 12000
+        data = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    out = np.zeros(180000, dtype=np.int16)
+    out[:min(len(data), 180000)] = data[:180000]
+    return out
+
+
+_cache = {}
+
+
+def load_golden(name):
+    """-> (audio int16[180000], npz dict, json dict) for a golden frame."""
+    if name not in _cache:
+        from pyft8_amd import synth
+        g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+        with open(os.path.join(GOLDEN, name + ".json")) as f:
+            js = json.load(f)
+        m = js["meta"]
+        if m["kind"] == "wav":
+            audio = read_wav_i16(os.path.join(GOLDEN, m["file"]))
+        else:
+            audio = synth.make_frame(m["index"], n_signals=m["n_signals"], snr_range=tuple(m["snr"]))
+        _cache[name] = (audio, g, js)
+    return _cache[name]
+
+
+@pytest.fixture(params=GOLDEN_FRAMES)
+def golden(request):
+    return (request.param,) + load_golden(request.param)
