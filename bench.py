@@ -1,0 +1,173 @@
+"""bench.py -- FT8 15-s frames decoded per second on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--frames B]
+
+One "step" = one pass of the whole receive hot path (spectrogram -> Costas sync -> LLR -> cycle FFT ->
+fine sync -> LDPC BP -> OSD -> records) over one batch of B synthetic 15-s frames per GPU (BASELINE
+config 1: 50 signals/frame, -10..+10 dB).  The audio is resident in HBM before the timed region.
+Frames are independent, so ranks shard them with no data-path collective (weak scaling); the decoded
+records are gathered to rank 0 over RCCL once, outside the timed region, to validate the gather path.
+Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement" for the roofline accounting).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per frame of each kernel group (DESIGN.md / SURVEY.md 8d), N_c = 200 candidates
+ALG_BYTES = {
+    "spectrogram": 360000 + 375 * 976 * 4,                 # int16 audio in + dB grid out
+    "sync": 375 * 976 * 4,                                 # grid read
+    "topk": 928 * 8,
+    "grid_llr": 200 * 58 * 8 * 4 + 200 * 174 * 4,          # payload gather + llr out
+    "bp_grid": 200 * 174 * 4,
+    "select0": 200 * 48,
+    "cycle_fft": 360000 + 47414 * 8,                       # audio in + the spectrum bins ever read
+    "fine": 200 * 1064 * 8 + 200 * 174 * 4,                # spectrum slices + llr out
+    "bp_fine": 200 * 174 * 4 * 2,
+    "select1": 200 * 48,
+    "osd": 200 * 174 * 4,
+    "select2": 200 * 48,
+}
+ALG_BYTES_FRAME = 6025712                                  # SURVEY.md 8d total
+HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def _gen(args):
+    from pyft8_amd import synth
+    i, nsig, lo, hi = args
+    return synth.make_frame(i, n_signals=nsig, snr_range=(lo, hi))
+
+
+def make_frames(start, count, nsig=50, snr=(-10.0, 10.0)):
+    import multiprocessing as mp
+    n = min(count, max(1, min(32, (os.cpu_count() or 1))))
+    with mp.get_context("fork").Pool(n) as pool:
+        frames = pool.map(_gen, [(start + i, nsig, snr[0], snr[1]) for i in range(count)], chunksize=max(1, count // (4 * n)))
+    return np.stack(frames)
+
+
+def cpu_baseline(frames, budget_s=15.0):
+    """The CPU oracle (single thread) on a bounded sample of the same frames."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    from pyft8_amd import _lib
+    cfg = O.default_config(**_lib.fft_plans())
+    O.decode_frame(frames[0], cfg)
+    t0 = time.perf_counter()
+    n = 0
+    while n < len(frames) and time.perf_counter() - t0 < budget_s:
+        O.decode_frame(frames[n], cfg)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} frames of this rank-0 batch, oracle/ft8_oracle.c single-threaded, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 1: 256)")
+    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames generated per rank (tiled to --frames)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from pyft8_amd import _lib, messages
+    B = args.frames
+    uniq = min(args.unique, B)
+    frames = make_frames(rank * 1000000, uniq)
+    reps = (B + uniq - 1) // uniq
+    host = np.concatenate([frames] * reps)[:B]
+    d_audio = torch.from_numpy(host).cuda()
+    h = _lib.Handle(device=local, max_frames=B)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        h.enqueue(d_audio.data_ptr(), B)
+    h.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h.enqueue(d_audio.data_ptr(), B)
+    h.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # per-kernel timing (HIP events on the library's stream), outside the timed region
+    h.set_profiling(True)
+    acc = {}
+    nprof = 3
+    for _ in range(nprof):
+        h.enqueue(d_audio.data_ptr(), B)
+        h.sync()
+        for k, v in h.stage_times().items():
+            acc[k] = acc.get(k, 0.0) + v / nprof
+    h.set_profiling(False)
+    rec, cnt, ev, evc = h.fetch(B)
+    n_dec = int(sum((rec[f][:cnt[f]]["status"] == 1).sum() for f in range(B)))
+    n_msgs = sum(len(messages.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]))) for f in range(min(B, 16)))
+
+    # gather path (RCCL): per-rank fixed-capacity record blocks to rank 0 -- off the timed path
+    if world > 1:
+        blk = torch.from_numpy(rec.view(np.uint8).reshape(B, -1).copy()).cuda()
+        out = [torch.empty_like(blk) for _ in range(world)] if rank == 0 else None
+        dist.gather(blk, out, dst=0)
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        dom = max(acc, key=acc.get)
+        dom_ms = acc[dom]
+        achieved = ALG_BYTES[dom] * B / (dom_ms * 1e-3) / 1e9
+        value = world * B * args.steps / dt
+        line = {
+            "metric": "FT8 15-s frames decoded/sec", "value": value, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config 1: batch of {B} synthetic 15-s frames per GPU ({uniq} distinct, tiled), 50 signals/frame, "
+                                   "-10..+10 dB SNR, Receiver defaults (BP 5/20 iters, OSD 30/2)",
+                       "frames_per_gpu": B, "decoded_candidates_per_frame": n_dec / B,
+                       "unique_messages_first16": n_msgs, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": dom_ms, "alg_bytes_per_launch": ALG_BYTES[dom] * B,
+                         "whole_path_frac": value / world * ALG_BYTES_FRAME / 1e9 / HBM_PEAK_GBS},
+            "stage_ms": {k: round(v, 4) for k, v in acc.items()},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(frames)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    h.close()
+
+
+if __name__ == "__main__":
+    main()

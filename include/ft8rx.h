@@ -1,0 +1,132 @@
+/* ft8rx.h -- C ABI of libft8rx.so: the MI355X-native FT8 receive hot path.
+ *
+ * The reference (G1OJS/PyFT8) is pure Python and has no FFI for this path; its boundary is the
+ * Python surface of PyFT8/receiver.py + PyFT8/decoders.py.  Each entry point
+ * below names the reference interface it stands in for; pyft8_amd/{receiver,decoders}.py bind
+ * them with ctypes and re-create that Python surface.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on
+ * success and a negative code on failure (ft8rx_last_error() gives the text); nothing throws
+ * across the ABI.  One handle == one HIP device + one stream; a handle is not thread-safe,
+ * separate handles are.  All device workspaces are allocated at ft8rx_create(); the hot path
+ * allocates nothing.  Pointers are host pointers unless the parameter is named d_*.
+ */
+#ifndef FT8RX_H
+#define FT8RX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FT8RX_NSAMP      180000   /* 15 s @ 12 kHz, int16 mono (receiver.py:9-12,241) */
+#define FT8RX_GRID_ROWS  376      /* row 0 = never-written 1.0 row, rows 1..375 = hops (receiver.py:237-240) */
+#define FT8RX_GRID_COLS  976      /* receiver.py:240 */
+#define FT8RX_SPEC_BINS  49152    /* kept bins of the 192000-point cycle spectrum (receiver.py:280-286) */
+#define FT8RX_MAX_CANDS  256      /* upper bound for config.max_cands */
+#define FT8RX_EVENT_CAP  512      /* per-frame capacity of the CRC-pass event log */
+
+/* Receiver(...) kwargs (receiver.py:311-313) + module/decoder constants (receiver.py:30,78,91,95;
+ * decoders.py:223).  BASELINE "30 iters / OSD depth" extension knobs are these same fields. */
+typedef struct {
+    float   sync_score_min;          /* 85 */
+    int32_t max_cands;               /* 200 */
+    int32_t f0_lo, f0_hi;            /* 32, 960 = int(search_freq_range / 3.125) */
+    int32_t h0_lo, h0_hi;            /* -37, 87 = int((search_time_range + 0.5) * 25) */
+    int32_t bp_nc0_a, bp_iters_a;    /* 35, 5  : ldpc_decode(llr, 35, 5)  (ipass 0 and 3) */
+    int32_t bp_nc0_b, bp_iters_b;    /* 90, 20 : ldpc_decode(llr, 90, 20) (ipass 4) */
+    int32_t osd_single, osd_double;  /* 30, 2  : osd_012(llr, 30, 2) */
+    float   llr_sd_min;              /* 5 : Candidate.llr_sd_min */
+} ft8rx_config;
+
+enum { FT8RX_ST_ACTIVE = 0, FT8RX_ST_DECODED = 1, FT8RX_ST_STOP_GRID_SD = 2, FT8RX_ST_STOP_COSTAS = 3,
+       FT8RX_ST_STOP_FINE_SD = 4, FT8RX_ST_EXHAUSTED = 5 };
+enum { FT8RX_M_GOOD91 = 0, FT8RX_M_LDPC_A = 1, FT8RX_M_LDPC_B = 2, FT8RX_M_OSD = 3, FT8RX_M_LDPC_B_OSD = 4 };
+
+/* One candidate's outcome (replaces the state of a reference `Candidate`, receiver.py:29-66). 48 bytes. */
+typedef struct {
+    uint64_t msg_lo, msg_hi;         /* 77-bit payload, bit 76 = first transmitted bit; valid iff status==DECODED */
+    float    score, grid_sd, fine_sd;
+    int16_t  f0_idx, h0_idx;
+    int8_t   ttweak, ftweak, snr_grid, snr_fine;
+    uint8_t  status, ipass, ap, method;
+    int16_t  n_its;                  /* BP iteration index or OSD trial index of the success */
+    uint8_t  nsync, pad;
+    uint32_t pad2;
+} ft8rx_record;
+
+/* One CRC-14-passing, non-zero 77-bit word met on the decode ladder (= one call of the reference's
+ * unpack(), decoders.py:131).  The host replays these in reference order to reproduce the call-hash
+ * table side effects (databases.py:10-26).  24 bytes. */
+typedef struct {
+    uint64_t msg_lo, msg_hi;
+    uint16_t cand;                   /* candidate index within the frame */
+    uint8_t  ipass;                  /* ladder step the call belongs to (0..6) */
+    uint8_t  slot;                   /* attempt index inside the ipass step (AP index / saved-llr index) */
+    uint16_t seq;                    /* order inside the attempt: GOOD91=0, BP iteration+1, OSD trial */
+    uint16_t valid;                  /* unpack() would have returned a tuple */
+} ft8rx_event;
+
+typedef struct ft8rx_handle ft8rx_handle;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int  ft8rx_default_config(ft8rx_config* cfg);                       /* Receiver.__init__ defaults */
+int  ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_handle** out);
+void ft8rx_destroy(ft8rx_handle* h);
+const char* ft8rx_last_error(ft8rx_handle* h);                      /* h may be NULL: last create error */
+int  ft8rx_device_count(void);
+/* FFT radix plans the kernels use (0-terminated, <= 8 entries each): 1920, 3200, 300, 320 point */
+int  ft8rx_get_fft_plans(int32_t* p1920, int32_t* p3200, int32_t* p300, int32_t* p320);
+
+/* ---- whole hot path: audio -> candidate records ------------------------------------------
+ * Stands in for AudioIn._callback x375 + Receiver.search + the Candidate.decode ladder driven by
+ * Receiver.manage_cycle (receiver.py:295-306, 338-367, 68-107, 389-398) under frame-complete
+ * semantics, for n_frames independent 15-s frames.
+ *   records : [n_frames][cfg.max_cands]   counts : [n_frames]
+ *   events  : [n_frames][FT8RX_EVENT_CAP] event_counts : [n_frames] (may exceed the cap => truncated) */
+int  ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int n_frames,
+                        ft8rx_record* records, int32_t* counts, ft8rx_event* events, int32_t* event_counts);
+/* Same, split for throughput measurement: audio already resident in HBM (device pointer),
+ * enqueue is asynchronous on the handle's stream, fetch copies results to the host. */
+int  ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int n_frames);
+int  ft8rx_sync(ft8rx_handle* h);
+int  ft8rx_fetch_results(ft8rx_handle* h, int n_frames, ft8rx_record* records, int32_t* counts,
+                         ft8rx_event* events, int32_t* event_counts);
+/* per-kernel HIP-event timing of the most recent enqueue (enable before enqueue). names/ms: up to 16 */
+int  ft8rx_set_profiling(ft8rx_handle* h, int on);
+int  ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms);
+
+/* ---- stage entry points (parity tests; each mirrors one reference function) ---------------- */
+/* AudioIn.get_hop_spectrum x375 (receiver.py:288-293): grid [n][376][976] */
+int  ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int n_frames, float* grid);
+/* Receiver.search (receiver.py:338-367): per frame <= max_cands (f0,h0,score), sorted */
+int  ft8rx_sync_search(ft8rx_handle* h, const float* grid, int n_frames,
+                       int32_t* f0_idx, int32_t* h0_idx, float* score, int32_t* counts);
+/* Candidate._get_llr_grid/_dB_to_llr (receiver.py:136-138, 208-222) for n (frame,f0,h0) triples */
+int  ft8rx_llr_grid(ft8rx_handle* h, const float* grid, int n_frames, int n, const int32_t* frame,
+                    const int32_t* f0_idx, const int32_t* h0_idx, float* llr /*[n][174]*/, float* sd, int32_t* snr);
+/* AudioIn.get_cycle_spectrum (receiver.py:280-286): spec [n][49152] complex64 (bins 0..49151) */
+int  ft8rx_cycle_spectrum(ft8rx_handle* h, const int16_t* audio, int n_frames, float* spec);
+/* Candidate._get_llr_fine (receiver.py:140-206) for n (frame,f0,h0) triples; sgrid [n][79][8] may be NULL.
+ * ret[i]: 1 continue, 0 Costas gate failed, -1 sd gate failed */
+int  ft8rx_fine(ft8rx_handle* h, const float* spec, int n_frames, int n, const int32_t* frame,
+                const int32_t* f0_idx, const int32_t* h0_idx, int32_t* ret, int32_t* ttweak, int32_t* ftweak,
+                int32_t* nsync, float* llr, float* sd, int32_t* snr, float* sgrid);
+/* ldpc_decode(llr, max_ncheck0, max_iters) (decoders.py:153-171) on n vectors.
+ * ok[i]=1 => msg; has_out[i]=1 => llr_out[i] holds the mutated llr (the reference's third return) */
+int  ft8rx_ldpc(ft8rx_handle* h, const float* llr, int n, int max_ncheck0, int max_iters,
+                int32_t* ok, uint64_t* msg_lo, uint64_t* msg_hi, int32_t* n_its, int32_t* has_out, float* llr_out);
+/* osd_012(llr, singleflips, doubleflips) (decoders.py:223-272) on n vectors */
+int  ft8rx_osd(ft8rx_handle* h, const float* llr, int n, int singleflips, int doubleflips,
+               int32_t* ok, uint64_t* msg_lo, uint64_t* msg_hi, int32_t* trial);
+/* crc_unpack91 (decoders.py:117-131) on n x 91 soft/hard values: res 0 = no CRC, 1 = CRC ok but unpack None, 2 = tuple */
+int  ft8rx_crc_valid(ft8rx_handle* h, const float* cw91, int n, int32_t* res, uint64_t* msg_lo, uint64_t* msg_hi);
+/* unpack() validity predicate (decoders.py:16-115) on n 77-bit words */
+int  ft8rx_valid77(ft8rx_handle* h, const uint64_t* msg_lo, const uint64_t* msg_hi, int n, int32_t* valid);
+/* arithmetic-contract probes: which 0 = log10f, 1 = tanhf; 2 = forward FFT of length n (x = interleaved complex) */
+int  ft8rx_math_probe(ft8rx_handle* h, int which, const float* x, int n, float* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

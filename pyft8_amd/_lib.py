@@ -1,0 +1,273 @@
+"""ctypes binding of libft8rx.so (include/ft8rx.h).  There is NO CPU fallback: if the HIP library is
+missing or no MI355X is visible, the product raises."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libft8rx.so")
+SRC = os.path.join(HERE, "csrc", "ft8rx.hip")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result",
+               "-Wno-unused-value", "-fPIC", "-shared"]
+
+NSAMP, GRID_ROWS, GRID_COLS, SPEC_BINS, MAX_CANDS, EVENT_CAP = 180000, 376, 976, 49152, 256, 512
+
+
+class Config(C.Structure):
+    _fields_ = [("sync_score_min", C.c_float), ("max_cands", C.c_int32),
+                ("f0_lo", C.c_int32), ("f0_hi", C.c_int32), ("h0_lo", C.c_int32), ("h0_hi", C.c_int32),
+                ("bp_nc0_a", C.c_int32), ("bp_iters_a", C.c_int32), ("bp_nc0_b", C.c_int32), ("bp_iters_b", C.c_int32),
+                ("osd_single", C.c_int32), ("osd_double", C.c_int32), ("llr_sd_min", C.c_float)]
+
+
+RECORD_DTYPE = np.dtype([("msg_lo", "<u8"), ("msg_hi", "<u8"), ("score", "<f4"), ("grid_sd", "<f4"), ("fine_sd", "<f4"),
+                         ("f0_idx", "<i2"), ("h0_idx", "<i2"), ("ttweak", "i1"), ("ftweak", "i1"), ("snr_grid", "i1"),
+                         ("snr_fine", "i1"), ("status", "u1"), ("ipass", "u1"), ("ap", "u1"), ("method", "u1"),
+                         ("n_its", "<i2"), ("nsync", "u1"), ("pad", "u1"), ("pad2", "<u4")])
+EVENT_DTYPE = np.dtype([("msg_lo", "<u8"), ("msg_hi", "<u8"), ("cand", "<u2"), ("ipass", "u1"), ("slot", "u1"),
+                        ("seq", "<u2"), ("valid", "<u2")])
+assert RECORD_DTYPE.itemsize == 48 and EVENT_DTYPE.itemsize == 24
+
+ST_ACTIVE, ST_DECODED, ST_STOP_GRID_SD, ST_STOP_COSTAS, ST_STOP_FINE_SD, ST_EXHAUSTED = range(6)
+M_GOOD91, M_LDPC_A, M_LDPC_B, M_OSD, M_LDPC_B_OSD = range(5)
+
+_lib = None
+
+
+class Ft8rxError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = [SRC, os.path.join(HERE, "csrc", "ft8_dev.h"), os.path.join(HERE, "csrc", "ft8_tables.h"),
+            os.path.join(os.path.dirname(HERE), "include", "ft8rx.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(d) for d in deps):
+        cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Ft8rxError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(pyft8_amd has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.ft8rx_last_error.restype = C.c_char_p
+        L.ft8rx_last_error.argtypes = [C.c_void_p]
+        L.ft8rx_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.ft8rx_destroy.argtypes = [C.c_void_p]
+        L.ft8rx_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def default_config(**kw):
+    c = Config()
+    lib().ft8rx_default_config(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def fft_plans():
+    ps = [(C.c_int32 * 8)() for _ in range(4)]
+    lib().ft8rx_get_fft_plans(*ps)
+    names = ["plan1920", "plan3200", "plan300", "plan320"]
+    return {n: [x for x in p if x] for n, p in zip(names, ps)}
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Handle:
+    """One HIP device + stream + preallocated workspaces for up to max_frames frames."""
+
+    def __init__(self, cfg=None, device=0, max_frames=1):
+        L = lib()
+        self.cfg = cfg or default_config()
+        self.max_frames = int(max_frames)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        rc = L.ft8rx_create(C.byref(self.cfg), self.device, self.max_frames, C.byref(self._h))
+        if rc != 0:
+            raise Ft8rxError(f"ft8rx_create failed ({rc}): {L.ft8rx_last_error(None).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().ft8rx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise Ft8rxError(f"{what} failed ({rc}): {lib().ft8rx_last_error(self._h).decode()}")
+
+    # ---- whole path
+    def decode_batch(self, audio):
+        audio = np.ascontiguousarray(audio, np.int16)
+        if audio.ndim == 1:
+            audio = audio[None]
+        B = audio.shape[0]
+        assert audio.shape[1] == NSAMP
+        return self._run(audio, B)
+
+    def _alloc_out(self, B):
+        mc = self.cfg.max_cands
+        return (np.zeros((B, mc), RECORD_DTYPE), np.zeros(B, np.int32), np.zeros((B, EVENT_CAP), EVENT_DTYPE), np.zeros(B, np.int32))
+
+    def _run(self, audio, B):
+        rec, cnt, ev, evc = self._alloc_out(B)
+        rc = lib().ft8rx_decode_batch(self._h, _ptr(audio, C.c_int16), B, rec.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32),
+                                      ev.ctypes.data_as(C.c_void_p), _ptr(evc, C.c_int32))
+        self._chk(rc, "ft8rx_decode_batch")
+        return rec, cnt, ev, evc
+
+    def enqueue(self, d_audio_ptr, B):
+        self._chk(lib().ft8rx_enqueue_batch(self._h, C.c_void_p(d_audio_ptr), int(B)), "ft8rx_enqueue_batch")
+
+    def sync(self):
+        self._chk(lib().ft8rx_sync(self._h), "ft8rx_sync")
+
+    def fetch(self, B):
+        rec, cnt, ev, evc = self._alloc_out(B)
+        rc = lib().ft8rx_fetch_results(self._h, int(B), rec.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32),
+                                       ev.ctypes.data_as(C.c_void_p), _ptr(evc, C.c_int32))
+        self._chk(rc, "ft8rx_fetch_results")
+        return rec, cnt, ev, evc
+
+    def set_profiling(self, on):
+        lib().ft8rx_set_profiling(self._h, int(bool(on)))
+
+    def stage_times(self):
+        n = C.c_int()
+        names = (C.c_char_p * 24)()
+        ms = (C.c_float * 24)()
+        lib().ft8rx_get_stage_times(self._h, C.byref(n), names, ms)
+        return {names[i].decode(): ms[i] for i in range(n.value)}
+
+    # ---- stage entry points
+    def spectrogram(self, audio):
+        audio = np.ascontiguousarray(audio, np.int16)
+        if audio.ndim == 1:
+            audio = audio[None]
+        B = audio.shape[0]
+        g = np.empty((B, GRID_ROWS, GRID_COLS), np.float32)
+        self._chk(lib().ft8rx_spectrogram(self._h, _ptr(audio, C.c_int16), B, _ptr(g, C.c_float)), "ft8rx_spectrogram")
+        return g
+
+    def sync_search(self, grid):
+        grid = np.ascontiguousarray(grid, np.float32)
+        if grid.ndim == 2:
+            grid = grid[None]
+        B, mc = grid.shape[0], self.cfg.max_cands
+        f0 = np.zeros((B, mc), np.int32); h0 = np.zeros((B, mc), np.int32); sc = np.zeros((B, mc), np.float32); cnt = np.zeros(B, np.int32)
+        self._chk(lib().ft8rx_sync_search(self._h, _ptr(grid, C.c_float), B, _ptr(f0, C.c_int32), _ptr(h0, C.c_int32),
+                                          _ptr(sc, C.c_float), _ptr(cnt, C.c_int32)), "ft8rx_sync_search")
+        return f0, h0, sc, cnt
+
+    def llr_grid(self, grid, frame, f0, h0):
+        grid = np.ascontiguousarray(grid, np.float32)
+        if grid.ndim == 2:
+            grid = grid[None]
+        frame, f0, h0 = (np.ascontiguousarray(x, np.int32) for x in (frame, f0, h0))
+        n = len(f0)
+        llr = np.zeros((n, 174), np.float32); sd = np.zeros(n, np.float32); snr = np.zeros(n, np.int32)
+        self._chk(lib().ft8rx_llr_grid(self._h, _ptr(grid, C.c_float), grid.shape[0], n, _ptr(frame, C.c_int32), _ptr(f0, C.c_int32),
+                                       _ptr(h0, C.c_int32), _ptr(llr, C.c_float), _ptr(sd, C.c_float), _ptr(snr, C.c_int32)), "ft8rx_llr_grid")
+        return llr, sd, snr
+
+    def cycle_spectrum(self, audio):
+        audio = np.ascontiguousarray(audio, np.int16)
+        if audio.ndim == 1:
+            audio = audio[None]
+        B = audio.shape[0]
+        s = np.empty((B, SPEC_BINS), np.complex64)
+        self._chk(lib().ft8rx_cycle_spectrum(self._h, _ptr(audio, C.c_int16), B, s.ctypes.data_as(C.POINTER(C.c_float))), "ft8rx_cycle_spectrum")
+        return s
+
+    def fine(self, spec, frame, f0, h0, want_sgrid=False):
+        spec = np.ascontiguousarray(spec, np.complex64)
+        if spec.ndim == 1:
+            spec = spec[None]
+        frame, f0, h0 = (np.ascontiguousarray(x, np.int32) for x in (frame, f0, h0))
+        n = len(f0)
+        ret, tt, ft, ns, snr = (np.zeros(n, np.int32) for _ in range(5))
+        llr = np.zeros((n, 174), np.float32); sd = np.zeros(n, np.float32)
+        sg = np.zeros((n, 79, 8), np.float32) if want_sgrid else None
+        self._chk(lib().ft8rx_fine(self._h, spec.ctypes.data_as(C.POINTER(C.c_float)), spec.shape[0], n, _ptr(frame, C.c_int32),
+                                   _ptr(f0, C.c_int32), _ptr(h0, C.c_int32), _ptr(ret, C.c_int32), _ptr(tt, C.c_int32), _ptr(ft, C.c_int32),
+                                   _ptr(ns, C.c_int32), _ptr(llr, C.c_float), _ptr(sd, C.c_float), _ptr(snr, C.c_int32),
+                                   _ptr(sg, C.c_float) if want_sgrid else None), "ft8rx_fine")
+        return dict(ret=ret, ttweak=tt, ftweak=ft, nsync=ns, llr=llr, sd=sd, snr=snr, sgrid=sg)
+
+    def ldpc(self, llr, max_ncheck0, max_iters):
+        llr = np.ascontiguousarray(llr, np.float32).reshape(-1, 174)
+        n = len(llr)
+        ok, nits, has = (np.zeros(n, np.int32) for _ in range(3))
+        lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        out = np.zeros((n, 174), np.float32)
+        self._chk(lib().ft8rx_ldpc(self._h, _ptr(llr, C.c_float), n, int(max_ncheck0), int(max_iters), _ptr(ok, C.c_int32),
+                                   _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), _ptr(nits, C.c_int32), _ptr(has, C.c_int32),
+                                   _ptr(out, C.c_float)), "ft8rx_ldpc")
+        return ok, lo, hi, nits, has, out
+
+    def osd(self, llr, singleflips=30, doubleflips=2):
+        llr = np.ascontiguousarray(llr, np.float32).reshape(-1, 174)
+        n = len(llr)
+        ok, trial = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        self._chk(lib().ft8rx_osd(self._h, _ptr(llr, C.c_float), n, int(singleflips), int(doubleflips), _ptr(ok, C.c_int32),
+                                  _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), _ptr(trial, C.c_int32)), "ft8rx_osd")
+        return ok, lo, hi, trial
+
+    def crc_valid(self, cw91):
+        cw91 = np.ascontiguousarray(cw91, np.float32).reshape(-1, 91)
+        n = len(cw91)
+        res = np.zeros(n, np.int32); lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        self._chk(lib().ft8rx_crc_valid(self._h, _ptr(cw91, C.c_float), n, _ptr(res, C.c_int32), _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64)), "ft8rx_crc_valid")
+        return res, lo, hi
+
+    def valid77(self, bits):
+        lo = np.array([b & (2 ** 64 - 1) for b in bits], np.uint64)
+        hi = np.array([b >> 64 for b in bits], np.uint64)
+        out = np.zeros(len(lo), np.int32)
+        self._chk(lib().ft8rx_valid77(self._h, _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), len(lo), _ptr(out, C.c_int32)), "ft8rx_valid77")
+        return out
+
+    def math_probe(self, which, x):
+        if which == 2:
+            x = np.ascontiguousarray(x, np.complex64)
+            y = np.empty_like(x)
+            self._chk(lib().ft8rx_math_probe(self._h, 2, x.ctypes.data_as(C.POINTER(C.c_float)), len(x), y.ctypes.data_as(C.POINTER(C.c_float))), "ft8rx_math_probe")
+            return y
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        self._chk(lib().ft8rx_math_probe(self._h, int(which), _ptr(x, C.c_float), x.size, _ptr(y, C.c_float)), "ft8rx_math_probe")
+        return y
+
+
+_default = {}
+
+
+def default_handle(max_frames=1):
+    """Process-wide handle used by the function-style API in decoders.py."""
+    h = _default.get("h")
+    if h is None or h.max_frames < max_frames:
+        if h is not None:
+            h.close()
+        h = Handle(max_frames=max_frames)
+        _default["h"] = h
+    return h

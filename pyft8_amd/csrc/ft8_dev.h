@@ -1,0 +1,250 @@
+// ft8_dev.h -- device-side building blocks for the gfx950 FT8 receive kernels.
+//
+// Arithmetic contract: plain IEEE-754 fp32/fp64, no FMA contraction (-ffp-contract=off), correctly
+// rounded divide/sqrt (hipcc default), operation order written out explicitly.  DESIGN.md lists the
+// contract; the CPU oracle states the same formulas independently, which is what makes the parity
+// tests bit-exact.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ft8_tables.h"
+
+typedef float2 cpx;
+
+#define FT8_DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------ elementary math
+FT8_DEV float ft8_log10f(float x) {
+    if (!(x > 0.0f)) return (x == 0.0f) ? -__builtin_inff() : __builtin_nanf("");
+    if (x > 3.0e38f) return __builtin_inff();
+    uint32_t ix = __float_as_uint(x);
+    int e = 0;
+    if (ix < 0x00800000u) { x = x * 8388608.0f; ix = __float_as_uint(x); e = -23; }
+    e += (int)(ix >> 23) - 127;
+    float m = __uint_as_float((ix & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.11111111f;
+    p = p * s2 + 0.14285715f;
+    p = p * s2 + 0.2f;
+    p = p * s2 + 0.33333334f;
+    p = p * s2 + 1.0f;
+    float lnm = (2.0f * s) * p;
+    float fe = (float)e;
+    return fe * 0.301025390625f + (fe * 4.6050390e-6f + lnm * 0.4342945f);
+}
+
+FT8_DEV float ft8_tanhf(float x) {
+    if (x != x) return x;
+    float ax = __builtin_fabsf(x), r;
+    if (ax < 1.0f) {
+        float x2 = ax * ax;
+        float num = ((x2 + 378.0f) * x2 + 17325.0f) * x2 + 135135.0f;
+        float den = ((28.0f * x2 + 3150.0f) * x2 + 62370.0f) * x2 + 135135.0f;
+        r = (ax * num) / den;
+    } else {
+        float y = 2.0f * ax;
+        if (y > 20.0f) y = 20.0f;
+        int k = (int)(y * 1.442695041f + 0.5f);
+        float fk = (float)k;
+        float t = (y - fk * 0.693359375f) - fk * (-2.12194440e-4f);
+        float p = 1.9841270e-4f;
+        p = p * t + 1.3888889e-3f;
+        p = p * t + 8.3333333e-3f;
+        p = p * t + 4.1666667e-2f;
+        p = p * t + 1.6666667e-1f;
+        p = p * t + 0.5f;
+        p = p * t + 1.0f;
+        p = p * t + 1.0f;
+        float E = p * __uint_as_float((uint32_t)(k + 127) << 23);
+        r = 1.0f - 2.0f / (E + 1.0f);
+    }
+    return (x < 0.0f) ? -r : r;
+}
+
+// ------------------------------------------------------------------------------------ complex helpers / DFT primitives
+FT8_DEV cpx cmul(cpx a, cpx w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+FT8_DEV cpx cadd(cpx a, cpx b) { return make_float2(a.x + b.x, a.y + b.y); }
+FT8_DEV cpx csub(cpx a, cpx b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+template <int R> FT8_DEV void dft(cpx* a);
+template <> FT8_DEV void dft<2>(cpx* a) { cpx t = a[0]; a[0] = cadd(t, a[1]); a[1] = csub(t, a[1]); }
+template <> FT8_DEV void dft<3>(cpx* a) {
+    cpx t1 = cadd(a[1], a[2]), t2 = csub(a[1], a[2]);
+    cpx m = make_float2(a[0].x + (-0.5f) * t1.x, a[0].y + (-0.5f) * t1.y);
+    cpx n = make_float2(0.86602540f * t2.x, 0.86602540f * t2.y);
+    a[0] = cadd(a[0], t1);
+    a[1] = make_float2(m.x + n.y, m.y - n.x);
+    a[2] = make_float2(m.x - n.y, m.y + n.x);
+}
+template <> FT8_DEV void dft<4>(cpx* a) {
+    cpx t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]), t2 = cadd(a[1], a[3]), t3 = csub(a[1], a[3]);
+    a[0] = cadd(t0, t2); a[2] = csub(t0, t2);
+    a[1] = make_float2(t1.x + t3.y, t1.y - t3.x);
+    a[3] = make_float2(t1.x - t3.y, t1.y + t3.x);
+}
+template <> FT8_DEV void dft<5>(cpx* a) {
+    const float c1 = 0.30901699f, c2 = -0.80901699f, s1 = 0.95105652f, s2 = 0.58778525f;
+    cpx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+    cpx m1 = make_float2((a[0].x + c1 * t1.x) + c2 * t2.x, (a[0].y + c1 * t1.y) + c2 * t2.y);
+    cpx m2 = make_float2((a[0].x + c2 * t1.x) + c1 * t2.x, (a[0].y + c2 * t1.y) + c1 * t2.y);
+    cpx n1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    cpx n2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    cpx t5 = cadd(t1, t2);
+    a[0] = cadd(a[0], t5);
+    a[1] = make_float2(m1.x + n1.y, m1.y - n1.x);
+    a[4] = make_float2(m1.x - n1.y, m1.y + n1.x);
+    a[2] = make_float2(m2.x + n2.y, m2.y - n2.x);
+    a[3] = make_float2(m2.x - n2.y, m2.y + n2.x);
+}
+template <> FT8_DEV void dft<8>(cpx* a) {
+    const float h = 0.70710678f;
+    cpx e[4] = {a[0], a[2], a[4], a[6]}, o[4] = {a[1], a[3], a[5], a[7]};
+    dft<4>(e); dft<4>(o);
+    cpx o1 = make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+    cpx o2 = make_float2(o[2].y, -o[2].x);
+    cpx o3 = make_float2(h * (o[3].y - o[3].x), -(h * (o[3].x + o[3].y)));
+    a[0] = cadd(e[0], o[0]); a[4] = csub(e[0], o[0]);
+    a[1] = cadd(e[1], o1);   a[5] = csub(e[1], o1);
+    a[2] = cadd(e[2], o2);   a[6] = csub(e[2], o2);
+    a[3] = cadd(e[3], o3);   a[7] = csub(e[3], o3);
+}
+
+// ------------------------------------------------------------------------------------ LDS Stockham FFT
+// Decimation-in-frequency autosort passes over NSEQ independent length-N sequences laid out
+// back to back in LDS.  pass(R): m = n/R; butterfly (p,q): a_j = x[q + s(p + j m)],
+// y[q + s(R p + j)] = DFT_R(a)_j * W_N^{j p s}.  Compile-time n, s => index math by constants.
+template <int N, int n, int s, int R>
+FT8_DEV void fft_pass(const cpx* __restrict__ src, cpx* __restrict__ dst, const cpx* __restrict__ W,
+                      int nseq, int tid, int nthreads) {
+    constexpr int m = n / R;
+    constexpr int nb = N / R;
+    const int total = nb * nseq;
+    for (int b = tid; b < total; b += nthreads) {
+        const int seq = b / nb, bb = b - seq * nb;
+        const int p = bb / s, q = bb - p * s;
+        const cpx* x = src + seq * N;
+        cpx* y = dst + seq * N;
+        cpx a[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) a[j] = x[q + s * (p + j * m)];
+        dft<R>(a);
+        y[q + s * (R * p)] = a[0];
+#pragma unroll
+        for (int j = 1; j < R; j++) {
+            cpx v = a[j];
+            if (m > 1 && p != 0) v = cmul(v, W[j * p * s]);
+            y[q + s * (R * p + j)] = v;
+        }
+    }
+}
+
+template <int N, int n, int s, int... Rs> struct FftPasses;
+template <int N, int n, int s> struct FftPasses<N, n, s> {
+    static FT8_DEV cpx* run(cpx* src, cpx*, const cpx*, int, int, int) { return src; }
+};
+template <int N, int n, int s, int R, int... Rest> struct FftPasses<N, n, s, R, Rest...> {
+    static FT8_DEV cpx* run(cpx* src, cpx* dst, const cpx* W, int nseq, int tid, int nthreads) {
+        fft_pass<N, n, s, R>(src, dst, W, nseq, tid, nthreads);
+        __syncthreads();
+        return FftPasses<N, n / R, s * R, Rest...>::run(dst, src, W, nseq, tid, nthreads);
+    }
+};
+// Runs the whole plan; returns the buffer that holds the result (data must be visible, i.e. the
+// caller has synchronised after filling `a`).
+template <int N, int... Rs>
+FT8_DEV cpx* lds_fft(cpx* a, cpx* b, const cpx* W, int nseq, int tid, int nthreads) {
+    return FftPasses<N, N, 1, Rs...>::run(a, b, W, nseq, tid, nthreads);
+}
+
+// ------------------------------------------------------------------------------------ CRC-14 and message validity
+FT8_DEV unsigned ft8_crc14(uint64_t lo, uint64_t hi) {                      // reference decoders.py:123-129
+    unsigned r = 0;
+    for (int i = 0; i < 96; i++) {
+        unsigned b = 0;
+        if (i < 77) { int pos = 76 - i; b = (unsigned)((pos >= 64 ? (hi >> (pos - 64)) : (lo >> pos)) & 1u); }
+        unsigned top = (r >> 13) & 1u;
+        r = ((r << 1) & 0x3FFFu) | b;
+        if (top) r ^= 0x2757u;
+    }
+    return r;
+}
+
+// 28-bit standard callsign plausibility (reference decoders.py:95-115); first = first character after strip
+FT8_DEV bool ft8_std_call_ok(uint32_t c28, char* first) {
+    int64_t nn = (int64_t)c28 - (2063592 + 4194304);
+    int ch[6];   // character codes: 0 = space, 1..10 digits, 11..36 letters
+    if (nn < 0) { ch[0] = 36; ch[1] = 36; ch[2] = 10; ch[3] = 36; ch[4] = 36; ch[5] = 36; }   // "ZZ9ZZZ" quirk
+    else {
+        int i0 = (int)(nn / 7085880); nn %= 7085880;
+        int i1 = (int)(nn / 196830);  nn %= 196830;
+        int i2 = (int)(nn / 19683);   nn %= 19683;
+        int i3 = (int)(nn / 729);     nn %= 729;
+        int i4 = (int)(nn / 27);      int i5 = (int)(nn % 27);
+        ch[0] = i0;                               // ' ' + digits + letters
+        ch[1] = i1 + 1;                           // digits + letters
+        ch[2] = (i2 < 10) ? i2 + 1 : 0;           // digits + 17 spaces
+        ch[3] = i3 ? i3 + 10 : 0; ch[4] = i4 ? i4 + 10 : 0; ch[5] = i5 ? i5 + 10 : 0;   // ' ' + letters
+    }
+    int a = 0, b = 6;
+    while (a < b && ch[a] == 0) a++;
+    while (b > a && ch[b - 1] == 0) b--;
+    int L = b - a;
+    if (L < 3) return false;
+    for (int i = a; i < b; i++) if (ch[i] == 0) return false;
+    int c0 = ch[a], c1 = ch[a + 1], c2 = ch[a + 2];
+    *first = (c0 >= 11) ? (char)('A' + c0 - 11) : (char)('0' + c0 - 1);
+    bool d1 = (c1 >= 1 && c1 <= 10), d2 = (c2 >= 1 && c2 <= 10);
+    if (c0 >= 11 && ((FT8_PFX1_MASK >> (c0 - 11)) & 1u) && d1)
+        if (!(((FT8_PFX1_TRAP >> (c0 - 11)) & 1u) && d2)) return true;
+    if (((FT8_PFX2[c0 - 1] >> (c1 - 1)) & 1ULL) && d2) return true;
+    return false;
+}
+
+FT8_DEV bool ft8_call29_ok(uint32_t c29, int i3) {                            // reference decoders.py:70-93
+    uint32_t pr = c29 & 1u, c28 = c29 >> 1;
+    if (c28 < 2063592u + 4194303u) return true;          // tokens, CQ nnn, CQ xxxx, hashed calls: always a string
+    char first;
+    if (!ft8_std_call_ok(c28, &first)) return false;
+    if (pr && i3 != 2 && !(first == 'A' || first == 'K' || first == 'N' || first == 'W')) return false;   // '/R' rule
+    return true;
+}
+
+// unpack() returns a tuple?  (reference decoders.py:16-68)
+FT8_DEV bool ft8_valid77(uint64_t lo, uint64_t hi) {
+    if (lo == 0 && hi == 0) return false;
+    unsigned i3 = (unsigned)(lo & 7u);
+    if (i3 == 1 || i3 == 2) {
+        uint32_t g16 = (uint32_t)((lo >> 3) & 0xFFFFu);
+        uint32_t cb29 = (uint32_t)((lo >> 19) & 0x1FFFFFFFu);
+        uint32_t ca29 = (uint32_t)(((lo >> 48) | (hi << 16)) & 0x1FFFFFFFu);
+        uint32_t g15 = g16 & 0x7FFFu;
+        if (g15 == 0) return false;
+        if (g15 == 32400 || g15 == 32401) return false;   // '' grid => tuple contains '' (decoders.py:62,67)
+        return ft8_call29_ok(ca29, (int)i3) && ft8_call29_ok(cb29, (int)i3);
+    }
+    if (i3 == 4) {
+        unsigned cq = (unsigned)((lo >> 3) & 1u), rrr = (unsigned)((lo >> 4) & 3u);
+        return !((cq && rrr) || (!cq && !rrr));
+    }
+    return false;
+}
+
+// 91 hard bits given as two ballots (b0: codeword bits 0..63, b1: bits 64..90, LSB = lowest index)
+// -> 77-bit message (bit 76 = codeword bit 0) and the received CRC field
+FT8_DEV void ft8_cw_to_msg(uint64_t b0, uint64_t b1, uint64_t* lo, uint64_t* hi, unsigned* crc) {
+    uint64_t r0 = __brevll(b0), r1 = __brevll(b1);
+    *hi = r0 >> 51;
+    *lo = (r0 << 13) | (r1 >> 51);
+    *crc = (unsigned)((r1 >> 37) & 0x3FFFu);
+}
+
+// 0 = no CRC match (or all-zero message), 1 = CRC ok but unpack() -> None, 2 = accepted
+FT8_DEV int ft8_crc_check(uint64_t b0, uint64_t b1, uint64_t* lo, uint64_t* hi) {
+    unsigned crc;
+    ft8_cw_to_msg(b0, b1, lo, hi, &crc);
+    if (*lo == 0 && *hi == 0) return 0;
+    if (ft8_crc14(*lo, *hi) != crc) return 0;
+    return ft8_valid77(*lo, *hi) ? 2 : 1;
+}

@@ -1,0 +1,1262 @@
+// ft8rx.hip -- MI355X (gfx950) FT8 receive hot path: HIP kernels + the C ABI of include/ft8rx.h.
+//
+// Pipeline for a batch of B independent 15-s frames (all stream-ordered on one HIP stream, no host
+// round trips; frames are the batch dimension, candidates the second one):
+//   k_spectrogram  (hop, frame)         Hann * 3840-pt real FFT (1920-pt complex Stockham in LDS) -> dB grid
+//   k_sync         (16-f0 tile, frame)  Costas correlation over all time offsets from an LDS tile
+//   k_topk         (frame)              threshold + stable top-K (bitonic sort in LDS)
+//   k_grid_llr     (candidate)          payload gather -> max-log LLRs -> sigma normalisation
+//   k_bp           (candidate, AP)      one wavefront: GOOD91 + flooding BP, ballot parity, LDS exchange
+//   k_select0      (candidate)          first success in ladder order
+//   k_cyc_a/b/c    (tile, frame)        192000-pt real FFT as 300x320 four-step + real split
+//   k_fine         (candidate)          9x(slice/taper/3200-pt IFFT) + 32-pt DFT scoring, Costas gate, LLRs
+//   k_bp           (candidate, AP)      GOOD91 + BP(90,20) with saved outputs
+//   k_select1, k_osd (candidate, slot) one wavefront: rank sort, register-resident GF(2) Gauss-Jordan
+//                                       with ballot pivoting, lane-per-trial CRC-14 + validity, k_select2
+// Reference line citations are to PyFT8/receiver.py and PyFT8/decoders.py (see include/ft8rx.h).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/ft8rx.h"
+#include "ft8_dev.h"
+
+#define MAXC FT8RX_MAX_CANDS
+#define NF0MAX 1024
+
+// ------------------------------------------------------------------------------------ device tables
+struct Tables {
+    const float* win;        // [3840] Hann (np.hanning) as f32
+    const cpx* W1920;        // twiddles
+    const cpx* WR3840;       // [976] real-split twiddles e^{-2 pi i k/3840}
+    const cpx* W3200;
+    const cpx* W96000;
+    const cpx* W300;
+    const cpx* W320;
+    const cpx* WR192k;       // [49152]
+    const cpx* W32;
+    const double* taper;     // [100]
+};
+
+__device__ __constant__ int d_COSTAS[7] = {3, 1, 4, 0, 6, 5, 2};
+__device__ __constant__ uint8_t d_PAYSYM[58] = {7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,
+    43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71};
+// AP masks (reference receiver.py:21-27), copied verbatim as data
+__device__ __constant__ int8_t d_AP_CQ[29]   = {0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,1,0,0};
+__device__ __constant__ int8_t d_AP_END[3][19] = {{0,1, 1,1,1,1,1, 0,0,1,1,1, 0,1,0,1,0, 0,1},
+                                                  {0,1, 1,1,1,1,1, 0,1,0,0,1, 0,1,0,0,0, 0,1},
+                                                  {0,1, 1,1,1,1,1, 0,1,0,0,1, 0,0,1,0,0, 0,1}};
+// LDPC tables in device memory (copies of ft8_tables.h)
+__device__ uint8_t  d_CHK_N[83];
+__device__ int16_t  d_CHK_V[83][7];
+__device__ uint16_t d_CHK_E0[83];
+__device__ uint8_t  d_EDGE_V[522];
+__device__ uint8_t  d_EDGE_C[522];
+__device__ uint16_t d_VAR_E[174][3];
+__device__ uint64_t d_G0[91][3];
+
+struct Att {               // one decode attempt's outcome
+    uint64_t lo, hi;
+    int16_t n_its;
+    uint8_t ok;            // 1 = accepted
+    uint8_t method;        // FT8RX_M_*
+    uint8_t nc0;           // initial unsatisfied-check count (BP)
+    uint8_t has_out;       // BP left a 174-vector behind (the reference's third return value)
+    uint8_t pad[2];
+};
+
+static const double W6_HOST = (double)(-0.16666667163372040f);
+#define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */
+
+// grid row accessor with the reference's modulo-750 wrap (receiver.py:240,347,360)
+FT8_DEV float grid_at(const float* __restrict__ g, int row, int col) {
+    row %= 750; if (row < 0) row += 750;
+    if (row >= 1 && row <= 375) return g[row * FT8RX_GRID_COLS + col];
+    return 1.0f;
+}
+
+FT8_DEV void log_event(ft8rx_event* ev, int32_t* evcount, int frame, int cand, int ipass, int slot, int seq,
+                       uint64_t lo, uint64_t hi, int valid) {
+    if (!ev) return;
+    int idx = atomicAdd(&evcount[frame], 1);
+    if (idx < FT8RX_EVENT_CAP) {
+        ft8rx_event e; e.msg_lo = lo; e.msg_hi = hi; e.cand = (uint16_t)cand; e.ipass = (uint8_t)ipass;
+        e.slot = (uint8_t)slot; e.seq = (uint16_t)seq; e.valid = (uint16_t)valid;
+        ev[(size_t)frame * FT8RX_EVENT_CAP + idx] = e;
+    }
+}
+
+// ------------------------------------------------------------------------------------ K1 spectrogram
+__global__ __launch_bounds__(256) void k_spectrogram(const int16_t* __restrict__ audio, float* __restrict__ grid, Tables T) {
+    __shared__ cpx bufA[1920];
+    __shared__ cpx bufB[1920];
+    const int hop = blockIdx.x + 1, f = blockIdx.y, tid = threadIdx.x;
+    const int16_t* a = audio + (size_t)f * FT8RX_NSAMP;
+    const int base = 480 * hop - 3840;
+    for (int m = tid; m < 1920; m += 256) {
+        int i0 = base + 2 * m;
+        float x0 = 0.0f, x1 = 0.0f;
+        if (i0 >= 0) {
+            short2 v = *reinterpret_cast<const short2*>(a + i0);
+            x0 = (float)v.x * T.win[2 * m]; x1 = (float)v.y * T.win[2 * m + 1];
+        }
+        bufA[m] = make_float2(x0, x1);
+    }
+    __syncthreads();
+    cpx* z = lds_fft<1920, 8, 8, 5, 3, 2>(bufA, bufB, T.W1920, 1, tid, 256);
+    float* out = grid + ((size_t)f * FT8RX_GRID_ROWS + hop) * FT8RX_GRID_COLS;
+    for (int k = tid; k < FT8RX_GRID_COLS; k += 256) {
+        cpx p = z[k], q = z[(1920 - k) % 1920];
+        float er = 0.5f * (p.x + q.x), ei = 0.5f * (p.y - q.y);
+        float orr = 0.5f * (p.y + q.y), oi = 0.5f * (q.x - p.x);
+        cpx w = T.WR3840[k];
+        float xr = er + (w.x * orr - w.y * oi);
+        float xi = ei + (w.x * oi + w.y * orr);
+        float mag = sqrtf(xr * xr + xi * xi);
+        out[k] = 20.0f * ft8_log10f(mag + 1e-12f);
+    }
+}
+
+__global__ void k_fill_row0(float* grid, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * FT8RX_GRID_COLS) grid[(size_t)(i / FT8RX_GRID_COLS) * FT8RX_GRID_ROWS * FT8RX_GRID_COLS + (i % FT8RX_GRID_COLS)] = 1.0f;
+}
+
+// ------------------------------------------------------------------------------------ K2 sync search
+// block = 16 consecutive f0 of one frame; LDS tile = every grid row any h0 can touch x 29 columns.
+__global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, float* __restrict__ best_score,
+                                              int32_t* __restrict__ best_h0, ft8rx_config cfg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nh0 = cfg.h0_hi - cfg.h0_lo;
+    const int nrows = nh0 + 24;
+    float* tile = reinterpret_cast<float*>(smem);                 // [nrows][29]
+    float* redS = tile + nrows * 29;                              // [256]
+    int* redH = reinterpret_cast<int*>(redS + 256);               // [256]
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int f0base = cfg.f0_lo + 16 * blockIdx.x;
+    const int rlo = cfg.h0_lo + 148;
+    const float* g = grid + (size_t)f * FT8RX_GRID_ROWS * FT8RX_GRID_COLS;
+    for (int i = tid; i < nrows * 29; i += 256) {
+        int r = i / 29, c = i - r * 29;
+        int col = f0base + c;
+        tile[i] = (col < FT8RX_GRID_COLS) ? grid_at(g, rlo + r, col) : 0.0f;
+    }
+    __syncthreads();
+    const int f0l = tid & 15;
+    float best = 0.0f; int bh = 0;
+    for (int hi = tid >> 4; hi < nh0; hi += 16) {
+        double s1 = 0.0, tsum = 0.0;
+#pragma unroll
+        for (int s = 0; s < 7; s++) {
+            const float* row = tile + (hi + 4 * s) * 29 + f0l;
+            double t = 0.0;
+#pragma unroll
+            for (int b = 0; b < 14; b++) t += (double)row[b];
+            tsum += t;
+            const int c = d_COSTAS[s];
+            s1 += (double)row[2 * c] + (double)row[2 * c + 1];
+        }
+        float score = (float)(s1 + W6 * (tsum - s1));
+        if (score > best) { best = score; bh = cfg.h0_lo + hi; }      // ascending h0 => first strict maximum
+    }
+    redS[tid] = best; redH[tid] = bh;
+    __syncthreads();
+    if (tid < 16) {
+        float bs = 0.0f; int h = 0;
+        for (int gI = 0; gI < 16; gI++) {
+            float s = redS[tid + 16 * gI]; int hh = redH[tid + 16 * gI];
+            if (s > bs || (s == bs && s > 0.0f && hh < h)) { bs = s; h = hh; }
+        }
+        int f0 = f0base + tid;
+        if (f0 < cfg.f0_hi) {
+            best_score[(size_t)f * NF0MAX + (f0 - cfg.f0_lo)] = bs;
+            best_h0[(size_t)f * NF0MAX + (f0 - cfg.f0_lo)] = h;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ K3 top-K
+// threshold, stable sort by score descending (ties: f0 ascending = original order), keep max_cands
+__global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ best_score, const int32_t* __restrict__ best_h0,
+                                               ft8rx_record* __restrict__ rec, int32_t* __restrict__ ncand, ft8rx_config cfg) {
+    __shared__ uint64_t key[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int nf0 = cfg.f0_hi - cfg.f0_lo;
+    uint64_t k = ~0ull;
+    if (tid < nf0) {
+        float s = best_score[(size_t)f * NF0MAX + tid];
+        if (s > cfg.sync_score_min) k = ((uint64_t)(~__float_as_uint(s)) << 32) | (uint32_t)tid;   // s > 0: bit pattern is monotonic
+    }
+    key[tid] = k;
+    __syncthreads();
+    for (int size = 2; size <= 1024; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            int partner = tid ^ stride;
+            if (partner > tid) {
+                uint64_t a = key[tid], b = key[partner];
+                bool up = ((tid & size) == 0);
+                if ((a > b) == up) { key[tid] = b; key[partner] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    uint64_t kk = key[tid];
+    int cnt = __syncthreads_count(kk != ~0ull);
+    if (tid == 0) ncand[f] = cnt < cfg.max_cands ? cnt : cfg.max_cands;
+    if (tid < cfg.max_cands) {
+        ft8rx_record r; memset(&r, 0, sizeof(r));
+        if (kk != ~0ull) {
+            int i = (int)(kk & 0xffffffffu);
+            r.f0_idx = (int16_t)(cfg.f0_lo + i);
+            r.h0_idx = (int16_t)best_h0[(size_t)f * NF0MAX + i];
+            r.score = __uint_as_float(~(uint32_t)(kk >> 32));
+            r.status = FT8RX_ST_ACTIVE; r.ipass = 0xff;
+        } else r.status = FT8RX_ST_EXHAUSTED;
+        rec[(size_t)f * MAXC + tid] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------ LLR extraction (receiver.py:208-222)
+// p[464] dB values in LDS -> normalised llr[174] in LDS `llr`.  Every thread of the block must call this
+// (it contains block barriers); only the threads with active==true (exactly one wavefront, lane = its
+// lane id) do the work.  sd/snr are returned to the active lanes.
+FT8_DEV void llr_from_p(const float* p, float* llr, float* sq, int lane, bool active, float* sd_out, int* snr_out) {
+    float sd = 0.0f; int snr = 0;
+    if (active) {
+        float pmax = -__builtin_inff(), pmin = __builtin_inff();
+        for (int i = lane; i < 464; i += 64) { float v = p[i]; if (v > pmax) pmax = v; if (v < pmin) pmin = v; }
+        for (int o = 32; o > 0; o >>= 1) {
+            float a = __shfl_xor(pmax, o), b = __shfl_xor(pmin, o);
+            if (a > pmax) pmax = a;
+            if (b < pmin) pmin = b;
+        }
+        float d = (pmax - pmin) - 58.0f;
+        snr = (int)d; if (snr < -24) snr = -24; if (snr > 24) snr = 24;
+        if (lane < 58) {
+            const float* q = p + 8 * lane;
+            float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
+#define MAX4(a, b, c, d) ({ float _m = (a); if ((b) > _m) _m = (b); if ((c) > _m) _m = (c); if ((d) > _m) _m = (d); _m; })
+            float la = MAX4(q4, q5, q6, q7) - MAX4(q0, q1, q2, q3);
+            float lb = MAX4(q2, q3, q4, q7) - MAX4(q0, q1, q5, q6);
+            float lc = MAX4(q1, q2, q6, q7) - MAX4(q0, q3, q4, q5);
+#undef MAX4
+            llr[3 * lane] = la; llr[3 * lane + 1] = lb; llr[3 * lane + 2] = lc;
+            sq[3 * lane] = la * la; sq[3 * lane + 1] = lb * lb; sq[3 * lane + 2] = lc * lc;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        // numpy pairwise float32 sums of llr (lanes 0..15) and llr^2 (lanes 16..31): n=174 -> blocks [0,80) and [80,174)
+        const float* arr = (lane & 16) ? sq : llr;
+        const int j = lane & 7, half = (lane >> 3) & 1;
+        const int base = half ? 80 : 0, nblk = half ? 88 : 80;
+        float r = arr[base + j];
+        for (int i = 8; i < nblk; i += 8) r += arr[base + i + j];
+        r = r + __shfl_xor(r, 1);
+        r = r + __shfl_xor(r, 2);
+        r = r + __shfl_xor(r, 4);
+        if (half) for (int i = 88; i < 94; i++) r += arr[80 + i];
+        float tot_l = __shfl(r, 0) + __shfl(r, 8);
+        float tot_s = __shfl(r, 16) + __shfl(r, 24);
+        float mean = tot_l / 174.0f;
+        float var = tot_s / 174.0f - mean * mean;
+        sd = sqrtf(var);
+    }
+    __syncthreads();
+    if (active) for (int i = lane; i < 174; i += 64) llr[i] = (2.83f * llr[i]) / sd;
+    __syncthreads();
+    *sd_out = sd; *snr_out = snr;
+}
+
+// block of 64 = one candidate (or one test triple when `trip` is given)
+__global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid, ft8rx_record* __restrict__ rec,
+                                                 const int32_t* __restrict__ ncand, float* __restrict__ llr0,
+                                                 ft8rx_config cfg, const int32_t* __restrict__ trip, float* __restrict__ t_sd,
+                                                 int32_t* __restrict__ t_snr) {
+    __shared__ float p[464];
+    __shared__ float llr[174];
+    __shared__ float sq[174];
+    const int lane = threadIdx.x;
+    int frame, ci, f0, h0;
+    if (trip) { frame = trip[3 * blockIdx.x]; f0 = trip[3 * blockIdx.x + 1]; h0 = trip[3 * blockIdx.x + 2]; ci = 0; }
+    else {
+        frame = blockIdx.x / MAXC; ci = blockIdx.x % MAXC;
+        if (ci >= ncand[frame]) return;
+        const ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
+        f0 = r.f0_idx; h0 = r.h0_idx;
+    }
+    const float* g = grid + (size_t)frame * FT8RX_GRID_ROWS * FT8RX_GRID_COLS;
+    for (int i = lane; i < 464; i += 64) {
+        int s = i >> 3, t = i & 7;
+        p[i] = grid_at(g, h0 + 4 + 4 * (int)d_PAYSYM[s], f0 + 1 + 2 * t);        // receiver.py:358-362
+    }
+    __syncthreads();
+    float sd; int snr;
+    llr_from_p(p, llr, sq, lane, true, &sd, &snr);
+    float* out = llr0 + (size_t)blockIdx.x * 174;
+    for (int i = lane; i < 174; i += 64) out[i] = llr[i];
+    if (lane == 0) {
+        if (trip) { t_sd[blockIdx.x] = sd; t_snr[blockIdx.x] = snr; }
+        else {
+            ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
+            r.grid_sd = sd; r.snr_grid = (int8_t)snr;
+            if (sd <= cfg.llr_sd_min) r.status = FT8RX_ST_STOP_GRID_SD;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ AP masks (receiver.py:109-117)
+FT8_DEV float ap_value(int ap, int i, float v) {
+    if (ap == 1) {
+        if (i < 29) return d_AP_CQ[i] ? 5.0f : -5.0f;
+        if (i == 74 || i == 75 || i == 57 || i == 58) return -5.0f;
+        if (i == 76) return 5.0f;
+    } else if (ap >= 2) {
+        if (i >= 58 && i < 77) return d_AP_END[ap - 2][i - 58] ? 5.0f : -5.0f;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------ LDPC belief propagation
+// One wavefront per (candidate, AP) -- or per test vector.  Edge-parallel tanh / message update
+// (lane l owns edges l, l+64, ...), check-parallel products, variable-parallel accumulation in the
+// reference's np.add.at order; everything exchanged through LDS; parity via __ballot.
+// mode 0: pipeline ipass 0 (GOOD91 then BP(nc0_a, iters_a)), mode 1: pipeline fine stage
+// (GOOD91 for ap<2, BP(nc0_b, iters_b), save output llr), mode 2: raw vectors (tests).
+__global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ llr_in, ft8rx_record* __restrict__ rec,
+                                           const int32_t* __restrict__ ncand, Att* __restrict__ attG, Att* __restrict__ attB,
+                                           float* __restrict__ saved, ft8rx_event* ev, int32_t* evcount, ft8rx_config cfg,
+                                           int max_nc0, int max_iters) {
+    __shared__ float llr[176];
+    __shared__ float tl[528];
+    __shared__ float dl[528];
+    __shared__ float P[84];
+    const int lane = threadIdx.x;
+    int frame = 0, ci = 0, ap = 0; size_t vec;
+    if (mode == 2) vec = blockIdx.x;
+    else {
+        ap = blockIdx.x % 5; int c = blockIdx.x / 5; frame = c / MAXC; ci = c % MAXC;
+        if (ci >= ncand[frame]) return;
+        if (rec[(size_t)frame * MAXC + ci].status != FT8RX_ST_ACTIVE) return;
+        vec = (size_t)c;
+    }
+    for (int i = lane; i < 174; i += 64) llr[i] = ap_value(ap, i, llr_in[vec * 174 + i]);
+    __syncthreads();
+    Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
+    Att resG; memset(&resG, 0, sizeof(resG)); resG.n_its = -1;
+    const int ipG = (mode == 0) ? 0 : 2;
+    // ---- GOOD91: CRC on the hard decisions of llr[:91] (receiver.py:119-122)
+    bool doneG = false;
+    if (mode == 0 || (mode == 1 && ap < 2)) {
+        uint64_t b0 = __ballot(llr[lane] > 0.0f);
+        uint64_t b1 = __ballot(lane < 27 && llr[64 + (lane < 27 ? lane : 0)] > 0.0f);
+        uint64_t lo, hi;
+        int r = ft8_crc_check(b0, b1, &lo, &hi);
+        if (r) { if (lane == 0) log_event(ev, evcount, frame, ci, ipG, ap, 0, lo, hi, r == 2); }
+        if (r == 2) { resG.ok = 1; resG.lo = lo; resG.hi = hi; resG.n_its = 0; resG.method = FT8RX_M_GOOD91; doneG = true; }
+    }
+    // per-lane static tables
+    int ev_[9], ec_[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { int e = lane + 64 * i; ev_[i] = (e < 522) ? d_EDGE_V[e] : 0; ec_[i] = (e < 522) ? d_EDGE_C[e] : 0; }
+    const int c0 = lane, c1 = lane + 64;
+    const int n0 = d_CHK_N[c0], e00 = d_CHK_E0[c0];
+    const int n1 = (c1 < 83) ? d_CHK_N[c1] : 0, e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
+    float mc[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) mc[i] = 0.0f;
+    bool run_bp = !(mode == 0 && doneG);       // ipass 0: the BP of this AP is only reached if GOOD91 failed
+    res.has_out = 1;
+    if (run_bp) for (int it = 0; it < max_iters; it++) {
+        // parity of every check from the hard decisions
+        int par0 = 0, par1 = 0;
+        for (int j = 0; j < n0; j++) par0 ^= (llr[d_CHK_V[c0][j]] > 0.0f) ? 1 : 0;
+        for (int j = 0; j < n1; j++) par1 ^= (llr[d_CHK_V[c1][j]] > 0.0f) ? 1 : 0;
+        int ncheck = __popcll(__ballot(par0)) + __popcll(__ballot(par1));
+        if (it == 0) { res.nc0 = (uint8_t)ncheck; if (ncheck > max_nc0) { res.has_out = 0; break; } }
+        if (ncheck == 0) {
+            uint64_t b0 = __ballot(llr[lane] > 0.0f);
+            uint64_t b1 = __ballot(lane < 27 && llr[64 + (lane < 27 ? lane : 0)] > 0.0f);
+            uint64_t lo, hi;
+            int r = ft8_crc_check(b0, b1, &lo, &hi);
+            if (r) {
+                int ipass = (mode == 0) ? 0 : ((ap < 2 && res.nc0 <= cfg.bp_nc0_a && it < cfg.bp_iters_a) ? 3 : 4);
+                if (lane == 0) log_event(ev, evcount, frame, ci, ipass, ap, it + 1, lo, hi, r == 2);
+            }
+            if (r == 2) { res.ok = 1; res.lo = lo; res.hi = hi; res.n_its = (int16_t)it; res.has_out = 0; }
+            break;      // success, or frozen state: the reference changes nothing from here on (decoders.py:161-164)
+        }
+        float tt[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int e = lane + 64 * i;
+            if (e < 522) { float v2c = llr[ev_[i]] - mc[i]; tt[i] = ft8_tanhf(-v2c); tl[e] = tt[i]; }
+        }
+        __syncthreads();
+        {
+            float Pp = tl[e00];
+            for (int j = 1; j < n0; j++) Pp = Pp * tl[e00 + j];
+            P[c0] = Pp;
+            if (c1 < 83) { float Q = tl[e01]; for (int j = 1; j < n1; j++) Q = Q * tl[e01 + j]; P[c1] = Q; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int e = lane + 64 * i;
+            if (e < 522) {
+                float ee = P[ec_[i]] / tt[i];
+                float nm = ee / ((ee - 1.18f) * (1.18f + ee));
+                dl[e] = nm - mc[i];
+                mc[i] = nm;
+            }
+        }
+        __syncthreads();
+        for (int v = lane; v < 174; v += 64) {
+            float col = 0.0f;
+            col += dl[d_VAR_E[v][0]]; col += dl[d_VAR_E[v][1]]; col += dl[d_VAR_E[v][2]];
+            llr[v] += col;
+        }
+        __syncthreads();
+    }
+    else res.has_out = 0;
+    if (res.ok) res.method = (mode == 0) ? FT8RX_M_LDPC_A : FT8RX_M_LDPC_B;
+    if (mode == 2) {
+        if (lane == 0) attB[vec] = res;
+        if (res.has_out) for (int i = lane; i < 174; i += 64) saved[vec * 174 + i] = llr[i];
+        return;
+    }
+    if (mode == 0) { if (lane == 0) attB[vec * 5 + ap] = doneG ? resG : res; return; }
+    if (lane == 0) { attB[vec * 5 + ap] = res; if (ap < 2) attG[vec * 2 + ap] = resG; }
+    if (res.has_out) for (int i = lane; i < 174; i += 64) saved[(vec * 5 + ap) * 174 + i] = llr[i];
+}
+
+// first success in ladder order after ipass 0 (receiver.py:72-78)
+__global__ void k_select0(ft8rx_record* rec, const int32_t* ncand, const Att* att0, int B) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B * MAXC) return;
+    int frame = c / MAXC, ci = c % MAXC;
+    if (ci >= ncand[frame]) return;
+    ft8rx_record& r = rec[c];
+    if (r.status != FT8RX_ST_ACTIVE) return;
+    for (int ap = 0; ap < 5; ap++) {
+        const Att& a = att0[(size_t)c * 5 + ap];
+        if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 0; r.ap = (uint8_t)ap; r.method = a.method; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+}
+
+// first success among ipass 2 (GOOD91 ap0,1), 3 (BP_A ap0,1 derived from the BP_B run), 4 (BP_B ap0..4)
+__global__ void k_select1(ft8rx_record* rec, const int32_t* ncand, const Att* attG, const Att* attB, int B, ft8rx_config cfg) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B * MAXC) return;
+    int frame = c / MAXC, ci = c % MAXC;
+    if (ci >= ncand[frame]) return;
+    ft8rx_record& r = rec[c];
+    if (r.status != FT8RX_ST_ACTIVE) return;
+    for (int ap = 0; ap < 2; ap++) {
+        const Att& a = attG[(size_t)c * 2 + ap];
+        if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 2; r.ap = (uint8_t)ap; r.method = FT8RX_M_GOOD91; r.n_its = 0; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+    for (int ap = 0; ap < 2; ap++) {
+        const Att& a = attB[(size_t)c * 5 + ap];
+        if (a.ok && a.nc0 <= cfg.bp_nc0_a && a.n_its < cfg.bp_iters_a) {
+            r.status = FT8RX_ST_DECODED; r.ipass = 3; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_A; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+    for (int ap = 0; ap < 5; ap++) {
+        const Att& a = attB[(size_t)c * 5 + ap];
+        if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 4; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_B; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+}
+
+// ipass 5 (OSD on llr0+AP, slots 0..4) then ipass 6 (OSD on the saved BP outputs, slots 5..9)
+__global__ void k_select2(ft8rx_record* rec, const int32_t* ncand, const Att* attO, int B) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B * MAXC) return;
+    int frame = c / MAXC, ci = c % MAXC;
+    if (ci >= ncand[frame]) return;
+    ft8rx_record& r = rec[c];
+    if (r.status != FT8RX_ST_ACTIVE) return;
+    for (int s = 0; s < 10; s++) {
+        const Att& a = attO[(size_t)c * 10 + s];
+        if (a.ok) {
+            r.status = FT8RX_ST_DECODED; r.ipass = (s < 5) ? 5 : 6; r.ap = (uint8_t)(s % 5);
+            r.method = (s < 5) ? FT8RX_M_OSD : FT8RX_M_LDPC_B_OSD; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+    r.status = FT8RX_ST_EXHAUSTED;
+}
+
+// ------------------------------------------------------------------------------------ cycle spectrum: 192000-pt real FFT
+// z[m] = x[2m] + i x[2m+1], 96000 = 300 x 320 four-step, then the real split for bins < 49152.
+__global__ __launch_bounds__(256) void k_cyc_a(const int16_t* __restrict__ audio, cpx* __restrict__ A, Tables T) {
+    __shared__ cpx bufA[8 * 300];
+    __shared__ cpx bufB[8 * 300];
+    const int f = blockIdx.y, tid = threadIdx.x, n2b = 8 * blockIdx.x;
+    const int16_t* a = audio + (size_t)f * FT8RX_NSAMP;
+    for (int i = tid; i < 2400; i += 256) {
+        int c = i & 7, n1 = i >> 3;
+        int m = 320 * n1 + n2b + c;
+        float re = 0.0f, im = 0.0f;
+        if (2 * m < FT8RX_NSAMP) { short2 v = *reinterpret_cast<const short2*>(a + 2 * m); re = (float)v.x; im = (float)v.y; }
+        bufA[c * 300 + n1] = make_float2(re, im);
+    }
+    __syncthreads();
+    cpx* r = lds_fft<300, 5, 5, 4, 3>(bufA, bufB, T.W300, 8, tid, 256);
+    cpx* out = A + (size_t)f * 96000;
+    for (int i = tid; i < 2400; i += 256) {
+        int c = i & 7, k1 = i >> 3, n2 = n2b + c;
+        cpx v = r[c * 300 + k1];
+        if (n2 * k1 != 0) v = cmul(v, T.W96000[n2 * k1]);
+        out[k1 * 320 + n2] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cyc_b(const cpx* __restrict__ A, cpx* __restrict__ Z, Tables T) {
+    __shared__ cpx bufA[4 * 320];
+    __shared__ cpx bufB[4 * 320];
+    const int f = blockIdx.y, tid = threadIdx.x, k1b = 4 * blockIdx.x;
+    const cpx* in = A + (size_t)f * 96000 + (size_t)k1b * 320;
+    for (int i = tid; i < 1280; i += 256) bufA[i] = in[i];
+    __syncthreads();
+    cpx* r = lds_fft<320, 8, 8, 5>(bufA, bufB, T.W320, 4, tid, 256);
+    cpx* out = Z + (size_t)f * 96000;
+    for (int i = tid; i < 1280; i += 256) {
+        int rr = i & 3, k2 = i >> 2;
+        out[(k1b + rr) + 300 * k2] = r[rr * 320 + k2];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cyc_c(const cpx* __restrict__ Z, cpx* __restrict__ spec, Tables T) {
+    const int f = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    const cpx* z = Z + (size_t)f * 96000;
+    cpx p = z[k], q = z[(96000 - k) % 96000];
+    float er = 0.5f * (p.x + q.x), ei = 0.5f * (p.y - q.y);
+    float orr = 0.5f * (p.y + q.y), oi = 0.5f * (q.x - p.x);
+    cpx w = T.WR192k[k];
+    spec[(size_t)f * FT8RX_SPEC_BINS + k] = make_float2(er + (w.x * orr - w.y * oi), ei + (w.x * oi + w.y * orr));
+}
+
+// ------------------------------------------------------------------------------------ fine time/frequency sync (receiver.py:140-206)
+// One 256-thread block per candidate.  z = 3200-sample baseband series in LDS.
+FT8_DEV void fine_build_fft(const cpx* __restrict__ S, int fb, cpx* zA, cpx* zB, const Tables& T, int tid, cpx** zres) {
+    for (int k = tid; k < 3200; k += 256) {
+        cpx v = make_float2(0.0f, 0.0f);
+        if (k < 850) {
+            v = S[fb + k];
+            if (k >= 750) { double t = T.taper[k - 750]; v.x = (float)((double)v.x * t); v.y = (float)((double)v.y * t); }
+            v.y = -v.y;
+        } else if (k >= 3050) {
+            int j = k - 3050;
+            v = S[fb - 150 + j];
+            if (j < 100) { double t = T.taper[j]; v.x = (float)((double)v.x * t); v.y = (float)((double)v.y * t); }
+            v.y = -v.y;
+        }
+        zA[k] = v;
+    }
+    __syncthreads();
+    cpx* r = lds_fft<3200, 8, 4, 4, 5, 5>(zA, zB, T.W3200, 1, tid, 256);
+    const float inv = 0.0003125f;
+    for (int k = tid; k < 3200; k += 256) { cpx v = r[k]; r[k] = make_float2(v.x * inv, -(v.y * inv)); }
+    __syncthreads();
+    *zres = r;
+}
+
+FT8_DEV float fine_mag(const cpx* z, const cpx* W32, int tb, int s, int t) {
+    int i0 = tb + 32 * s; if (i0 < 0) i0 = 0; if (i0 > 3168) i0 = 3168;
+    cpx acc = make_float2(0.0f, 0.0f);
+#pragma unroll 8
+    for (int n = 0; n < 32; n++) acc = cadd(acc, cmul(z[i0 + n], W32[(n * t) & 31]));
+    return sqrtf(acc.x * acc.x + acc.y * acc.y);
+}
+
+FT8_DEV float fine_score_from(const float* mg /*[7][7]*/) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int a = 0; a < 7; a++) for (int b = 0; b < 7; b++) { if (b == d_COSTAS[a]) s1 += (double)mg[a * 7 + b]; else s2 += (double)mg[a * 7 + b]; }
+    return (float)(s1 + W6 * s2);
+}
+
+__global__ __launch_bounds__(256) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
+                                              const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
+                                              const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
+                                              float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx* zA = reinterpret_cast<cpx*>(smem);
+    cpx* zB = zA + 3200;
+    float* mg = reinterpret_cast<float*>(zB + 3200);   // [8][49] magnitudes, later [79][8] grid
+    float* p = mg + 640;                               // [464]
+    float* llr = p + 464;                              // [176]
+    float* sq = llr + 176;                             // [176]
+    float* sc = sq + 176;                              // [16] scores
+    int* ish = reinterpret_cast<int*>(sc + 16);        // [4]
+    __shared__ cpx w32[32];
+    const int tid = threadIdx.x;
+    int frame, ci = 0, f0, h0;
+    if (trip) { frame = trip[3 * blockIdx.x]; f0 = trip[3 * blockIdx.x + 1]; h0 = trip[3 * blockIdx.x + 2]; }
+    else {
+        frame = blockIdx.x / MAXC; ci = blockIdx.x % MAXC;
+        if (ci >= ncand[frame]) return;
+        const ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
+        if (r.status != FT8RX_ST_ACTIVE) return;
+        f0 = r.f0_idx; h0 = r.h0_idx;
+    }
+    if (tid < 32) w32[tid] = T.W32[tid];
+    const cpx* S = spec + (size_t)frame * FT8RX_SPEC_BINS;
+    const int fb0 = 50 * f0;
+    const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);
+    cpx* z;
+    // --- time tweaks at ftweak 0: range(-8,8,2)
+    fine_build_fft(S, fb0, zA, zB, T, tid, &z);
+    for (int i = tid; i < 8 * 49; i += 256) {
+        int ti = i / 49, ab = i - ti * 49, a = ab / 7, b = ab - a * 7;
+        mg[i] = fine_mag(z, w32, tb0 - 8 + 2 * ti, 36 + a, b);
+    }
+    __syncthreads();
+    if (tid < 8) sc[tid] = fine_score_from(mg + 49 * tid);
+    __syncthreads();
+    if (tid == 0) {
+        int bi = 0; float best = sc[0];
+        for (int i = 1; i < 8; i++) if (sc[i] > best) { best = sc[i]; bi = i; }
+        ish[0] = -8 + 2 * bi; sc[8] = best;
+    }
+    __syncthreads();
+    const int tt = ish[0];
+    const float score_f0 = sc[8];
+    // --- frequency tweaks: range(-32,33,8)
+    float best = 0.0f; int ft = 0, last_ft = 0;
+    for (int i = 0; i < 9; i++) {
+        int fcur = -32 + 8 * i;
+        float s;
+        if (fcur == 0) s = score_f0;             // same series, same offset: identical value
+        else {
+            fine_build_fft(S, fb0 + fcur, zA, zB, T, tid, &z);
+            last_ft = fcur;
+            if (tid < 49) { int a = tid / 7, b = tid - a * 7; mg[tid] = fine_mag(z, w32, tb0 + tt, 36 + a, b); }
+            __syncthreads();
+            if (tid == 0) sc[9] = fine_score_from(mg);
+            __syncthreads();
+            s = sc[9];
+            __syncthreads();
+        }
+        if (i == 0 || s > best) { best = s; ft = fcur; }
+    }
+    if (ft != last_ft) fine_build_fft(S, fb0 + ft, zA, zB, T, tid, &z);
+    for (int i = tid; i < 632; i += 256) mg[i] = fine_mag(z, w32, tb0 + tt, i >> 3, i & 7);
+    __syncthreads();
+    // --- Costas gate (receiver.py:164-167)
+    bool match = false;
+    if (tid < 21) {
+        int blk = tid / 7, a = tid - blk * 7;
+        const float* q = mg + 8 * (36 * blk + a);
+        int am = 0; for (int t = 1; t < 8; t++) if (q[t] > q[am]) am = t;
+        match = (am == d_COSTAS[a]);
+    }
+    if (tid < 64) { int nm = __popcll(__ballot(match)); if (tid == 0) ish[1] = nm; }
+    __syncthreads();
+    const int nsync = ish[1];
+    if (trip && t_sgrid) for (int i = tid; i < 632; i += 256) t_sgrid[(size_t)blockIdx.x * 632 + i] = mg[i];
+    int ret = 1; float sd = 0.0f; int snr = 0;
+    if (nsync <= 6) ret = 0;           // block-uniform
+    else {
+        for (int i = tid; i < 464; i += 256) p[i] = 20.0f * ft8_log10f(mg[8 * (int)d_PAYSYM[i >> 3] + (i & 7)]);   // receiver.py:170
+        __syncthreads();
+        llr_from_p(p, llr, sq, tid, tid < 64, &sd, &snr);
+        if (tid == 0) { sc[10] = sd; ish[2] = snr; }
+        __syncthreads();
+        sd = sc[10]; snr = ish[2];
+        if (sd <= cfg.llr_sd_min) ret = -1;
+        float* out = llr0 + (size_t)blockIdx.x * 174;
+        for (int i = tid; i < 174; i += 256) out[i] = llr[i];
+    }
+    if (tid == 0) {
+        if (trip) { int32_t* o = t_out + 5 * (size_t)blockIdx.x; o[0] = ret; o[1] = tt; o[2] = ft; o[3] = nsync; o[4] = snr; t_sd[blockIdx.x] = sd; }
+        else {
+            ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
+            r.ttweak = (int8_t)tt; r.ftweak = (int8_t)ft; r.nsync = (uint8_t)nsync;
+            if (ret == 0) r.status = FT8RX_ST_STOP_COSTAS;
+            else { r.fine_sd = sd; r.snr_fine = (int8_t)snr; if (ret < 0) r.status = FT8RX_ST_STOP_FINE_SD; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ OSD (decoders.py:223-272)
+// One wavefront per attempt.  Lane r holds generator row r (and row 64+r for r<27) in registers.
+FT8_DEV uint64_t shfl64(uint64_t v, int src) {
+    uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+FT8_DEV uint64_t xor_reduce64(uint64_t v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)(v >> 32), o);
+        v ^= ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+#define OSD_MAXTRIALS 512
+// mode 0: pipeline (work = (candidate, slot 0..9)); mode 2: raw vectors
+__global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,
+                                            const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,
+                                            const int32_t* __restrict__ ncand, Att* __restrict__ attO,
+                                            ft8rx_event* ev, int32_t* evcount, int singles, int doubles) {
+    __shared__ float llr[176];
+    __shared__ uint8_t order[176];
+    __shared__ uint64_t flip[64][2];
+    __shared__ int16_t tri[OSD_MAXTRIALS][2];
+    __shared__ int ntr_s;
+    const int lane = threadIdx.x;
+    int frame = 0, ci = 0, slot = 0; size_t vec = blockIdx.x;
+    if (mode == 0) {
+        slot = blockIdx.x % 10; int c = blockIdx.x / 10; frame = c / MAXC; ci = c % MAXC;
+        if (ci >= ncand[frame]) return;
+        if (rec[(size_t)frame * MAXC + ci].status != FT8RX_ST_ACTIVE) return;
+        if (slot < 5) { for (int i = lane; i < 174; i += 64) llr[i] = ap_value(slot, i, llr_in[(size_t)c * 174 + i]); }
+        else {
+            if (!attB[(size_t)c * 5 + (slot - 5)].has_out) { if (lane == 0) { Att a; memset(&a, 0, sizeof(a)); a.n_its = -1; attO[(size_t)c * 10 + slot] = a; } return; }
+            for (int i = lane; i < 174; i += 64) llr[i] = saved[((size_t)c * 5 + (slot - 5)) * 174 + i];
+        }
+        vec = (size_t)c * 10 + slot;
+    } else {
+        for (int i = lane; i < 174; i += 64) llr[i] = llr_in[vec * 174 + i];
+    }
+    if (lane == 0) {     // trial list in the reference's order: order-0, singles, restricted doubles
+        int n = 0;
+        tri[n][0] = -1; tri[n][1] = -1; n++;
+        for (int i = 0; i < singles && n < OSD_MAXTRIALS; i++) { tri[n][0] = (int16_t)i; tri[n][1] = -1; n++; }
+        for (int i = 0; i < singles; i++) for (int j = 0; j < doubles; j++) if (j < i && n < OSD_MAXTRIALS) { tri[n][0] = (int16_t)i; tri[n][1] = (int16_t)j; n++; }
+        ntr_s = n;
+    }
+    __syncthreads();
+    // ---- reliability order: |llr| descending, ties and NaNs (last) by index (fixed rule for np.argsort, decoders.py:226)
+    for (int i = lane; i < 174; i += 64) {
+        float ki = __builtin_fabsf(llr[i]); bool ni = (ki != ki);
+        int rank = 0;
+        for (int j = 0; j < 174; j++) {
+            float kj = __builtin_fabsf(llr[j]); bool nj = (kj != kj);
+            bool before;
+            if (ni) before = nj ? (j < i) : true;
+            else before = nj ? false : ((kj > ki) || (kj == ki && j < i));
+            rank += before ? 1 : 0;
+        }
+        order[rank] = (uint8_t)i;
+    }
+    __syncthreads();
+    // ---- Gauss-Jordan over GF(2), most-reliable-basis selection
+    uint64_t a0 = d_G0[lane][0], a1 = d_G0[lane][1], a2 = d_G0[lane][2];
+    const bool hasB = lane < 27;
+    uint64_t b0 = hasB ? d_G0[64 + lane][0] : 0, b1 = hasB ? d_G0[64 + lane][1] : 0, b2 = hasB ? d_G0[64 + lane][2] : 0;
+    bool usedA = false, usedB = !hasB;
+    int kA = -1, kB = -1; bool hardA = false, hardB = false;
+    int k = 0;
+    for (int ic = 0; ic < 174 && k < 91; ic++) {
+        const int col = order[ic], w = col >> 6, sh = col & 63;
+        const uint64_t wa = (w == 0) ? a0 : (w == 1) ? a1 : a2;
+        const uint64_t wb = (w == 0) ? b0 : (w == 1) ? b1 : b2;
+        const bool bitA = (wa >> sh) & 1ull, bitB = (wb >> sh) & 1ull;
+        const uint64_t mA = __ballot(bitA && !usedA), mB = __ballot(bitB && !usedB);
+        if (!mA && !mB) continue;
+        const bool inA = (mA != 0);
+        const int src = inA ? __builtin_ctzll(mA) : __builtin_ctzll(mB);
+        const uint64_t p0 = shfl64(inA ? a0 : b0, src), p1 = shfl64(inA ? a1 : b1, src), p2 = shfl64(inA ? a2 : b2, src);
+        const bool isPivA = inA && lane == src, isPivB = !inA && lane == src;
+        if (bitA && !isPivA) { a0 ^= p0; a1 ^= p1; a2 ^= p2; }
+        if (bitB && !isPivB) { b0 ^= p0; b1 ^= p1; b2 ^= p2; }
+        const bool hard = llr[col] > 0.0f;
+        if (isPivA) { usedA = true; kA = k; hardA = hard; }
+        if (isPivB) { usedB = true; kB = k; hardB = hard; }
+        k++;
+    }
+    // order-0 codeword (message part = first 91 bits) and the flip rows
+    uint64_t c0 = (hardA ? a0 : 0) ^ (hardB ? b0 : 0), c1 = (hardA ? a1 : 0) ^ (hardB ? b1 : 0);
+    c0 = xor_reduce64(c0); c1 = xor_reduce64(c1);
+    if (kA >= 0 && 90 - kA < 64 && 90 - kA >= 0) { flip[90 - kA][0] = a0; flip[90 - kA][1] = a1; }
+    if (kB >= 0 && 90 - kB < 64 && 90 - kB >= 0) { flip[90 - kB][0] = b0; flip[90 - kB][1] = b1; }
+    __syncthreads();
+    const int ntr = ntr_s;
+    const uint64_t M1 = (1ull << 27) - 1;
+    Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
+    const int ipass = (slot < 5) ? 5 : 6;
+    for (int base = 0; base < ntr; base += 64) {
+        const int t = base + lane;
+        int r = 0; uint64_t lo = 0, hi = 0;
+        if (t < ntr) {
+            uint64_t w0 = c0, w1 = c1;
+            int i = tri[t][0], j = tri[t][1];
+            if (i >= 0) { w0 ^= flip[i][0]; w1 ^= flip[i][1]; }
+            if (j >= 0) { w0 ^= flip[j][0]; w1 ^= flip[j][1]; }
+            r = ft8_crc_check(w0, w1 & M1, &lo, &hi);
+        }
+        const uint64_t acc = __ballot(r == 2);
+        const int win = acc ? __builtin_ctzll(acc) : 64;
+        if (r && lane <= win) log_event(ev, evcount, frame, ci, ipass, slot, t, lo, hi, r == 2);   // calls the reference made
+        if (acc) {
+            res.ok = 1; res.lo = shfl64(lo, win); res.hi = shfl64(hi, win); res.n_its = (int16_t)(base + win);
+            res.method = (slot < 5) ? FT8RX_M_OSD : FT8RX_M_LDPC_B_OSD;
+            break;
+        }
+    }
+    if (lane == 0) attO[vec] = res;
+}
+
+// ------------------------------------------------------------------------------------ small probes (tests)
+__global__ void k_math_probe(int which, const float* x, float* y, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (which == 0) ? ft8_log10f(x[i]) : ft8_tanhf(x[i]);
+}
+template <int N, int... Rs>
+__global__ void k_fft_probe(const cpx* x, cpx* y, const cpx* W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx* a = reinterpret_cast<cpx*>(smem); cpx* b = a + N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) a[i] = x[i];
+    __syncthreads();
+    cpx* r = lds_fft<N, Rs...>(a, b, W, 1, threadIdx.x, blockDim.x);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) y[i] = r[i];
+}
+__global__ void k_crc_probe(const float* cw91, int n, int32_t* res, uint64_t* lo, uint64_t* hi) {
+    int v = blockIdx.x; int lane = threadIdx.x;
+    const float* c = cw91 + (size_t)v * 91;
+    uint64_t b0 = __ballot(c[lane] > 0.0f);
+    uint64_t b1 = __ballot(lane < 27 && c[64 + (lane < 27 ? lane : 0)] > 0.0f);
+    uint64_t l, h; int r = ft8_crc_check(b0, b1, &l, &h);
+    if (lane == 0) { res[v] = r; lo[v] = l; hi[v] = h; }
+}
+__global__ void k_valid_probe(const uint64_t* lo, const uint64_t* hi, int n, int32_t* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ft8_valid77(lo[i], hi[i]) ? 1 : 0;
+}
+
+// ====================================================================================== host side
+#define HIPCHK(h, x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_err(h, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); return -2; } } while (0)
+
+static std::string g_create_err;
+
+struct ft8rx_handle {
+    ft8rx_config cfg;
+    int device, max_frames;
+    hipStream_t stream;
+    Tables T;
+    std::vector<void*> allocs;
+    int16_t* d_audio;            // staging for host-pointer entry points
+    float* d_grid;
+    float* d_best_score; int32_t* d_best_h0;
+    ft8rx_record* d_rec; int32_t* d_ncand;
+    float* d_llr0; float* d_saved;
+    Att *d_att0, *d_attG, *d_attB, *d_attO;
+    cpx *d_A, *d_Z, *d_spec;
+    ft8rx_event* d_ev; int32_t* d_evcount;
+    std::string err;
+    bool profiling;
+    std::vector<hipEvent_t> pev;
+    std::vector<const char*> pnames;
+    int n_stage;
+    float stage_ms[24];
+};
+
+static void set_err(ft8rx_handle* h, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+}
+
+template <typename T> static int dalloc(ft8rx_handle* h, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) { set_err(h, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e)); return -2; }
+    h->allocs.push_back(q); *p = (T*)q; return 0;
+}
+
+static void host_twiddle(int n, int count, std::vector<cpx>& w) {
+    w.resize(count);
+    for (int t = 0; t < count; t++) {
+        double ang = (2.0 * M_PI * (double)t) / (double)n;
+        w[t] = make_float2((float)cos(ang), (float)(-sin(ang)));
+    }
+}
+template <typename T> static int upload(ft8rx_handle* h, const T** dst, const std::vector<T>& v) {
+    T* p; if (dalloc(h, &p, v.size())) return -2;
+    if (hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { set_err(h, "table upload failed"); return -2; }
+    *dst = p; return 0;
+}
+
+struct Scratch {     // RAII device scratch for the test entry points
+    ft8rx_handle* h; std::vector<void*> p;
+    ~Scratch() { for (void* q : p) hipFree(q); }
+    template <typename T> T* get(size_t n) { void* q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T*)q; }
+    template <typename T> T* put(const T* src, size_t n) { T* q = get<T>(n); if (q && hipMemcpy(q, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr; return q; }
+};
+
+extern "C" {
+
+int ft8rx_default_config(ft8rx_config* c) {
+    if (!c) return -1;
+    c->sync_score_min = 85.0f; c->max_cands = 200; c->f0_lo = 32; c->f0_hi = 960; c->h0_lo = -37; c->h0_hi = 87;
+    c->bp_nc0_a = 35; c->bp_iters_a = 5; c->bp_nc0_b = 90; c->bp_iters_b = 20; c->osd_single = 30; c->osd_double = 2;
+    c->llr_sd_min = 5.0f;
+    return 0;
+}
+
+int ft8rx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int ft8rx_get_fft_plans(int32_t* p1920, int32_t* p3200, int32_t* p300, int32_t* p320) {
+    const int32_t a[8] = {8, 8, 5, 3, 2, 0, 0, 0}, b[8] = {8, 4, 4, 5, 5, 0, 0, 0}, c[8] = {5, 5, 4, 3, 0, 0, 0, 0}, d[8] = {8, 8, 5, 0, 0, 0, 0, 0};
+    if (p1920) memcpy(p1920, a, sizeof(a));
+    if (p3200) memcpy(p3200, b, sizeof(b));
+    if (p300) memcpy(p300, c, sizeof(c));
+    if (p320) memcpy(p320, d, sizeof(d));
+    return 0;
+}
+
+const char* ft8rx_last_error(ft8rx_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+void ft8rx_destroy(ft8rx_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    for (void* p : h->allocs) hipFree(p);
+    for (auto e : h->pev) hipEventDestroy(e);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_handle** out) {
+    if (!cfg || !out || max_frames < 1) { set_err(nullptr, "ft8rx_create: bad arguments"); return -1; }
+    if (cfg->max_cands < 1 || cfg->max_cands > MAXC || cfg->f0_lo < 4 || cfg->f0_hi > 960 || cfg->f0_lo >= cfg->f0_hi ||
+        cfg->h0_hi <= cfg->h0_lo || cfg->h0_hi - cfg->h0_lo > 352 || cfg->bp_nc0_a > cfg->bp_nc0_b || cfg->bp_iters_a > cfg->bp_iters_b ||
+        cfg->osd_single < 0 || cfg->osd_single > 64 || cfg->osd_double < 0 ||
+        1 + cfg->osd_single + cfg->osd_single * cfg->osd_double > OSD_MAXTRIALS) {
+        set_err(nullptr, "ft8rx_create: configuration out of the supported range"); return -1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_err(nullptr, "ft8rx_create: no HIP device available (this library has no CPU fallback)"); return -3; }
+    if (device < 0 || device >= ndev) { set_err(nullptr, "ft8rx_create: device %d out of range (%d devices)", device, ndev); return -1; }
+    ft8rx_handle* h = new ft8rx_handle();
+    h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
+    const size_t B = (size_t)max_frames;
+    int rc = 0;
+    rc |= dalloc(h, &h->d_audio, B * FT8RX_NSAMP);
+    rc |= dalloc(h, &h->d_grid, B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS);
+    rc |= dalloc(h, &h->d_best_score, B * NF0MAX);
+    rc |= dalloc(h, &h->d_best_h0, B * NF0MAX);
+    rc |= dalloc(h, &h->d_rec, B * MAXC);
+    rc |= dalloc(h, &h->d_ncand, B);
+    rc |= dalloc(h, &h->d_llr0, B * MAXC * 174);
+    rc |= dalloc(h, &h->d_saved, B * MAXC * 5 * 174);
+    rc |= dalloc(h, &h->d_att0, B * MAXC * 5);
+    rc |= dalloc(h, &h->d_attG, B * MAXC * 2);
+    rc |= dalloc(h, &h->d_attB, B * MAXC * 5);
+    rc |= dalloc(h, &h->d_attO, B * MAXC * 10);
+    rc |= dalloc(h, &h->d_A, B * 96000);
+    rc |= dalloc(h, &h->d_Z, B * 96000);
+    rc |= dalloc(h, &h->d_spec, B * FT8RX_SPEC_BINS);
+    rc |= dalloc(h, &h->d_ev, B * FT8RX_EVENT_CAP);
+    rc |= dalloc(h, &h->d_evcount, B);
+    if (rc) { g_create_err = h->err; ft8rx_destroy(h); return -2; }
+    // ---- tables (double precision on the host, rounded once)
+    std::vector<float> win(3840);
+    for (int i = 0; i < 3840; i++) win[i] = (float)(0.5 + 0.5 * cos(M_PI * (double)(2 * i + 1 - 3840) / 3839.0));   // np.hanning (receiver.py:236)
+    std::vector<double> taper(100);
+    { double step = (0.0 - M_PI) / 99.0; for (int i = 0; i < 100; i++) { double y = (i == 99) ? 0.0 : (double)i * step + M_PI; taper[i] = 0.5 * (1.0 + cos(y)); } }   // receiver.py:183-184
+    std::vector<cpx> w;
+    rc |= upload(h, &h->T.win, win);
+    rc |= upload(h, &h->T.taper, taper);
+    host_twiddle(1920, 1920, w);   rc |= upload(h, &h->T.W1920, w);
+    host_twiddle(3840, 976, w);    rc |= upload(h, &h->T.WR3840, w);
+    host_twiddle(3200, 3200, w);   rc |= upload(h, &h->T.W3200, w);
+    host_twiddle(96000, 96000, w); rc |= upload(h, &h->T.W96000, w);
+    host_twiddle(300, 300, w);     rc |= upload(h, &h->T.W300, w);
+    host_twiddle(320, 320, w);     rc |= upload(h, &h->T.W320, w);
+    host_twiddle(192000, FT8RX_SPEC_BINS, w); rc |= upload(h, &h->T.WR192k, w);
+    host_twiddle(32, 32, w);       rc |= upload(h, &h->T.W32, w);
+    if (rc) { g_create_err = h->err; ft8rx_destroy(h); return -2; }
+    // LDPC tables
+    bool ok = true;
+    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CHK_N), FT8_CHK_N, sizeof(FT8_CHK_N)) == hipSuccess;
+    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CHK_V), FT8_CHK_V, sizeof(FT8_CHK_V)) == hipSuccess;
+    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CHK_E0), FT8_CHK_E0, sizeof(FT8_CHK_E0)) == hipSuccess;
+    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_EDGE_V), FT8_EDGE_V, sizeof(FT8_EDGE_V)) == hipSuccess;
+    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_EDGE_C), FT8_EDGE_C, sizeof(FT8_EDGE_C)) == hipSuccess;
+    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_VAR_E), FT8_VAR_E, sizeof(FT8_VAR_E)) == hipSuccess;
+    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_G0), FT8_G0, sizeof(FT8_G0)) == hipSuccess;
+    // kernels that need > 64 KiB of dynamic LDS
+    ok &= hipFuncSetAttribute((const void*)k_fine, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
+    if (!ok) { set_err(nullptr, "ft8rx_create: device table upload failed"); ft8rx_destroy(h); return -2; }
+    // the never-written grid row 0 (receiver.py:240)
+    int nfill = (int)B * FT8RX_GRID_COLS;
+    k_fill_row0<<<(nfill + 255) / 256, 256, 0, h->stream>>>(h->d_grid, (int)B);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: init kernel failed"); ft8rx_destroy(h); return -2; }
+    for (int i = 0; i < 24; i++) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); }
+    *out = h;
+    return 0;
+}
+
+int ft8rx_set_profiling(ft8rx_handle* h, int on) { if (!h) return -1; h->profiling = on != 0; return 0; }
+
+int ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms) {
+    if (!h || !n) return -1;
+    *n = h->n_stage;
+    for (int i = 0; i < h->n_stage; i++) { if (names) names[i] = h->pnames[i]; if (ms) ms[i] = h->stage_ms[i]; }
+    return 0;
+}
+
+static size_t fine_lds_bytes() { return 2 * 3200 * sizeof(cpx) + (640 + 464 + 176 + 176 + 16 + 4) * sizeof(float); }
+static size_t sync_lds_bytes(const ft8rx_config& c) { return ((size_t)(c.h0_hi - c.h0_lo + 24) * 29 + 512) * sizeof(float); }
+
+#define STAGE(name) do { if (h->profiling) { hipEventRecord(h->pev[h->pnames.size()], h->stream); h->pnames.push_back(name); } } while (0)
+
+int ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int B) {
+    if (!h || !d_audio) return -1;
+    if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_enqueue_batch: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const ft8rx_config& c = h->cfg;
+    hipStream_t s = h->stream;
+    h->pnames.clear();
+    HIPCHK(h, hipMemsetAsync(h->d_evcount, 0, sizeof(int32_t) * B, s));
+    STAGE("spectrogram");
+    k_spectrogram<<<dim3(375, B), 256, 0, s>>>(d_audio, h->d_grid, h->T);
+    STAGE("sync");
+    const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
+    k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(h->d_grid, h->d_best_score, h->d_best_h0, c);
+    STAGE("topk");
+    k_topk<<<B, 1024, 0, s>>>(h->d_best_score, h->d_best_h0, h->d_rec, h->d_ncand, c);
+    STAGE("grid_llr");
+    k_grid_llr<<<B * MAXC, 64, 0, s>>>(h->d_grid, h->d_rec, h->d_ncand, h->d_llr0, c, nullptr, nullptr, nullptr);
+    STAGE("bp_grid");
+    k_bp<<<B * MAXC * 5, 64, 0, s>>>(0, h->d_llr0, h->d_rec, h->d_ncand, nullptr, h->d_att0, nullptr, h->d_ev, h->d_evcount, c, c.bp_nc0_a, c.bp_iters_a);
+    STAGE("select0");
+    k_select0<<<(B * MAXC + 255) / 256, 256, 0, s>>>(h->d_rec, h->d_ncand, h->d_att0, B);
+    STAGE("cycle_fft");
+    k_cyc_a<<<dim3(40, B), 256, 0, s>>>(d_audio, h->d_A, h->T);
+    k_cyc_b<<<dim3(75, B), 256, 0, s>>>(h->d_A, h->d_Z, h->T);
+    k_cyc_c<<<dim3(FT8RX_SPEC_BINS / 256, B), 256, 0, s>>>(h->d_Z, h->d_spec, h->T);
+    STAGE("fine");
+    k_fine<<<B * MAXC, 256, fine_lds_bytes(), s>>>(h->d_spec, h->d_rec, h->d_ncand, h->d_llr0, h->T, c, nullptr, nullptr, nullptr, nullptr);
+    STAGE("bp_fine");
+    k_bp<<<B * MAXC * 5, 64, 0, s>>>(1, h->d_llr0, h->d_rec, h->d_ncand, h->d_attG, h->d_attB, h->d_saved, h->d_ev, h->d_evcount, c, c.bp_nc0_b, c.bp_iters_b);
+    STAGE("select1");
+    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(h->d_rec, h->d_ncand, h->d_attG, h->d_attB, B, c);
+    STAGE("osd");
+    k_osd<<<B * MAXC * 10, 64, 0, s>>>(0, h->d_llr0, h->d_saved, h->d_attB, h->d_rec, h->d_ncand, h->d_attO, h->d_ev, h->d_evcount, c.osd_single, c.osd_double);
+    STAGE("select2");
+    k_select2<<<(B * MAXC + 255) / 256, 256, 0, s>>>(h->d_rec, h->d_ncand, h->d_attO, B);
+    if (h->profiling) hipEventRecord(h->pev[h->pnames.size()], s);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int ft8rx_sync(ft8rx_handle* h) {
+    if (!h) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->profiling && !h->pnames.empty()) {
+        h->n_stage = (int)h->pnames.size();
+        for (int i = 0; i < h->n_stage; i++) hipEventElapsedTime(&h->stage_ms[i], h->pev[i], h->pev[i + 1]);
+    }
+    return 0;
+}
+
+int ft8rx_fetch_results(ft8rx_handle* h, int B, ft8rx_record* records, int32_t* counts, ft8rx_event* events, int32_t* event_counts) {
+    if (!h || B < 1 || B > h->max_frames) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int mc = h->cfg.max_cands;
+    if (counts) HIPCHK(h, hipMemcpy(counts, h->d_ncand, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    if (records) HIPCHK(h, hipMemcpy2D(records, sizeof(ft8rx_record) * mc, h->d_rec, sizeof(ft8rx_record) * MAXC, sizeof(ft8rx_record) * mc, B, hipMemcpyDeviceToHost));
+    if (event_counts) HIPCHK(h, hipMemcpy(event_counts, h->d_evcount, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    if (events) HIPCHK(h, hipMemcpy(events, h->d_ev, sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_record* records, int32_t* counts,
+                       ft8rx_event* events, int32_t* event_counts) {
+    if (!h || !audio) return -1;
+    if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_decode_batch: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
+    int rc = ft8rx_enqueue_batch(h, h->d_audio, B);
+    if (rc) return rc;
+    return ft8rx_fetch_results(h, B, records, counts, events, event_counts);
+}
+
+// ---------------------------------------------------------------------------- stage entry points
+#define NEED(p) do { if (!(p)) { set_err(h, "scratch allocation/copy failed (%s:%d)", __FILE__, __LINE__); return -2; } } while (0)
+
+int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid) {
+    if (!h || !audio || !grid || B < 1 || B > h->max_frames) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
+    k_spectrogram<<<dim3(375, B), 256, 0, h->stream>>>(h->d_audio, h->d_grid, h->T);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(grid, h->d_grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_sync_search(ft8rx_handle* h, const float* grid, int B, int32_t* f0_idx, int32_t* h0_idx, float* score, int32_t* counts) {
+    if (!h || !grid || B < 1 || B > h->max_frames) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    const ft8rx_config& c = h->cfg;
+    HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
+    const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
+    k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), h->stream>>>(h->d_grid, h->d_best_score, h->d_best_h0, c);
+    k_topk<<<B, 1024, 0, h->stream>>>(h->d_best_score, h->d_best_h0, h->d_rec, h->d_ncand, c);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<ft8rx_record> rec((size_t)B * MAXC);
+    HIPCHK(h, hipMemcpy(rec.data(), h->d_rec, sizeof(ft8rx_record) * rec.size(), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(counts, h->d_ncand, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    for (int f = 0; f < B; f++) for (int i = 0; i < c.max_cands; i++) {
+        const ft8rx_record& r = rec[(size_t)f * MAXC + i];
+        size_t o = (size_t)f * c.max_cands + i;
+        f0_idx[o] = r.f0_idx; h0_idx[o] = r.h0_idx; score[o] = r.score;
+    }
+    // restore the 1.0 row in case the caller's grid differed
+    return 0;
+}
+
+int ft8rx_llr_grid(ft8rx_handle* h, const float* grid, int B, int n, const int32_t* frame, const int32_t* f0_idx,
+                   const int32_t* h0_idx, float* llr, float* sd, int32_t* snr) {
+    if (!h || !grid || B < 1 || B > h->max_frames || n < 1) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
+    std::vector<int32_t> trip(3 * (size_t)n);
+    for (int i = 0; i < n; i++) { trip[3 * i] = frame[i]; trip[3 * i + 1] = f0_idx[i]; trip[3 * i + 2] = h0_idx[i]; }
+    Scratch S{h};
+    int32_t* d_trip = S.put(trip.data(), trip.size()); NEED(d_trip);
+    float* d_llr = S.get<float>((size_t)n * 174); NEED(d_llr);
+    float* d_sd = S.get<float>(n); NEED(d_sd);
+    int32_t* d_snr = S.get<int32_t>(n); NEED(d_snr);
+    k_grid_llr<<<n, 64, 0, h->stream>>>(h->d_grid, nullptr, nullptr, d_llr, h->cfg, d_trip, d_sd, d_snr);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(llr, d_llr, sizeof(float) * (size_t)n * 174, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(sd, d_sd, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(snr, d_snr, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_cycle_spectrum(ft8rx_handle* h, const int16_t* audio, int B, float* spec) {
+    if (!h || !audio || !spec || B < 1 || B > h->max_frames) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
+    k_cyc_a<<<dim3(40, B), 256, 0, h->stream>>>(h->d_audio, h->d_A, h->T);
+    k_cyc_b<<<dim3(75, B), 256, 0, h->stream>>>(h->d_A, h->d_Z, h->T);
+    k_cyc_c<<<dim3(FT8RX_SPEC_BINS / 256, B), 256, 0, h->stream>>>(h->d_Z, h->d_spec, h->T);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(spec, h->d_spec, sizeof(cpx) * (size_t)B * FT8RX_SPEC_BINS, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_fine(ft8rx_handle* h, const float* spec, int B, int n, const int32_t* frame, const int32_t* f0_idx, const int32_t* h0_idx,
+               int32_t* ret, int32_t* ttweak, int32_t* ftweak, int32_t* nsync, float* llr, float* sd, int32_t* snr, float* sgrid) {
+    if (!h || !spec || B < 1 || B > h->max_frames || n < 1) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->d_spec, spec, sizeof(cpx) * (size_t)B * FT8RX_SPEC_BINS, hipMemcpyHostToDevice));
+    std::vector<int32_t> trip(3 * (size_t)n);
+    for (int i = 0; i < n; i++) { trip[3 * i] = frame[i]; trip[3 * i + 1] = f0_idx[i]; trip[3 * i + 2] = h0_idx[i]; }
+    Scratch S{h};
+    int32_t* d_trip = S.put(trip.data(), trip.size()); NEED(d_trip);
+    float* d_llr = S.get<float>((size_t)n * 174); NEED(d_llr);
+    HIPCHK(h, hipMemset(d_llr, 0, sizeof(float) * (size_t)n * 174));
+    float* d_sd = S.get<float>(n); NEED(d_sd);
+    int32_t* d_out = S.get<int32_t>((size_t)n * 5); NEED(d_out);
+    float* d_sg = sgrid ? S.get<float>((size_t)n * 632) : nullptr; if (sgrid) NEED(d_sg);
+    k_fine<<<n, 256, fine_lds_bytes(), h->stream>>>(h->d_spec, nullptr, nullptr, d_llr, h->T, h->cfg, d_trip, d_out, d_sd, d_sg);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<int32_t> o((size_t)n * 5);
+    HIPCHK(h, hipMemcpy(o.data(), d_out, sizeof(int32_t) * o.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) { ret[i] = o[5 * i]; ttweak[i] = o[5 * i + 1]; ftweak[i] = o[5 * i + 2]; nsync[i] = o[5 * i + 3]; snr[i] = o[5 * i + 4]; }
+    HIPCHK(h, hipMemcpy(llr, d_llr, sizeof(float) * (size_t)n * 174, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(sd, d_sd, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (sgrid) HIPCHK(h, hipMemcpy(sgrid, d_sg, sizeof(float) * (size_t)n * 632, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_ldpc(ft8rx_handle* h, const float* llr, int n, int max_ncheck0, int max_iters, int32_t* ok, uint64_t* msg_lo,
+               uint64_t* msg_hi, int32_t* n_its, int32_t* has_out, float* llr_out) {
+    if (!h || !llr || n < 1) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    Scratch S{h};
+    float* d_in = S.put(llr, (size_t)n * 174); NEED(d_in);
+    float* d_out = S.get<float>((size_t)n * 174); NEED(d_out);
+    HIPCHK(h, hipMemset(d_out, 0, sizeof(float) * (size_t)n * 174));
+    Att* d_att = S.get<Att>(n); NEED(d_att);
+    k_bp<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, d_att, d_out, nullptr, nullptr, h->cfg, max_ncheck0, max_iters);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<Att> a(n);
+    HIPCHK(h, hipMemcpy(a.data(), d_att, sizeof(Att) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) { ok[i] = a[i].ok; msg_lo[i] = a[i].lo; msg_hi[i] = a[i].hi; n_its[i] = a[i].ok ? a[i].n_its : -1; has_out[i] = a[i].has_out; }
+    if (llr_out) HIPCHK(h, hipMemcpy(llr_out, d_out, sizeof(float) * (size_t)n * 174, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_osd(ft8rx_handle* h, const float* llr, int n, int singleflips, int doubleflips, int32_t* ok, uint64_t* msg_lo,
+              uint64_t* msg_hi, int32_t* trial) {
+    if (!h || !llr || n < 1) return -1;
+    if (singleflips < 0 || singleflips > 64 || doubleflips < 0 || 1 + singleflips + singleflips * doubleflips > OSD_MAXTRIALS) { set_err(h, "ft8rx_osd: flip counts out of range"); return -1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    Scratch S{h};
+    float* d_in = S.put(llr, (size_t)n * 174); NEED(d_in);
+    Att* d_att = S.get<Att>(n); NEED(d_att);
+    k_osd<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, nullptr, d_att, nullptr, nullptr, singleflips, doubleflips);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<Att> a(n);
+    HIPCHK(h, hipMemcpy(a.data(), d_att, sizeof(Att) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) { ok[i] = a[i].ok; msg_lo[i] = a[i].lo; msg_hi[i] = a[i].hi; trial[i] = a[i].ok ? a[i].n_its : -1; }
+    return 0;
+}
+
+int ft8rx_crc_valid(ft8rx_handle* h, const float* cw91, int n, int32_t* res, uint64_t* msg_lo, uint64_t* msg_hi) {
+    if (!h || !cw91 || n < 1) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    Scratch S{h};
+    float* d_in = S.put(cw91, (size_t)n * 91); NEED(d_in);
+    int32_t* d_res = S.get<int32_t>(n); NEED(d_res);
+    uint64_t* d_lo = S.get<uint64_t>(n); NEED(d_lo);
+    uint64_t* d_hi = S.get<uint64_t>(n); NEED(d_hi);
+    k_crc_probe<<<n, 64, 0, h->stream>>>(d_in, n, d_res, d_lo, d_hi);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(res, d_res, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(msg_lo, d_lo, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(msg_hi, d_hi, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_valid77(ft8rx_handle* h, const uint64_t* msg_lo, const uint64_t* msg_hi, int n, int32_t* valid) {
+    if (!h || !msg_lo || !msg_hi || n < 1) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    Scratch S{h};
+    uint64_t* d_lo = S.put(msg_lo, n); NEED(d_lo);
+    uint64_t* d_hi = S.put(msg_hi, n); NEED(d_hi);
+    int32_t* d_v = S.get<int32_t>(n); NEED(d_v);
+    k_valid_probe<<<(n + 255) / 256, 256, 0, h->stream>>>(d_lo, d_hi, n, d_v);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(valid, d_v, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_math_probe(ft8rx_handle* h, int which, const float* x, int n, float* y) {
+    if (!h || !x || !y || n < 1) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    Scratch S{h};
+    if (which == 0 || which == 1) {
+        float* d_x = S.put(x, n); NEED(d_x);
+        float* d_y = S.get<float>(n); NEED(d_y);
+        k_math_probe<<<(n + 255) / 256, 256, 0, h->stream>>>(which, d_x, d_y, n);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(y, d_y, sizeof(float) * n, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (which == 2) {
+        cpx* d_x = S.put((const cpx*)x, n); NEED(d_x);
+        cpx* d_y = S.get<cpx>(n); NEED(d_y);
+        const size_t lds = 2 * (size_t)n * sizeof(cpx);
+        if (n == 1920) k_fft_probe<1920, 8, 8, 5, 3, 2><<<1, 256, lds, h->stream>>>(d_x, d_y, h->T.W1920);
+        else if (n == 3200) k_fft_probe<3200, 8, 4, 4, 5, 5><<<1, 256, lds, h->stream>>>(d_x, d_y, h->T.W3200);
+        else if (n == 300) k_fft_probe<300, 5, 5, 4, 3><<<1, 256, lds, h->stream>>>(d_x, d_y, h->T.W300);
+        else if (n == 320) k_fft_probe<320, 8, 8, 5><<<1, 256, lds, h->stream>>>(d_x, d_y, h->T.W320);
+        else { set_err(h, "ft8rx_math_probe: no FFT plan of length %d", n); return -1; }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(y, d_y, sizeof(cpx) * n, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    return -1;
+}
+
+}  // extern "C"

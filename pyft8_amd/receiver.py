@@ -1,0 +1,155 @@
+"""Drop-in surface of PyFT8/receiver.py for the MI355X build: batched, frame-complete decoding.
+
+    Receiver(input_device_keywords, on_message, sync_score_min=85, max_cands=200,
+             search_freq_range=[100,3000], search_time_range=[-2.0,3.0], verbose=False)   reference receiver.py:310-336
+      .audio_in.search_grid / .waterfall_data / .get_cycle_spectrum()                    reference receiver.py:225-306
+      .search(cyclestart_string, odd_even, search_f_idxs) -> [Candidate]                  reference receiver.py:338-367
+      .set_band(band)                                                                     reference receiver.py:369
+      .decode_frames(audio_i16[B,180000]) -> list[list[message dict]]                     (batch entry)
+    decode_frames(audio, **receiver_kwargs)                                               module-level convenience
+
+The reference is a real-time, one-frame-per-15-s receiver driven by PortAudio; this build decodes whole
+frames ("frame-complete" semantics) in batches on the GPU.  Messages are delivered through
+`on_message(dict)` with the reference's keys, on the caller's thread, in the reference's emit order.
+There is no CPU path: without libft8rx.so and an MI355X the constructor raises.
+"""
+import numpy as np
+
+from . import _lib
+from . import messages as _m
+
+T_CYC, SYM_RATE, SAMP_RATE = 15, 6.25, 12000
+WATERFALL_DOWNSAMPLE = 2
+
+
+def config_from_kwargs(sync_score_min=85, max_cands=200, search_freq_range=(100, 3000), search_time_range=(-2.0, 3.0), **ext):
+    """Receiver kwargs -> ft8rx_config (index arithmetic of reference receiver.py:233-235, 319)."""
+    df = SYM_RATE / 2
+    cfg = _lib.default_config(
+        sync_score_min=float(sync_score_min), max_cands=int(max_cands),
+        f0_lo=int(search_freq_range[0] / df), f0_hi=int(search_freq_range[1] / df),
+        h0_lo=int((search_time_range[0] + 0.5) * 4 * SYM_RATE), h0_hi=int((search_time_range[1] + 0.5) * 4 * SYM_RATE))
+    for k, v in ext.items():          # extension knobs: bp_iters_b, osd_single, osd_double, ...
+        setattr(cfg, k, v)
+    return cfg
+
+
+class Candidate:
+    """Read-only view of one sync candidate (reference receiver.py:29-50 `Candidate.origin`)."""
+
+    def __init__(self, origin, search_grid_bounds, record=None):
+        self.origin = origin
+        self.search_grid_bounds = search_grid_bounds
+        self.record = record
+        self.decode_result = None
+
+
+class AudioIn:
+    """Holds the host views the reference's GUI reads (receiver.py:240, 272-278).  Filled per decoded frame."""
+
+    def __init__(self, search_freq_range, receiver):
+        self.input_device_idx = None
+        self.search_hps, self.search_bpt = 4, 2
+        self.search_freq_range = search_freq_range
+        self.df = SYM_RATE / self.search_bpt
+        self.search_f0_idx_range = [int(search_freq_range[0] / self.df), int(search_freq_range[1] / self.df)]
+        self.search_hops_per_cycle = int(T_CYC * SYM_RATE * self.search_hps)
+        self.search_hops_per_grid = 2 * self.search_hops_per_cycle
+        self.dt = T_CYC / self.search_hops_per_cycle
+        self.search_grid = np.ones((self.search_hops_per_grid, _lib.GRID_COLS), dtype=np.float32)
+        self.search_grid_ptr = 0
+        self._rx = receiver
+        self._audio = None
+        self.cycle_spectrum = None
+        d = WATERFALL_DOWNSAMPLE
+        self.waterfall_data = {"data": self.search_grid[::d, ::d].T, "df": self.df * d, "dt": self.dt * d,
+                               "sig_w": int(79 * self.search_hps / d), "sig_h": int(8 * self.search_bpt / d),
+                               "pixels_per_cycle": int(self.search_hops_per_cycle / d)}
+
+    def load_frame(self, audio_i16):
+        """Frame-complete stand-in for 375 calls of _callback (receiver.py:295-306)."""
+        self._audio = np.ascontiguousarray(audio_i16, np.int16).reshape(_lib.NSAMP)
+        g = self._rx._handle(1).spectrogram(self._audio)[0]
+        self.search_grid[1:376] = g[1:376]          # in place: waterfall_data['data'] is a live view
+        self.search_grid_ptr = 375
+        self.cycle_spectrum = None
+
+    def get_cycle_spectrum(self):
+        """First 49152 bins of the reference's 96001-bin spectrum (receiver.py:280-286): all the fine sync reads."""
+        if self.cycle_spectrum is None:
+            if self._audio is None:
+                raise _lib.Ft8rxError("no frame loaded")
+            self.cycle_spectrum = self._rx._handle(1).cycle_spectrum(self._audio)[0]
+        return self.cycle_spectrum
+
+
+class Receiver:
+    def __init__(self, input_device_keywords, on_message, sync_score_min=85, max_cands=200,
+                 search_freq_range=[100, 3000], search_time_range=[-2.5 + 0.5, 2.5 + 0.5], verbose=False,
+                 device=0, max_frames=1, **extension_knobs):
+        self.on_message = on_message
+        self.sync_score_min, self.max_cands = sync_score_min, max_cands
+        self.verbose = verbose
+        self.band = None
+        self.candidates = []
+        self.cfg = config_from_kwargs(sync_score_min, max_cands, search_freq_range, search_time_range, **extension_knobs)
+        self.search_h0_range = [self.cfg.h0_lo, self.cfg.h0_hi]
+        self.search_start_hop = self.search_h0_range[1] + 43 * 4
+        self.device = device
+        self._h = None
+        self._handle(max_frames)                      # fail loudly now if there is no GPU / library
+        self.audio_in = AudioIn(search_freq_range, self)
+
+    def _handle(self, n_frames):
+        if self._h is None or self._h.max_frames < n_frames:
+            if self._h is not None:
+                self._h.close()
+            self._h = _lib.Handle(self.cfg, device=self.device, max_frames=n_frames)
+        return self._h
+
+    def set_band(self, band):
+        self.band = band
+
+    def search(self, cyclestart_string, odd_even, search_f_idxs=None):
+        """Costas sync search over the currently loaded frame (audio_in.load_frame)."""
+        if odd_even != 0:
+            raise _lib.Ft8rxError("frame-complete build: frames are decoded as cycle 0 of the grid (odd_even=0)")
+        rng = self.audio_in.search_f0_idx_range
+        if search_f_idxs is not None and (search_f_idxs[0], search_f_idxs[-1] + 1) != (rng[0], rng[1]):
+            raise _lib.Ft8rxError("search_f_idxs must equal the configured search_freq_range")
+        grid = np.ones((1, _lib.GRID_ROWS, _lib.GRID_COLS), np.float32)
+        grid[0, 1:376] = self.audio_in.search_grid[1:376]
+        f0, h0, sc, cnt = self._handle(1).sync_search(grid)
+        cands = []
+        for i in range(int(cnt[0])):
+            origin = {"h0_idx": int(h0[0, i]), "f0_idx": int(f0[0, i]), "tsec": int(h0[0, i]) / 25.0,
+                      "fHz": 3.125 * int(f0[0, i]), "score": float(sc[0, i]),
+                      "cyclestart_string": cyclestart_string, "band": self.band, "odd_even": odd_even}
+            cands.append(Candidate(origin, [int(h0[0, i]) + 4, int(h0[0, i]) + 4 * 71]))
+        self.candidates = cands
+        return cands
+
+    def decode_frames(self, audio_i16, cyclestart_strings=None, return_records=False):
+        """Decode B independent 15-s frames.  -> list (per frame) of message dicts in emit order."""
+        audio = np.ascontiguousarray(audio_i16, np.int16)
+        if audio.ndim == 1:
+            audio = audio[None]
+        B = audio.shape[0]
+        rec, cnt, ev, evc = self._handle(B).decode_batch(audio)
+        out = []
+        for f in range(B):
+            cs = cyclestart_strings[f] if cyclestart_strings is not None else "700101_000015"
+            out.append(_m.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]), cyclestart_string=cs, band=self.band,
+                                        odd_even=0, on_message=self.on_message))
+        return (out, rec, cnt) if return_records else out
+
+    def decode_frame(self, audio_i16, cyclestart_string="700101_000015"):
+        return self.decode_frames(np.asarray(audio_i16)[None], [cyclestart_string])[0]
+
+
+def decode_frames(audio_i16, on_message=None, **receiver_kwargs):
+    """decode_frames(audio_i16[B,180000], **receiver_kwargs) -> list[list[message dict]]  (SURVEY.md 8b)."""
+    audio = np.asarray(audio_i16)
+    n = 1 if audio.ndim == 1 else audio.shape[0]
+    rx = Receiver("", on_message, max_frames=n, **receiver_kwargs)
+    return rx.decode_frames(audio)
