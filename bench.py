@@ -37,6 +37,20 @@ ALG_BYTES = {
 }
 ALG_BYTES_FRAME = 6025712                                  # SURVEY.md 8d total
 HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8 TB/s spec
+PMC_PROFILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+                                                                  # command (tools/pmc_summary.py), B = 256
+
+
+def pmc_traffic(kernel_stage, B):
+    """HBM bytes per launch of the stage's kernels from the committed PMC profile (collected at B=256), or None."""
+    names = {"spectrogram": ["k_spectrogram"], "sync": ["k_sync"], "fine": ["k_fine"], "osd": ["k_osd"],
+             "cycle_fft": ["k_cyc_a", "k_cyc_b", "k_cyc_c"], "grid_llr": ["k_grid_llr"], "topk": ["k_topk"]}.get(kernel_stage)
+    if not names or not os.path.exists(PMC_PROFILE) or B != 256:
+        return None
+    prof = json.load(open(PMC_PROFILE))
+    if not all(n in prof for n in names):
+        return None
+    return sum(prof[n]["hbm_bytes"] for n in names)
 
 
 def _gen(args):
@@ -136,10 +150,11 @@ def main():
 
     # gather path (RCCL): per-rank fixed-capacity record blocks to rank 0 -- off the timed path
     if world > 1:
-        blk = torch.from_numpy(rec.view(np.uint8).reshape(B, -1).copy()).cuda()
-        out = [torch.empty_like(blk) for _ in range(world)] if rank == 0 else None
-        dist.gather(blk, out, dst=0)
+        from pyft8_amd.distributed import gather_results
+        allres = gather_results(rec, cnt, ev, evc, dst=0)
         torch.cuda.synchronize()
+        if rank == 0:
+            assert allres[0].shape[0] == world * B
 
     if rank == 0:
         dom = max(acc, key=acc.get)
@@ -155,7 +170,7 @@ def main():
                        "frames_per_gpu": B, "decoded_candidates_per_frame": n_dec / B,
                        "unique_messages_first16": n_msgs, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
                          "kernel_ms": dom_ms, "alg_bytes_per_launch": ALG_BYTES[dom] * B,
                          "whole_path_frac": value / world * ALG_BYTES_FRAME / 1e9 / HBM_PEAK_GBS},
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},

@@ -631,23 +631,23 @@ int ft8o_unpack77(void* hash, uint64_t lo, uint64_t hi, char out[3][16]) {
 int ft8o_valid77(uint64_t lo, uint64_t hi) { return ft8o_unpack77(NULL, lo, hi, NULL); }
 
 /* acceptance callback: called for every CRC-passing, non-zero 77-bit word in reference call order */
-typedef int (*accept_fn)(void* ctx, uint64_t lo, uint64_t hi);
-static int accept_pure(void* ctx, uint64_t lo, uint64_t hi) { (void)ctx; return ft8o_valid77(lo, hi); }
+typedef int (*accept_fn)(void* ctx, uint64_t lo, uint64_t hi, int seq);
+static int accept_pure(void* ctx, uint64_t lo, uint64_t hi, int seq) { (void)ctx; (void)seq; return ft8o_valid77(lo, hi); }
 
 /* hard bits of 91 values -> (msg, crc); decoders.py:117-131.  0: fail, 1: crc ok but unpack None, 2: accepted */
-static int crc_check_bits(const uint8_t* b91, accept_fn acc, void* ctx, uint64_t* lo_out, uint64_t* hi_out) {
+static int crc_check_bits(const uint8_t* b91, accept_fn acc, void* ctx, int seq, uint64_t* lo_out, uint64_t* hi_out) {
     uint64_t lo = 0, hi = 0; unsigned crc = 0;
     for (int k = 0; k < 77; k++) if (b91[k]) { int pos = 76 - k; if (pos >= 64) hi |= 1ULL << (pos - 64); else lo |= 1ULL << pos; }
     for (int k = 77; k < 91; k++) crc = (crc << 1) | (b91[k] ? 1u : 0u);
     if (lo == 0 && hi == 0) return 0;
     if (crc14_of77(lo, hi) != crc) return 0;
     if (lo_out) { *lo_out = lo; *hi_out = hi; }
-    return acc(ctx, lo, hi) ? 2 : 1;
+    return acc(ctx, lo, hi, seq) ? 2 : 1;
 }
 
 int ft8o_crc_valid91(const float* llr91, uint64_t* lo, uint64_t* hi) {
     uint8_t b[91]; for (int k = 0; k < 91; k++) b[k] = llr91[k] > 0.0f;
-    return crc_check_bits(b, accept_pure, NULL, lo, hi);
+    return crc_check_bits(b, accept_pure, NULL, 0, lo, hi);
 }
 
 /* ------------------------------------------------------------------ LDPC BP (decoders.py:140-171) */
@@ -666,7 +666,7 @@ static int ldpc_core(float* llr, int max_nc0, int max_iters, accept_fn acc, void
         if (it == 0 && ncheck > max_nc0) { *has_out = 0; return 0; }
         if (ncheck == 0) {
             uint8_t b[91]; for (int k = 0; k < 91; k++) b[k] = llr[k] > 0.0f;
-            int r = crc_check_bits(b, acc, ctx, lo, hi);
+            int r = crc_check_bits(b, acc, ctx, it + 1, lo, hi);
             if (r == 2) { *n_its = it; *has_out = 0; return 1; }
             /* reference does nothing this iteration => state is frozen; if the CRC passed (but unpack gave
              * None) every remaining iteration repeats the same failing unpack call.  The repeat count is
@@ -741,17 +741,17 @@ static int osd_core(const float* llr, int singles, int doubles, accept_fn acc, v
     uint8_t b[91];
     /* order-0 */
     { uint64_t w[2] = {cw0[0], cw0[1] & M1}; cw91_to_bits(w, b);
-      if (crc_check_bits(b, acc, ctx, lo, hi) == 2) { *trial_out = trial; return 1; } }
+      if (crc_check_bits(b, acc, ctx, trial, lo, hi) == 2) { *trial_out = trial; return 1; } }
     trial++;
     for (int i = 0; i < singles; i++, trial++) {
         const uint64_t* f = G[prow[90 - i]];
         uint64_t w[2] = {cw0[0] ^ f[0], (cw0[1] ^ f[1]) & M1}; cw91_to_bits(w, b);
-        if (crc_check_bits(b, acc, ctx, lo, hi) == 2) { *trial_out = trial; return 1; }
+        if (crc_check_bits(b, acc, ctx, trial, lo, hi) == 2) { *trial_out = trial; return 1; }
     }
     for (int i = 0; i < singles; i++) for (int j = 0; j < doubles; j++) if (j < i) {
         const uint64_t* f = G[prow[90 - i]]; const uint64_t* g = G[prow[90 - j]];
         uint64_t w[2] = {cw0[0] ^ f[0] ^ g[0], (cw0[1] ^ f[1] ^ g[1]) & M1}; cw91_to_bits(w, b);
-        if (crc_check_bits(b, acc, ctx, lo, hi) == 2) { *trial_out = trial; return 1; }
+        if (crc_check_bits(b, acc, ctx, trial, lo, hi) == 2) { *trial_out = trial; return 1; }
         trial++;
     }
     *trial_out = -1;
@@ -764,14 +764,14 @@ int ft8o_osd(const float* llr, int singles, int doubles, uint64_t* lo, uint64_t*
 
 /* ------------------------------------------------------------------ whole frame (receiver.py:68-107, 338-367, 389-398) */
 typedef struct {
-    hashtab* ht; ft8o_event* log; int32_t cap, n; int cand, ipass;
+    hashtab* ht; ft8o_event* log; int32_t cap, n; int cand, ipass, slot;
     char last[3][16]; int repeat;
 } fctx;
 
-static int accept_frame(void* vctx, uint64_t lo, uint64_t hi) {
+static int accept_frame(void* vctx, uint64_t lo, uint64_t hi, int seq) {
     fctx* f = (fctx*)vctx;
     int v = ft8o_unpack77(f->ht, lo, hi, f->last);
-    if (f->n < f->cap) { ft8o_event* e = &f->log[f->n]; e->msg_lo = lo; e->msg_hi = hi; e->cand = f->cand; e->ipass = f->ipass; e->valid = v; e->pad = 0; }
+    if (f->n < f->cap) { ft8o_event* e = &f->log[f->n]; e->msg_lo = lo; e->msg_hi = hi; e->cand = f->cand; e->ipass = f->ipass; e->valid = v; e->pad = (f->slot << 16) | (seq & 0xffff); }
     f->n++;
     return v;
 }
@@ -784,7 +784,7 @@ static int run_ldpc_frame(fctx* fc, float* llr, int nc0, int iters, ft8o_cand* c
     if (!ok && nits <= -2) {
         /* frozen all-checks-satisfied state: the reference repeats the failing unpack each remaining iteration */
         int rep = -nits - 2;
-        if (fc->n > 0 && fc->n <= fc->cap) { ft8o_event last = fc->log[fc->n - 1]; for (int i = 0; i < rep; i++) accept_frame(fc, last.msg_lo, last.msg_hi); }
+        if (fc->n > 0 && fc->n <= fc->cap) { ft8o_event last = fc->log[fc->n - 1]; for (int i = 0; i < rep; i++) accept_frame(fc, last.msg_lo, last.msg_hi, (last.pad & 0xffff) + 1 + i); }
         else for (int i = 0; i < rep; i++) fc->n++;
     }
     if (ok) { c->msg_lo = lo; c->msg_hi = hi; c->n_its = nits; }
@@ -828,9 +828,10 @@ int ft8o_decode_frame(const int16_t* audio, const ft8o_config* cfg, ft8o_cand* c
                 memcpy(s->llr0, s->llr, sizeof(s->llr0));
                 if (!ok) c->status = FT8O_ST_STOP_GRID_SD;
                 else for (int ap = 0; ap < 5 && !done; ap++) {
+                    fc.slot = ap;
                     ft8o_set_ap(s->llr0, ap, s->llr);
                     uint8_t b[91]; for (int k = 0; k < 91; k++) b[k] = s->llr[k] > 0.0f;
-                    if (crc_check_bits(b, accept_frame, &fc, &lo, &hi) == 2) { done = 1; c->method = FT8O_M_GOOD91; c->ap = ap; c->msg_lo = lo; c->msg_hi = hi; c->n_its = 0; break; }
+                    if (crc_check_bits(b, accept_frame, &fc, 0, &lo, &hi) == 2) { done = 1; c->method = FT8O_M_GOOD91; c->ap = ap; c->msg_lo = lo; c->msg_hi = hi; c->n_its = 0; break; }
                     if (run_ldpc_frame(&fc, s->llr, cfg->bp_nc0_a, cfg->bp_iters_a, c, &has_out)) { done = 1; c->method = FT8O_M_LDPC_A; c->ap = ap; }
                 }
             } else if (ip == 1) {
@@ -842,23 +843,27 @@ int ft8o_decode_frame(const int16_t* audio, const ft8o_config* cfg, ft8o_cand* c
             } else if (ip == 2) {
                 memcpy(s->llr0, s->llr, sizeof(s->llr0));
                 for (int ap = 0; ap < 2 && !done; ap++) {
+                    fc.slot = ap;
                     ft8o_set_ap(s->llr0, ap, s->llr);
                     uint8_t b[91]; for (int k = 0; k < 91; k++) b[k] = s->llr[k] > 0.0f;
-                    if (crc_check_bits(b, accept_frame, &fc, &lo, &hi) == 2) { done = 1; c->method = FT8O_M_GOOD91; c->ap = ap; c->msg_lo = lo; c->msg_hi = hi; c->n_its = 0; }
+                    if (crc_check_bits(b, accept_frame, &fc, 0, &lo, &hi) == 2) { done = 1; c->method = FT8O_M_GOOD91; c->ap = ap; c->msg_lo = lo; c->msg_hi = hi; c->n_its = 0; }
                 }
             } else if (ip == 3) {
                 for (int ap = 0; ap < 2 && !done; ap++) {
+                    fc.slot = ap;
                     ft8o_set_ap(s->llr0, ap, s->llr);
                     if (run_ldpc_frame(&fc, s->llr, cfg->bp_nc0_a, cfg->bp_iters_a, c, &has_out)) { done = 1; c->method = FT8O_M_LDPC_A; c->ap = ap; }
                 }
             } else if (ip == 4) {
                 for (int ap = 0; ap < 5 && !done; ap++) {
+                    fc.slot = ap;
                     ft8o_set_ap(s->llr0, ap, s->llr);
                     if (run_ldpc_frame(&fc, s->llr, cfg->bp_nc0_b, cfg->bp_iters_b, c, &has_out)) { done = 1; c->method = FT8O_M_LDPC_B; c->ap = ap; }
                     else if (has_out) { memcpy(s->saved[s->n_saved], s->llr, sizeof(s->llr)); s->saved_ap[s->n_saved++] = ap; }
                 }
             } else if (ip == 5) {
                 for (int ap = 0; ap < 5 && !done; ap++) {
+                    fc.slot = ap;
                     ft8o_set_ap(s->llr0, ap, s->llr);
                     int32_t trial;
                     if (osd_core(s->llr, cfg->osd_single, cfg->osd_double, accept_frame, &fc, &lo, &hi, &trial, NULL)) {
@@ -866,6 +871,7 @@ int ft8o_decode_frame(const int16_t* audio, const ft8o_config* cfg, ft8o_cand* c
                 }
             } else if (ip == 6) {
                 for (int k = 0; k < s->n_saved && !done; k++) {
+                    fc.slot = 5 + s->saved_ap[k];
                     int32_t trial;
                     if (osd_core(s->saved[k], cfg->osd_single, cfg->osd_double, accept_frame, &fc, &lo, &hi, &trial, NULL)) {
                         done = 1; c->method = FT8O_M_LDPC_B_OSD; c->ap = s->saved_ap[k]; c->msg_lo = lo; c->msg_hi = hi; c->n_its = trial; }

@@ -55,7 +55,7 @@ typedef struct {
     uint64_t msg_lo, msg_hi;
     int32_t cand, ipass;
     int32_t valid;          /* unpack returned a tuple */
-    int32_t pad;
+    int32_t pad;            /* (slot << 16) | seq : attempt index inside the ipass step, order inside the attempt */
 } ft8o_event;
 
 typedef struct {

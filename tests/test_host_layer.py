@@ -1,0 +1,124 @@
+"""CPU-only tests of the product's host side: the C ABI library loads and exports every declared symbol,
+the message layer / frame packaging replay reproduces the reference's dicts when fed oracle records, and the
+N>1 gather path works over gloo with world_size 2.  No compute calls into the GPU library here."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_FRAMES, ROOT, load_golden
+from helpers import oracle_frame, records_from_oracle
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from pyft8_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "ft8rx.h")).read()
+    names = sorted(set(re.findall(r"\b(ft8rx_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 20
+    L = _lib.lib()
+    for n in names:
+        assert hasattr(L, n), f"libft8rx.so does not export {n}"
+    # and nothing CPU-side pretends to be the product: create must fail without a GPU
+    if L.ft8rx_device_count() == 0:
+        with pytest.raises(_lib.Ft8rxError):
+            _lib.Handle()
+
+
+def test_record_layouts_match_header():
+    from pyft8_amd import _lib
+    assert _lib.RECORD_DTYPE.itemsize == 48 and _lib.EVENT_DTYPE.itemsize == 24
+    assert ctypes.sizeof(_lib.Config) == 13 * 4
+    plans = _lib.fft_plans()
+    assert int(np.prod(plans["plan1920"])) == 1920 and int(np.prod(plans["plan3200"])) == 3200
+    assert int(np.prod(plans["plan300"])) * int(np.prod(plans["plan320"])) == 96000
+
+
+def test_config_from_receiver_kwargs():
+    from pyft8_amd.receiver import config_from_kwargs
+    c = config_from_kwargs()
+    assert (c.f0_lo, c.f0_hi, c.h0_lo, c.h0_hi, c.max_cands, c.sync_score_min) == (32, 960, -37, 87, 200, 85.0)
+    c = config_from_kwargs(sync_score_min=100, max_cands=150, bp_iters_b=30)        # pyft8.py:136 intent + extension knob
+    assert (c.max_cands, c.sync_score_min, c.bp_iters_b) == (150, 100.0, 30)
+
+
+@pytest.mark.parametrize("name", GOLDEN_FRAMES)
+def test_package_frame_replays_reference_dicts(name):
+    """Host replay (ordering, hash side effects, duplicate filter, dict formatting) fed with oracle records
+    must give the reference's message dicts (minus decode_completed)."""
+    from pyft8_amd import messages as M
+    audio, gold, js = load_golden(name)
+    rec, n, ev, nev = records_from_oracle(oracle_frame(audio))
+    got = []
+    msgs = M.package_frame(rec, n, ev, nev, cyclestart_string="700101_000015", band=None, odd_even=0, on_message=got.append)
+    assert msgs == got and len(msgs) == len(js["messages"])
+    for m, ref in zip(msgs, js["messages"]):
+        for key, val in ref.items():
+            assert (list(m[key]) if key == "msg_tuple" else m[key]) == val, (key, m[key], val)
+        assert "decode_completed" in m
+
+
+def test_package_frame_survives_truncated_event_log():
+    from pyft8_amd import messages as M
+    audio, gold, js = load_golden("test_08")
+    rec, n, ev, nev = records_from_oracle(oracle_frame(audio))
+    msgs = M.package_frame(rec, n, ev[:5], nev)
+    assert sorted(" ".join(m["msg_tuple"]).replace("<...>", "#") for m in msgs) == \
+        sorted(" ".join(m["msg_tuple"]).replace("<...>", "#") for m in js["messages"])
+
+
+def test_shard_partition():
+    from pyft8_amd.distributed import shard
+    for n in (1, 7, 8, 256, 65536):
+        for w in (1, 2, 4, 8):
+            parts = [shard(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+            assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import torch.distributed as dist
+from conftest import load_golden
+from helpers import oracle_frame, records_from_oracle
+from pyft8_amd import _lib, messages as M
+from pyft8_amd.distributed import shard, gather_results
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+names = ["synth_200000", "synth_100000", "synth_200000"]          # 3 frames over 2 ranks: ragged shards
+start, count = shard(len(names), rank, world)
+recs, cnts, evs, evcs = [], [], [], []
+for nm in names[start:start + count]:
+    rec, n, ev, nev = records_from_oracle(oracle_frame(load_golden(nm)[0]))
+    e = np.zeros(_lib.EVENT_CAP, _lib.EVENT_DTYPE); e[:len(ev)] = ev[:_lib.EVENT_CAP]
+    recs.append(rec); cnts.append(n); evs.append(e); evcs.append(nev)
+out = gather_results(np.stack(recs), np.array(cnts, np.int32), np.stack(evs), np.array(evcs, np.int32), dst=0)
+if rank == 0:
+    rec, cnt, ev, evc = out
+    res = [[" ".join(m["msg_tuple"]) for m in M.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]))] for f in range(len(names))]
+    json.dump(res, open(sys.argv[2], "w"))
+else:
+    assert out is None
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_gather_two_ranks_gloo(tmp_path):
+    """world_size-2 run of the N>1 path on CPU (gloo): ragged shards, gather to rank 0, packaging."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    out = tmp_path / "out.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script), ROOT, str(out)],
+                          env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+    res = json.load(open(out))
+    want = [[" ".join(m["msg_tuple"]) for m in load_golden(nm)[2]["messages"]] for nm in ["synth_200000", "synth_100000", "synth_200000"]]
+    assert res == want
