@@ -400,15 +400,26 @@ static void fine_zsig(const float* spec, const ft8o_config* c, int fb, cpx* z) {
     free(scr);
 }
 
-/* |32-point DFT| tones 0..7 of symbol s starting at tb (receiver.py:189-195) */
+/* |32-point DFT| tones 0..7 of symbol s starting at tb (receiver.py:189-195).
+ * Contract: 32 = 4 x 8 decimation in time, outputs 0..7 only:
+ *   u[n2][k] = DFT8_k( x[4 n1 + n2], n1 = 0..7 ),  X[k] = ((u0 + u1 W^k) + u2 W^2k) + u3 W^3k,  W = e^{-2 pi i/32} */
 static void fine_symbol(const cpx* z, int tb, int s, float* g8) {
     static cpx W32[32]; static int ok = 0;
     if (!ok) { make_twiddle(32, W32); ok = 1; }
     int i0 = tb + 32 * s; if (i0 < 0) i0 = 0; if (i0 > 3168) i0 = 3168;
-    for (int t = 0; t < 8; t++) {
-        cpx acc = {0.0f, 0.0f};
-        for (int n = 0; n < 32; n++) acc = cadd(acc, cmul(z[i0 + n], W32[(n * t) & 31]));
-        g8[t] = sqrtf(acc.re * acc.re + acc.im * acc.im);
+    cpx u[4][8];
+    for (int n2 = 0; n2 < 4; n2++) {
+        for (int n1 = 0; n1 < 8; n1++) u[n2][n1] = z[i0 + 4 * n1 + n2];
+        dft8(u[n2]);
+    }
+    for (int k = 0; k < 8; k++) {
+        cpx acc = u[0][k];
+        for (int n2 = 1; n2 < 4; n2++) {
+            cpx t = u[n2][k];
+            if (k != 0) t = cmul(t, W32[(n2 * k) & 31]);
+            acc = cadd(acc, t);
+        }
+        g8[k] = sqrtf(acc.re * acc.re + acc.im * acc.im);
     }
 }
 

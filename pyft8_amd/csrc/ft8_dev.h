@@ -158,6 +158,80 @@ FT8_DEV cpx* lds_fft(cpx* a, cpx* b, const cpx* W, int nseq, int tid, int nthrea
     return FftPasses<N, N, 1, Rs...>::run(a, b, W, nseq, tid, nthreads);
 }
 
+// ------------------------------------------------------------------------------------ register-fused, in-place stages
+// Same arithmetic as the pass-by-pass Stockham schedule above (identical butterflies, identical twiddle
+// multiplies and skip rules), but one thread keeps a whole group of R1*R2 points in registers across two
+// consecutive passes, so the data makes one LDS round trip per *stage* instead of one per pass, and the
+// transform runs in place in a single LDS buffer (load all groups -> barrier -> store all groups).
+//   pass A (R1; n, s; m1 = n/R1) followed by pass B (R2; n/R1, s*R1; m2 = m1/R2), group (p', q):
+//   in : x[q + s (p' + j' m2 + j m1)]      out: z[q + s j + s R1 (R2 p' + j')]      j < R1, j' < R2
+template <int N, int n, int s, int R1, int R2>
+struct Fused2 {
+    static constexpr int m1 = n / R1, m2 = m1 / R2, groups = N / (R1 * R2);
+    // Affine addressing: element (j', j) of the group lives at base + j'*SJP + j*SJ, with compile-time strides, so
+    // every LDS access is one base register plus an immediate offset.  The caller picks base/strides to realise
+    // whatever physical layout it wants for the stage's input and output images.
+    template <int SJP, int SJ>
+    static FT8_DEV void load_affine(const cpx* __restrict__ x, int base, cpx (&a)[R2][R1]) {
+#pragma unroll
+        for (int jp = 0; jp < R2; jp++)
+#pragma unroll
+            for (int j = 0; j < R1; j++) a[jp][j] = x[base + jp * SJP + j * SJ];
+    }
+    template <int SJP, int SJ>
+    static FT8_DEV void store_affine(cpx* __restrict__ z, int base, const cpx (&a)[R2][R1]) {
+#pragma unroll
+        for (int jp = 0; jp < R2; jp++)
+#pragma unroll
+            for (int j = 0; j < R1; j++) z[base + jp * SJP + j * SJ] = a[jp][j];
+    }
+    static FT8_DEV void compute(int g, cpx (&a)[R2][R1], const cpx* __restrict__ W) { compute_pp(g / s, a, W); }
+    static FT8_DEV void compute_pp(int pp, cpx (&a)[R2][R1], const cpx* __restrict__ W) {
+#pragma unroll
+        for (int jp = 0; jp < R2; jp++) {
+            dft<R1>(a[jp]);
+            const int p = pp + jp * m2;
+            if (p != 0) {
+#pragma unroll
+                for (int j = 1; j < R1; j++) a[jp][j] = cmul(a[jp][j], W[j * p * s]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R1; j++) {
+            cpx b[R2];
+#pragma unroll
+            for (int jp = 0; jp < R2; jp++) b[jp] = a[jp][j];
+            dft<R2>(b);
+            if (m2 > 1 && pp != 0) {
+#pragma unroll
+                for (int jp = 1; jp < R2; jp++) b[jp] = cmul(b[jp], W[jp * pp * (s * R1)]);
+            }
+#pragma unroll
+            for (int jp = 0; jp < R2; jp++) a[jp][j] = b[jp];
+        }
+    }
+};
+
+// 8 tones of one 32-sample symbol, shared by 4 lanes (n2 = lane & 3):  32 = 4 x 8 decimation in time.
+//   u[k] = DFT8_k(x[4 n1 + n2]) on lane n2;  X[k] = ((u0 + u1 W^k) + u2 W^2k) + u3 W^3k on the quad leader.
+// `x` holds this lane's 8 samples; returns |X[k]| in mag[0..7] (valid on lanes with n2 == 0).
+FT8_DEV void sym32_quad(cpx* x, int n2, int lane, const cpx* __restrict__ w32, float* mag) {
+    dft<8>(x);
+    const int base = lane & ~3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        cpx t = x[k];
+        if (k != 0 && n2 != 0) t = cmul(t, w32[(n2 * k) & 31]);
+        cpx acc = t;                                   // quad leader: its own term is u0
+#pragma unroll
+        for (int o = 1; o < 4; o++) {
+            cpx v = make_float2(__shfl(t.x, base + o), __shfl(t.y, base + o));
+            acc = cadd(acc, v);
+        }
+        mag[k] = sqrtf(acc.x * acc.x + acc.y * acc.y);
+    }
+}
+
 // ------------------------------------------------------------------------------------ CRC-14 and message validity
 FT8_DEV unsigned ft8_crc14(uint64_t lo, uint64_t hi) {                      // reference decoders.py:123-129
     unsigned r = 0;

@@ -539,36 +539,83 @@ __global__ __launch_bounds__(256) void k_cyc_c(const cpx* __restrict__ Z, cpx* _
 }
 
 // ------------------------------------------------------------------------------------ fine time/frequency sync (receiver.py:140-206)
-// One 256-thread block per candidate.  z = 3200-sample baseband series in LDS.
-FT8_DEV void fine_build_fft(const cpx* __restrict__ S, int fb, cpx* zA, cpx* zB, const Tables& T, int tid, cpx** zres) {
-    for (int k = tid; k < 3200; k += 256) {
-        cpx v = make_float2(0.0f, 0.0f);
-        if (k < 850) {
-            v = S[fb + k];
-            if (k >= 750) { double t = T.taper[k - 750]; v.x = (float)((double)v.x * t); v.y = (float)((double)v.y * t); }
-            v.y = -v.y;
-        } else if (k >= 3050) {
-            int j = k - 3050;
-            v = S[fb - 150 + j];
-            if (j < 100) { double t = T.taper[j]; v.x = (float)((double)v.x * t); v.y = (float)((double)v.y * t); }
-            v.y = -v.y;
-        }
-        zA[k] = v;
-    }
-    __syncthreads();
-    cpx* r = lds_fft<3200, 8, 4, 4, 5, 5>(zA, zB, T.W3200, 1, tid, 256);
-    const float inv = 0.0003125f;
-    for (int k = tid; k < 3200; k += 256) { cpx v = r[k]; r[k] = make_float2(v.x * inv, -(v.y * inv)); }
-    __syncthreads();
-    *zres = r;
+// One 128-thread block per candidate.  The 3200-point inverse FFT (conj o forward o conj) runs in place in
+// one LDS buffer as three register-fused stages [8] | [4,4] | [5,5]; stage 1 reads the tapered spectrum
+// slice straight from global memory and knows that only 1000 of the 3200 bins are non-zero.  The 1/3200
+// scale and the output conjugation are applied where the series is consumed.
+#define FINE_NT 128
+#define FINE_INV 0.0003125f
+
+// conj(taper * spec) for bin k of the rolled 3200-bin slice (receiver.py:180-185); k < 850 or k >= 3050
+FT8_DEV cpx fine_input(const cpx* __restrict__ S, int fb, int k, const double* __restrict__ taper) {
+    cpx v; int ti;
+    if (k < 850) { v = S[fb + k]; ti = (k >= 750) ? k - 750 : -1; }
+    else { const int j = k - 3050; v = S[fb - 150 + j]; ti = (j < 100) ? j : -1; }
+    if (ti >= 0) { const double t = taper[ti]; v.x = (float)((double)v.x * t); v.y = (float)((double)v.y * t); }
+    v.y = -v.y;
+    return v;
 }
 
-FT8_DEV float fine_mag(const cpx* z, const cpx* W32, int tb, int s, int t) {
-    int i0 = tb + 32 * s; if (i0 < 0) i0 = 0; if (i0 > 3168) i0 = 3168;
-    cpx acc = make_float2(0.0f, 0.0f);
-#pragma unroll 8
-    for (int n = 0; n < 32; n++) acc = cadd(acc, cmul(z[i0 + n], W32[(n * t) & 31]));
-    return sqrtf(acc.x * acc.x + acc.y * acc.y);
+// forward FFT of the conjugated slice into z (unscaled, unconjugated), natural Stockham layout, in place.
+// (Measured alternatives, profiles/r01_notes.md: 256-thread blocks 7.96 ms, bank-conflict-free padded/transposed
+// inter-stage layouts 6.92 ms, this version 6.36 ms per 256 frames: the kernel is latency/barrier bound.)
+#define FINE_ZLEN 3200
+FT8_DEV int mapC(int i) { return i; }
+
+FT8_DEV void fine_stage1(const cpx* __restrict__ S, int fb, cpx* z, const cpx* __restrict__ W,
+                         const double* __restrict__ taper, int tid) {
+#pragma unroll 1
+    for (int p = tid; p < 400; p += FINE_NT) {                    // pass [8]: n = 3200, s = 1, m = 400
+        cpx a[8];
+        const cpx zero = make_float2(0.0f, 0.0f);
+        a[0] = fine_input(S, fb, p, taper);
+        a[1] = fine_input(S, fb, p + 400, taper);
+        a[2] = (p < 50) ? fine_input(S, fb, p + 800, taper) : zero;
+        a[3] = zero; a[4] = zero; a[5] = zero; a[6] = zero;
+        a[7] = (p >= 250) ? fine_input(S, fb, p + 2800, taper) : zero;
+        dft<8>(a);
+        z[8 * p] = a[0];
+#pragma unroll
+        for (int j = 1; j < 8; j++) { cpx v = a[j]; if (p != 0) v = cmul(v, W[j * p]); z[8 * p + j] = v; }
+    }
+    __syncthreads();
+}
+FT8_DEV void fine_stage2(cpx* z, const cpx* __restrict__ W, int tid) {
+    typedef Fused2<3200, 400, 8, 4, 4> F;                         // passes [4,4]: n = 400, s = 8; 200 groups
+    cpx a0[4][4], a1[4][4];
+    const int u1 = tid + FINE_NT;
+    const bool two = u1 < F::groups;
+    // group g = (pp = g / 8, q = g % 8): in  q + 8(pp + 25 j' + 100 j),  out  q + 8 j + 32 (4 pp + j')
+    F::load_affine<200, 800>(z, tid, a0);
+    if (two) F::load_affine<200, 800>(z, u1, a1);
+    __syncthreads();
+    F::compute_pp(tid >> 3, a0, W); F::store_affine<32, 8>(z, (tid & 7) + 128 * (tid >> 3), a0);
+    if (two) { F::compute_pp(u1 >> 3, a1, W); F::store_affine<32, 8>(z, (u1 & 7) + 128 * (u1 >> 3), a1); }
+    __syncthreads();
+}
+FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid) {
+    typedef Fused2<3200, 25, 128, 5, 5> F;                        // passes [5,5]: n = 25, s = 128; 128 groups
+    cpx a[5][5];
+    // group q: in  q + 128 (j' + 5 j),  out  q + 128 j + 640 j'
+    F::load_affine<128, 640>(z, tid, a);
+    __syncthreads();
+    F::compute_pp(0, a, W); F::store_affine<640, 128>(z, tid, a);
+    __syncthreads();
+}
+__device__ __noinline__ void fine_fft(const cpx* __restrict__ S, int fb, cpx* z, const Tables& T, int tid) {
+    fine_stage1(S, fb, z, T.W3200, T.taper, tid);
+    fine_stage2(z, T.W3200, tid);
+    fine_stage3(z, T.W3200, tid);
+}
+
+// |32-pt DFT| tones 0..7 of the symbol starting at sample i0, computed by the 4 lanes of a quad
+FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, int lane, const cpx* w32, float* mag) {
+    if (i0 < 0) i0 = 0;
+    if (i0 > 3168) i0 = 3168;
+    cpx x[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) { cpx v = z[mapC(i0 + 4 * n1 + n2)]; x[n1] = make_float2(v.x * FINE_INV, -(v.y * FINE_INV)); }
+    sym32_quad(x, n2, lane, w32, mag);
 }
 
 FT8_DEV float fine_score_from(const float* mg /*[7][7]*/) {
@@ -577,21 +624,19 @@ FT8_DEV float fine_score_from(const float* mg /*[7][7]*/) {
     return (float)(s1 + W6 * s2);
 }
 
-__global__ __launch_bounds__(256) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
-                                              const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
-                                              const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
-                                              float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cpx* zA = reinterpret_cast<cpx*>(smem);
-    cpx* zB = zA + 3200;
-    float* mg = reinterpret_cast<float*>(zB + 3200);   // [8][49] magnitudes, later [79][8] grid
-    float* p = mg + 640;                               // [464]
-    float* llr = p + 464;                              // [176]
-    float* sq = llr + 176;                             // [176]
-    float* sc = sq + 176;                              // [16] scores
-    int* ish = reinterpret_cast<int*>(sc + 16);        // [4]
+__global__ __launch_bounds__(FINE_NT, 4) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
+                                                  const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
+                                                  const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
+                                                  float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
+    __shared__ cpx z[FINE_ZLEN];
+    __shared__ float mg[640];          // [8][49] scoring magnitudes, later the [79][8] grid
+    __shared__ float p[464];
+    __shared__ float llr[176];
+    __shared__ float sq[176];
+    __shared__ float sc[16];
+    __shared__ int ish[4];
     __shared__ cpx w32[32];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     int frame, ci = 0, f0, h0;
     if (trip) { frame = trip[3 * blockIdx.x]; f0 = trip[3 * blockIdx.x + 1]; h0 = trip[3 * blockIdx.x + 2]; }
     else {
@@ -603,14 +648,21 @@ __global__ __launch_bounds__(256) void k_fine(const cpx* __restrict__ spec, ft8r
     }
     if (tid < 32) w32[tid] = T.W32[tid];
     const cpx* S = spec + (size_t)frame * FT8RX_SPEC_BINS;
-    const int fb0 = 50 * f0;
-    const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);
-    cpx* z;
-    // --- time tweaks at ftweak 0: range(-8,8,2)
-    fine_build_fft(S, fb0, zA, zB, T, tid, &z);
-    for (int i = tid; i < 8 * 49; i += 256) {
-        int ti = i / 49, ab = i - ti * 49, a = ab / 7, b = ab - a * 7;
-        mg[i] = fine_mag(z, w32, tb0 - 8 + 2 * ti, 36 + a, b);
+    const int fb0 = 50 * f0;                                      // int(0.5 + fHz*16)
+    const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
+    // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
+    fine_fft(S, fb0, z, T, tid);
+#pragma unroll 1
+    for (int r = 0; r < 2; r++) {
+        const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
+        const bool valid = qd < 56;
+        const int ti = valid ? qd / 7 : 0, a = valid ? qd - 7 * ti : 0;
+        float mag[8];
+        fine_sym_quad(z, tb0 - 8 + 2 * ti + 32 * (36 + a), n2, lane, w32, mag);
+        if (valid && n2 == 0) {
+#pragma unroll
+            for (int b = 0; b < 7; b++) mg[ti * 49 + a * 7 + b] = mag[b];
+        }
     }
     __syncthreads();
     if (tid < 8) sc[tid] = fine_score_from(mg + 49 * tid);
@@ -625,24 +677,43 @@ __global__ __launch_bounds__(256) void k_fine(const cpx* __restrict__ spec, ft8r
     const float score_f0 = sc[8];
     // --- frequency tweaks: range(-32,33,8)
     float best = 0.0f; int ft = 0, last_ft = 0;
+#pragma unroll 1
     for (int i = 0; i < 9; i++) {
-        int fcur = -32 + 8 * i;
+        const int fcur = -32 + 8 * i;
         float s;
         if (fcur == 0) s = score_f0;             // same series, same offset: identical value
         else {
-            fine_build_fft(S, fb0 + fcur, zA, zB, T, tid, &z);
+            fine_fft(S, fb0 + fcur, z, T, tid);
             last_ft = fcur;
-            if (tid < 49) { int a = tid / 7, b = tid - a * 7; mg[tid] = fine_mag(z, w32, tb0 + tt, 36 + a, b); }
+            if (tid < 64) {                       // 7 symbols x 4 lanes on wavefront 0
+                const int qd = tid >> 2, n2 = tid & 3;
+                const bool valid = qd < 7;
+                float mag[8];
+                fine_sym_quad(z, tb0 + tt + 32 * (36 + (valid ? qd : 0)), n2, lane, w32, mag);
+                if (valid && n2 == 0) {
+#pragma unroll
+                    for (int b = 0; b < 7; b++) mg[qd * 7 + b] = mag[b];
+                }
+            }
             __syncthreads();
             if (tid == 0) sc[9] = fine_score_from(mg);
             __syncthreads();
             s = sc[9];
-            __syncthreads();
         }
         if (i == 0 || s > best) { best = s; ft = fcur; }
     }
-    if (ft != last_ft) fine_build_fft(S, fb0 + ft, zA, zB, T, tid, &z);
-    for (int i = tid; i < 632; i += 256) mg[i] = fine_mag(z, w32, tb0 + tt, i >> 3, i & 7);
+    if (ft != last_ft) fine_fft(S, fb0 + ft, z, T, tid);
+#pragma unroll 1
+    for (int r = 0; r < 3; r++) {                 // full 79 x 8 grid
+        const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;
+        const bool valid = sy < 79;
+        float mag[8];
+        fine_sym_quad(z, tb0 + tt + 32 * (valid ? sy : 0), n2, lane, w32, mag);
+        if (valid && n2 == 0) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) mg[sy * 8 + b] = mag[b];
+        }
+    }
     __syncthreads();
     // --- Costas gate (receiver.py:164-167)
     bool match = false;
@@ -655,11 +726,11 @@ __global__ __launch_bounds__(256) void k_fine(const cpx* __restrict__ spec, ft8r
     if (tid < 64) { int nm = __popcll(__ballot(match)); if (tid == 0) ish[1] = nm; }
     __syncthreads();
     const int nsync = ish[1];
-    if (trip && t_sgrid) for (int i = tid; i < 632; i += 256) t_sgrid[(size_t)blockIdx.x * 632 + i] = mg[i];
+    if (trip && t_sgrid) for (int i = tid; i < 632; i += FINE_NT) t_sgrid[(size_t)blockIdx.x * 632 + i] = mg[i];
     int ret = 1; float sd = 0.0f; int snr = 0;
     if (nsync <= 6) ret = 0;           // block-uniform
     else {
-        for (int i = tid; i < 464; i += 256) p[i] = 20.0f * ft8_log10f(mg[8 * (int)d_PAYSYM[i >> 3] + (i & 7)]);   // receiver.py:170
+        for (int i = tid; i < 464; i += FINE_NT) p[i] = 20.0f * ft8_log10f(mg[8 * (int)d_PAYSYM[i >> 3] + (i & 7)]);   // receiver.py:170
         __syncthreads();
         llr_from_p(p, llr, sq, tid, tid < 64, &sd, &snr);
         if (tid == 0) { sc[10] = sd; ish[2] = snr; }
@@ -667,7 +738,7 @@ __global__ __launch_bounds__(256) void k_fine(const cpx* __restrict__ spec, ft8r
         sd = sc[10]; snr = ish[2];
         if (sd <= cfg.llr_sd_min) ret = -1;
         float* out = llr0 + (size_t)blockIdx.x * 174;
-        for (int i = tid; i < 174; i += 256) out[i] = llr[i];
+        for (int i = tid; i < 174; i += FINE_NT) out[i] = llr[i];
     }
     if (tid == 0) {
         if (trip) { int32_t* o = t_out + 5 * (size_t)blockIdx.x; o[0] = ret; o[1] = tt; o[2] = ft; o[3] = nsync; o[4] = snr; t_sd[blockIdx.x] = sd; }
@@ -977,8 +1048,6 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_EDGE_C), FT8_EDGE_C, sizeof(FT8_EDGE_C)) == hipSuccess;
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_VAR_E), FT8_VAR_E, sizeof(FT8_VAR_E)) == hipSuccess;
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_G0), FT8_G0, sizeof(FT8_G0)) == hipSuccess;
-    // kernels that need > 64 KiB of dynamic LDS
-    ok &= hipFuncSetAttribute((const void*)k_fine, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
     if (!ok) { set_err(nullptr, "ft8rx_create: device table upload failed"); ft8rx_destroy(h); return -2; }
     // the never-written grid row 0 (receiver.py:240)
     int nfill = (int)B * FT8RX_GRID_COLS;
@@ -998,7 +1067,6 @@ int ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms
     return 0;
 }
 
-static size_t fine_lds_bytes() { return 2 * 3200 * sizeof(cpx) + (640 + 464 + 176 + 176 + 16 + 4) * sizeof(float); }
 static size_t sync_lds_bytes(const ft8rx_config& c) { return ((size_t)(c.h0_hi - c.h0_lo + 24) * 29 + 512) * sizeof(float); }
 
 #define STAGE(name) do { if (h->profiling) { hipEventRecord(h->pev[h->pnames.size()], h->stream); h->pnames.push_back(name); } } while (0)
@@ -1029,7 +1097,7 @@ int ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int B) {
     k_cyc_b<<<dim3(75, B), 256, 0, s>>>(h->d_A, h->d_Z, h->T);
     k_cyc_c<<<dim3(FT8RX_SPEC_BINS / 256, B), 256, 0, s>>>(h->d_Z, h->d_spec, h->T);
     STAGE("fine");
-    k_fine<<<B * MAXC, 256, fine_lds_bytes(), s>>>(h->d_spec, h->d_rec, h->d_ncand, h->d_llr0, h->T, c, nullptr, nullptr, nullptr, nullptr);
+    k_fine<<<B * MAXC, FINE_NT, 0, s>>>(h->d_spec, h->d_rec, h->d_ncand, h->d_llr0, h->T, c, nullptr, nullptr, nullptr, nullptr);
     STAGE("bp_fine");
     k_bp<<<B * MAXC * 5, 64, 0, s>>>(1, h->d_llr0, h->d_rec, h->d_ncand, h->d_attG, h->d_attB, h->d_saved, h->d_ev, h->d_evcount, c, c.bp_nc0_b, c.bp_iters_b);
     STAGE("select1");
@@ -1157,7 +1225,7 @@ int ft8rx_fine(ft8rx_handle* h, const float* spec, int B, int n, const int32_t* 
     float* d_sd = S.get<float>(n); NEED(d_sd);
     int32_t* d_out = S.get<int32_t>((size_t)n * 5); NEED(d_out);
     float* d_sg = sgrid ? S.get<float>((size_t)n * 632) : nullptr; if (sgrid) NEED(d_sg);
-    k_fine<<<n, 256, fine_lds_bytes(), h->stream>>>(h->d_spec, nullptr, nullptr, d_llr, h->T, h->cfg, d_trip, d_out, d_sd, d_sg);
+    k_fine<<<n, FINE_NT, 0, h->stream>>>(h->d_spec, nullptr, nullptr, d_llr, h->T, h->cfg, d_trip, d_out, d_sd, d_sg);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<int32_t> o((size_t)n * 5);
     HIPCHK(h, hipMemcpy(o.data(), d_out, sizeof(int32_t) * o.size(), hipMemcpyDeviceToHost));
