@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 1: 256)")
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames generated per rank (tiled to --frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams a batch is cut across (1 = one chain of whole-batch launches)")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +113,7 @@ def main():
     host = np.concatenate([frames] * reps)[:B]
     d_audio = torch.from_numpy(host).cuda()
     h = _lib.Handle(device=local, max_frames=B)
+    h.set_streams(args.streams)
     torch.cuda.synchronize()
 
     def barrier():

@@ -93,6 +93,8 @@ int  ft8rx_sync(ft8rx_handle* h);
 int  ft8rx_fetch_results(ft8rx_handle* h, int n_frames, ft8rx_record* records, int32_t* counts,
                          ft8rx_event* events, int32_t* event_counts);
 /* per-kernel HIP-event timing of the most recent enqueue (enable before enqueue). names/ms: up to 16 */
+/* number of HIP streams a batch is cut across (1..8, default 4); profiling mode always uses one */
+int  ft8rx_set_streams(ft8rx_handle* h, int n);
 int  ft8rx_set_profiling(ft8rx_handle* h, int on);
 int  ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms);
 

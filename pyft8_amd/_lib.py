@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libft8rx.so")
+LIB_PATH = os.environ.get("FT8RX_LIB", os.path.join(HERE, "libft8rx.so"))   # FT8RX_LIB: A/B builds of the same ABI
 SRC = os.path.join(HERE, "csrc", "ft8rx.hip")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result",
                "-Wno-unused-value", "-fPIC", "-shared"]
@@ -147,6 +147,9 @@ class Handle:
                                        ev.ctypes.data_as(C.c_void_p), _ptr(evc, C.c_int32))
         self._chk(rc, "ft8rx_fetch_results")
         return rec, cnt, ev, evc
+
+    def set_streams(self, n):
+        self._chk(lib().ft8rx_set_streams(self._h, int(n)), "ft8rx_set_streams")
 
     def set_profiling(self, on):
         lib().ft8rx_set_profiling(self._h, int(bool(on)))

@@ -366,6 +366,10 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
     const int c0 = lane, c1 = lane + 64;
     const int n0 = d_CHK_N[c0], e00 = d_CHK_E0[c0];
     const int n1 = (c1 < 83) ? d_CHK_N[c1] : 0, e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
+    // membership masks of this lane's two checks over the 174 variables (3 x 64 bits each)
+    uint64_t cm0[3] = {0, 0, 0}, cm1[3] = {0, 0, 0};
+    for (int j = 0; j < n0; j++) { int v = d_CHK_V[c0][j]; cm0[v >> 6] |= 1ull << (v & 63); }
+    for (int j = 0; j < n1; j++) { int v = d_CHK_V[c1][j]; cm1[v >> 6] |= 1ull << (v & 63); }
     float mc[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) mc[i] = 0.0f;
@@ -373,14 +377,15 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
     res.has_out = 1;
     if (run_bp) for (int it = 0; it < max_iters; it++) {
         // parity of every check from the hard decisions
-        int par0 = 0, par1 = 0;
-        for (int j = 0; j < n0; j++) par0 ^= (llr[d_CHK_V[c0][j]] > 0.0f) ? 1 : 0;
-        for (int j = 0; j < n1; j++) par1 ^= (llr[d_CHK_V[c1][j]] > 0.0f) ? 1 : 0;
+        const uint64_t h0 = __ballot(llr[lane] > 0.0f), h1 = __ballot(llr[64 + lane] > 0.0f),
+                       h2 = __ballot(lane < 46 && llr[128 + (lane < 46 ? lane : 0)] > 0.0f);
+        const int par0 = (__popcll(h0 & cm0[0]) + __popcll(h1 & cm0[1]) + __popcll(h2 & cm0[2])) & 1;
+        const int par1 = (__popcll(h0 & cm1[0]) + __popcll(h1 & cm1[1]) + __popcll(h2 & cm1[2])) & 1;
         int ncheck = __popcll(__ballot(par0)) + __popcll(__ballot(par1));
         if (it == 0) { res.nc0 = (uint8_t)ncheck; if (ncheck > max_nc0) { res.has_out = 0; break; } }
         if (ncheck == 0) {
-            uint64_t b0 = __ballot(llr[lane] > 0.0f);
-            uint64_t b1 = __ballot(lane < 27 && llr[64 + (lane < 27 ? lane : 0)] > 0.0f);
+            uint64_t b0 = h0;
+            uint64_t b1 = h1 & ((1ull << 27) - 1);
             uint64_t lo, hi;
             int r = ft8_crc_check(b0, b1, &lo, &hi);
             if (r) {
@@ -399,9 +404,17 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
         __syncthreads();
         {
             float Pp = tl[e00];
-            for (int j = 1; j < n0; j++) Pp = Pp * tl[e00 + j];
+#pragma unroll
+            for (int j = 1; j < 6; j++) Pp = Pp * tl[e00 + j];
+            if (n0 == 7) Pp = Pp * tl[e00 + 6];
             P[c0] = Pp;
-            if (c1 < 83) { float Q = tl[e01]; for (int j = 1; j < n1; j++) Q = Q * tl[e01 + j]; P[c1] = Q; }
+            if (c1 < 83) {
+                float Q = tl[e01];
+#pragma unroll
+                for (int j = 1; j < 6; j++) Q = Q * tl[e01 + j];
+                if (n1 == 7) Q = Q * tl[e01 + 6];
+                P[c1] = Q;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -757,6 +770,12 @@ FT8_DEV uint64_t shfl64(uint64_t v, int src) {
     uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
 }
+// broadcast from a wave-uniform source lane through the scalar unit (v_readlane) instead of the LDS crossbar
+FT8_DEV uint64_t readlane64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
 FT8_DEV uint64_t xor_reduce64(uint64_t v) {
     for (int o = 32; o > 0; o >>= 1) {
         uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)(v >> 32), o);
@@ -813,7 +832,12 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
         order[rank] = (uint8_t)i;
     }
     __syncthreads();
-    // ---- Gauss-Jordan over GF(2), most-reliable-basis selection
+    // ---- Gauss-Jordan over GF(2), most-reliable-basis selection.  The sorted column order and the hard
+    // decisions are lifted into registers / wave-uniform masks so the dependent chain of one elimination step
+    // is readlane -> bit test -> ballot -> ctz -> readlane (no LDS access on the critical path).
+    const int ord0 = order[lane], ord1 = order[64 + lane], ord2 = (lane < 46) ? order[128 + lane] : 0;
+    const uint64_t hard0 = __ballot(llr[lane] > 0.0f), hard1 = __ballot(llr[64 + lane] > 0.0f),
+                   hard2 = __ballot(lane < 46 && llr[128 + (lane < 46 ? lane : 0)] > 0.0f);
     uint64_t a0 = d_G0[lane][0], a1 = d_G0[lane][1], a2 = d_G0[lane][2];
     const bool hasB = lane < 27;
     uint64_t b0 = hasB ? d_G0[64 + lane][0] : 0, b1 = hasB ? d_G0[64 + lane][1] : 0, b2 = hasB ? d_G0[64 + lane][2] : 0;
@@ -821,7 +845,9 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
     int kA = -1, kB = -1; bool hardA = false, hardB = false;
     int k = 0;
     for (int ic = 0; ic < 174 && k < 91; ic++) {
-        const int col = order[ic], w = col >> 6, sh = col & 63;
+        const int sel = ic >> 6, il = ic & 63;
+        const int col = __builtin_amdgcn_readlane(sel == 0 ? ord0 : (sel == 1 ? ord1 : ord2), il);
+        const int w = col >> 6, sh = col & 63;
         const uint64_t wa = (w == 0) ? a0 : (w == 1) ? a1 : a2;
         const uint64_t wb = (w == 0) ? b0 : (w == 1) ? b1 : b2;
         const bool bitA = (wa >> sh) & 1ull, bitB = (wb >> sh) & 1ull;
@@ -829,11 +855,19 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
         if (!mA && !mB) continue;
         const bool inA = (mA != 0);
         const int src = inA ? __builtin_ctzll(mA) : __builtin_ctzll(mB);
+#ifndef OSD_READLANE
+#define OSD_READLANE 0   /* measured: scalar readlane 2.19 ms vs ds_bpermute shuffle 2.12 ms per launch */
+#endif
+#if OSD_READLANE
+        const uint64_t p0 = readlane64(inA ? a0 : b0, src), p1 = readlane64(inA ? a1 : b1, src), p2 = readlane64(inA ? a2 : b2, src);
+#else
         const uint64_t p0 = shfl64(inA ? a0 : b0, src), p1 = shfl64(inA ? a1 : b1, src), p2 = shfl64(inA ? a2 : b2, src);
+#endif
         const bool isPivA = inA && lane == src, isPivB = !inA && lane == src;
         if (bitA && !isPivA) { a0 ^= p0; a1 ^= p1; a2 ^= p2; }
         if (bitB && !isPivB) { b0 ^= p0; b1 ^= p1; b2 ^= p2; }
-        const bool hard = llr[col] > 0.0f;
+        const uint64_t hw = (w == 0) ? hard0 : (w == 1) ? hard1 : hard2;
+        const bool hard = (hw >> sh) & 1ull;
         if (isPivA) { usedA = true; kA = k; hardA = hard; }
         if (isPivB) { usedB = true; kB = k; hardB = hard; }
         k++;
@@ -906,6 +940,9 @@ struct ft8rx_handle {
     ft8rx_config cfg;
     int device, max_frames;
     hipStream_t stream;
+    int n_streams;                       // chunks of a batch run their kernel chains on separate streams
+    hipStream_t sub[8];
+    hipEvent_t ev_fork, ev_join[8];
     Tables T;
     std::vector<void*> allocs;
     int16_t* d_audio;            // staging for host-pointer entry points
@@ -985,6 +1022,8 @@ void ft8rx_destroy(ft8rx_handle* h) {
     hipSetDevice(h->device);
     for (void* p : h->allocs) hipFree(p);
     for (auto e : h->pev) hipEventDestroy(e);
+    for (int i = 0; i < 8; i++) { if (h->sub[i]) hipStreamDestroy(h->sub[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1001,6 +1040,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     if (device < 0 || device >= ndev) { set_err(nullptr, "ft8rx_create: device %d out of range (%d devices)", device, ndev); return -1; }
     ft8rx_handle* h = new ft8rx_handle();
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
+    h->n_streams = 4; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
     int rc = 0;
@@ -1048,12 +1088,19 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_EDGE_C), FT8_EDGE_C, sizeof(FT8_EDGE_C)) == hipSuccess;
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_VAR_E), FT8_VAR_E, sizeof(FT8_VAR_E)) == hipSuccess;
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_G0), FT8_G0, sizeof(FT8_G0)) == hipSuccess;
+    {   // CRC-14 syndromes of the 77 unit messages (bit-serial definition, decoders.py:123-129)
+        uint16_t syn[77];
+        for (int pos = 0; pos < 77; pos++) syn[pos] = (uint16_t)ft8_crc14_serial_host(pos < 64 ? (1ull << pos) : 0ull, pos >= 64 ? (1ull << (pos - 64)) : 0ull);
+        ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CRC_SYN), syn, sizeof(syn)) == hipSuccess;
+    }
     if (!ok) { set_err(nullptr, "ft8rx_create: device table upload failed"); ft8rx_destroy(h); return -2; }
     // the never-written grid row 0 (receiver.py:240)
     int nfill = (int)B * FT8RX_GRID_COLS;
     k_fill_row0<<<(nfill + 255) / 256, 256, 0, h->stream>>>(h->d_grid, (int)B);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: init kernel failed"); ft8rx_destroy(h); return -2; }
     for (int i = 0; i < 24; i++) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); }
+    for (int i = 0; i < 8; i++) { hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking); hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming); }
+    hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     *out = h;
     return 0;
 }
@@ -1069,47 +1116,77 @@ int ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms
 
 static size_t sync_lds_bytes(const ft8rx_config& c) { return ((size_t)(c.h0_hi - c.h0_lo + 24) * 29 + 512) * sizeof(float); }
 
-#define STAGE(name) do { if (h->profiling) { hipEventRecord(h->pev[h->pnames.size()], h->stream); h->pnames.push_back(name); } } while (0)
+// the kernel chain for frames [f0, f0+B) on stream s (all buffers are frame-major, so a chunk is a pointer offset)
+static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B, hipStream_t s, bool prof) {
+    const ft8rx_config& c = h->cfg;
+    const size_t F = (size_t)f0;
+    const int16_t* audio = d_audio + F * FT8RX_NSAMP;
+    float* grid = h->d_grid + F * FT8RX_GRID_ROWS * FT8RX_GRID_COLS;
+    float* bs = h->d_best_score + F * NF0MAX; int32_t* bh = h->d_best_h0 + F * NF0MAX;
+    ft8rx_record* rec = h->d_rec + F * MAXC; int32_t* ncand = h->d_ncand + F;
+    float* llr0 = h->d_llr0 + F * MAXC * 174; float* saved = h->d_saved + F * MAXC * 5 * 174;
+    Att* att0 = h->d_att0 + F * MAXC * 5; Att* attG = h->d_attG + F * MAXC * 2; Att* attB = h->d_attB + F * MAXC * 5; Att* attO = h->d_attO + F * MAXC * 10;
+    cpx* A = h->d_A + F * 96000; cpx* Z = h->d_Z + F * 96000; cpx* spec = h->d_spec + F * FT8RX_SPEC_BINS;
+    ft8rx_event* ev = h->d_ev + F * FT8RX_EVENT_CAP; int32_t* evc = h->d_evcount + F;
+#define STAGE(name) do { if (prof) { hipEventRecord(h->pev[h->pnames.size()], s); h->pnames.push_back(name); } } while (0)
+    hipMemsetAsync(evc, 0, sizeof(int32_t) * B, s);
+    STAGE("spectrogram");
+    k_spectrogram<<<dim3(375, B), 256, 0, s>>>(audio, grid, h->T);
+    STAGE("sync");
+    const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
+    k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, c);
+    STAGE("topk");
+    k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c);
+    STAGE("grid_llr");
+    k_grid_llr<<<B * MAXC, 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr);
+    STAGE("bp_grid");
+    k_bp<<<B * MAXC * 5, 64, 0, s>>>(0, llr0, rec, ncand, nullptr, att0, nullptr, ev, evc, c, c.bp_nc0_a, c.bp_iters_a);
+    STAGE("select0");
+    k_select0<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B);
+    STAGE("cycle_fft");
+    k_cyc_a<<<dim3(40, B), 256, 0, s>>>(audio, A, h->T);
+    k_cyc_b<<<dim3(75, B), 256, 0, s>>>(A, Z, h->T);
+    k_cyc_c<<<dim3(FT8RX_SPEC_BINS / 256, B), 256, 0, s>>>(Z, spec, h->T);
+    STAGE("fine");
+    k_fine<<<B * MAXC, FINE_NT, 0, s>>>(spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr);
+    STAGE("bp_fine");
+    k_bp<<<B * MAXC * 5, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b);
+    STAGE("select1");
+    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attG, attB, B, c);
+    STAGE("osd");
+    k_osd<<<B * MAXC * 10, 64, 0, s>>>(0, llr0, saved, attB, rec, ncand, attO, ev, evc, c.osd_single, c.osd_double);
+    STAGE("select2");
+    k_select2<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attO, B);
+    if (prof) hipEventRecord(h->pev[h->pnames.size()], s);
+#undef STAGE
+}
 
 int ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int B) {
     if (!h || !d_audio) return -1;
     if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_enqueue_batch: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
     HIPCHK(h, hipSetDevice(h->device));
-    const ft8rx_config& c = h->cfg;
-    hipStream_t s = h->stream;
     h->pnames.clear();
-    HIPCHK(h, hipMemsetAsync(h->d_evcount, 0, sizeof(int32_t) * B, s));
-    STAGE("spectrogram");
-    k_spectrogram<<<dim3(375, B), 256, 0, s>>>(d_audio, h->d_grid, h->T);
-    STAGE("sync");
-    const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
-    k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(h->d_grid, h->d_best_score, h->d_best_h0, c);
-    STAGE("topk");
-    k_topk<<<B, 1024, 0, s>>>(h->d_best_score, h->d_best_h0, h->d_rec, h->d_ncand, c);
-    STAGE("grid_llr");
-    k_grid_llr<<<B * MAXC, 64, 0, s>>>(h->d_grid, h->d_rec, h->d_ncand, h->d_llr0, c, nullptr, nullptr, nullptr);
-    STAGE("bp_grid");
-    k_bp<<<B * MAXC * 5, 64, 0, s>>>(0, h->d_llr0, h->d_rec, h->d_ncand, nullptr, h->d_att0, nullptr, h->d_ev, h->d_evcount, c, c.bp_nc0_a, c.bp_iters_a);
-    STAGE("select0");
-    k_select0<<<(B * MAXC + 255) / 256, 256, 0, s>>>(h->d_rec, h->d_ncand, h->d_att0, B);
-    STAGE("cycle_fft");
-    k_cyc_a<<<dim3(40, B), 256, 0, s>>>(d_audio, h->d_A, h->T);
-    k_cyc_b<<<dim3(75, B), 256, 0, s>>>(h->d_A, h->d_Z, h->T);
-    k_cyc_c<<<dim3(FT8RX_SPEC_BINS / 256, B), 256, 0, s>>>(h->d_Z, h->d_spec, h->T);
-    STAGE("fine");
-    k_fine<<<B * MAXC, FINE_NT, 0, s>>>(h->d_spec, h->d_rec, h->d_ncand, h->d_llr0, h->T, c, nullptr, nullptr, nullptr, nullptr);
-    STAGE("bp_fine");
-    k_bp<<<B * MAXC * 5, 64, 0, s>>>(1, h->d_llr0, h->d_rec, h->d_ncand, h->d_attG, h->d_attB, h->d_saved, h->d_ev, h->d_evcount, c, c.bp_nc0_b, c.bp_iters_b);
-    STAGE("select1");
-    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(h->d_rec, h->d_ncand, h->d_attG, h->d_attB, B, c);
-    STAGE("osd");
-    k_osd<<<B * MAXC * 10, 64, 0, s>>>(0, h->d_llr0, h->d_saved, h->d_attB, h->d_rec, h->d_ncand, h->d_attO, h->d_ev, h->d_evcount, c.osd_single, c.osd_double);
-    STAGE("select2");
-    k_select2<<<(B * MAXC + 255) / 256, 256, 0, s>>>(h->d_rec, h->d_ncand, h->d_attO, B);
-    if (h->profiling) hipEventRecord(h->pev[h->pnames.size()], s);
+    // profiling mode: one chain on the main stream so that per-stage events bracket whole-batch launches.
+    // normal mode: the batch is cut into n_streams chunks whose chains overlap on separate streams -- the ladder
+    // kernels (BP, OSD, fine sync) are latency bound, so chunks fill each other's stalls.
+    int ns = h->profiling ? 1 : h->n_streams;
+    if (ns > B / 8) ns = B / 8;
+    if (ns <= 1) { enqueue_chain(h, d_audio, 0, B, h->stream, h->profiling); HIPCHK(h, hipGetLastError()); return 0; }
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    const int per = (B + ns - 1) / ns;
+    for (int i = 0; i < ns; i++) {
+        const int f0 = i * per, n = (f0 + per <= B) ? per : B - f0;
+        if (n <= 0) break;
+        HIPCHK(h, hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
+        enqueue_chain(h, d_audio, f0, n, h->sub[i], false);
+        HIPCHK(h, hipEventRecord(h->ev_join[i], h->sub[i]));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+    }
     HIPCHK(h, hipGetLastError());
     return 0;
 }
+
+int ft8rx_set_streams(ft8rx_handle* h, int n) { if (!h || n < 1 || n > 8) return -1; h->n_streams = n; return 0; }
 
 int ft8rx_sync(ft8rx_handle* h) {
     if (!h) return -1;
