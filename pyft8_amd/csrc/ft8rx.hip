@@ -615,7 +615,7 @@ FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid) {
     F::compute_pp(0, a, W); F::store_affine<640, 128>(z, tid, a);
     __syncthreads();
 }
-__device__ __noinline__ void fine_fft(const cpx* __restrict__ S, int fb, cpx* z, const Tables& T, int tid) {
+FT8_DEV void fine_fft(const cpx* __restrict__ S, int fb, cpx* z, const Tables& T, int tid) {
     fine_stage1(S, fb, z, T.W3200, T.taper, tid);
     fine_stage2(z, T.W3200, tid);
     fine_stage3(z, T.W3200, tid);
@@ -637,7 +637,7 @@ FT8_DEV float fine_score_from(const float* mg /*[7][7]*/) {
     return (float)(s1 + W6 * s2);
 }
 
-__global__ __launch_bounds__(FINE_NT, 4) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
+__global__ __launch_bounds__(FINE_NT, 2) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
                                                   const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
                                                   const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
                                                   float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
