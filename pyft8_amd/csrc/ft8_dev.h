@@ -171,6 +171,18 @@ struct Fused2 {
     // Affine addressing: element (j', j) of the group lives at base + j'*SJP + j*SJ, with compile-time strides, so
     // every LDS access is one base register plus an immediate offset.  The caller picks base/strides to realise
     // whatever physical layout it wants for the stage's input and output images.
+    // pass A only (R2 butterflies of radix R1 + twiddles); pass B is done by the caller (output pruning)
+    static FT8_DEV void compute_passA(int pp, cpx (&a)[R2][R1], const cpx* __restrict__ W) {
+#pragma unroll
+        for (int jp = 0; jp < R2; jp++) {
+            dft<R1>(a[jp]);
+            const int p = pp + jp * m2;
+            if (p != 0) {
+#pragma unroll
+                for (int j = 1; j < R1; j++) a[jp][j] = cmul(a[jp][j], W[j * p * s]);
+            }
+        }
+    }
     template <int SJP, int SJ>
     static FT8_DEV void load_affine(const cpx* __restrict__ x, int base, cpx (&a)[R2][R1]) {
 #pragma unroll

@@ -606,19 +606,35 @@ FT8_DEV void fine_stage2(cpx* z, const cpx* __restrict__ W, int tid) {
     if (two) { F::compute_pp(u1 >> 3, a1, W); F::store_affine<32, 8>(z, (u1 & 7) + 128 * (u1 >> 3), a1); }
     __syncthreads();
 }
-FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid) {
+// Only output samples in [lo, hi) are needed (the scoring IFFTs read one Costas block = ~230 samples): a final
+// radix-5 butterfly (q, j) produces samples q + 128 j + 640 j', at most one of which can fall in a window
+// shorter than 640, so butterflies with no sample in the window are skipped.  Needed outputs are bit-identical.
+FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int hi) {
     typedef Fused2<3200, 25, 128, 5, 5> F;                        // passes [5,5]: n = 25, s = 128; 128 groups
     cpx a[5][5];
     // group q: in  q + 128 (j' + 5 j),  out  q + 128 j + 640 j'
     F::load_affine<128, 640>(z, tid, a);
     __syncthreads();
-    F::compute_pp(0, a, W); F::store_affine<640, 128>(z, tid, a);
+    F::compute_passA(0, a, W);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int r = tid + 128 * j;
+        const int first = (lo <= r) ? r : r + 640 * ((lo - r + 639) / 640);   // smallest r + 640 j' >= lo
+        if (first < hi && first < 3200) {
+            cpx b[5];
+#pragma unroll
+            for (int jp = 0; jp < 5; jp++) b[jp] = a[jp][j];
+            dft<5>(b);                                             // last pass: no twiddles
+#pragma unroll
+            for (int jp = 0; jp < 5; jp++) z[r + 640 * jp] = b[jp];
+        }
+    }
     __syncthreads();
 }
-FT8_DEV void fine_fft(const cpx* __restrict__ S, int fb, cpx* z, const Tables& T, int tid) {
+FT8_DEV void fine_fft(const cpx* __restrict__ S, int fb, cpx* z, const Tables& T, int tid, int lo, int hi) {
     fine_stage1(S, fb, z, T.W3200, T.taper, tid);
     fine_stage2(z, T.W3200, tid);
-    fine_stage3(z, T.W3200, tid);
+    fine_stage3(z, T.W3200, tid, lo, hi);
 }
 
 // |32-pt DFT| tones 0..7 of the symbol starting at sample i0, computed by the 4 lanes of a quad
@@ -664,7 +680,7 @@ __global__ __launch_bounds__(FINE_NT, 2) void k_fine(const cpx* __restrict__ spe
     const int fb0 = 50 * f0;                                      // int(0.5 + fHz*16)
     const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
     // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
-    fine_fft(S, fb0, z, T, tid);
+    fine_fft(S, fb0, z, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43);   // the 8 time tweaks of the middle Costas block
 #pragma unroll 1
     for (int r = 0; r < 2; r++) {
         const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
@@ -696,7 +712,7 @@ __global__ __launch_bounds__(FINE_NT, 2) void k_fine(const cpx* __restrict__ spe
         float s;
         if (fcur == 0) s = score_f0;             // same series, same offset: identical value
         else {
-            fine_fft(S, fb0 + fcur, z, T, tid);
+            fine_fft(S, fb0 + fcur, z, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43);
             last_ft = fcur;
             if (tid < 64) {                       // 7 symbols x 4 lanes on wavefront 0
                 const int qd = tid >> 2, n2 = tid & 3;
@@ -715,7 +731,7 @@ __global__ __launch_bounds__(FINE_NT, 2) void k_fine(const cpx* __restrict__ spe
         }
         if (i == 0 || s > best) { best = s; ft = fcur; }
     }
-    if (ft != last_ft) fine_fft(S, fb0 + ft, z, T, tid);
+    fine_fft(S, fb0 + ft, z, T, tid, 0, 3200);   // full series for the 79 x 8 grid
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {                 // full 79 x 8 grid
         const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;

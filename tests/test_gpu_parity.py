@@ -295,3 +295,62 @@ def test_receiver_surface_matches_reference_listing():
     k = [i for i, r in enumerate(js["osd_result"]) if r is not None][0]
     assert " ".join(decoders.osd_012(gold["osd_llr_in"][k])) == js["osd_result"][k]
     assert decoders.unpack(int('00000000000000000100011011110000010010000000000111000001100011111000010010001', 2)) == ("CQ DX", "G1OJS", "IO90")
+
+
+def _decode_with(cfg_kw, audio):
+    from pyft8_amd import _lib
+    cfg = _lib.default_config(**cfg_kw)
+    h = _lib.Handle(cfg, max_frames=len(audio))
+    try:
+        return h.decode_batch(audio)
+    finally:
+        h.close()
+
+
+def test_large_batch_decode_set_equality():
+    """96 fresh synthetic frames (config-1 recipe): every candidate record and every message identical to the oracle."""
+    from pyft8_amd import _lib, synth
+    audio = synth.make_batch(50000, 96)
+    rec, cnt, ev, evc = _decode_with({}, audio)
+    ocfg = O.default_config(**_lib.fft_plans())
+    total = 0
+    for i in range(len(audio)):
+        total += _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
+    assert total > 96 * 20
+
+
+def test_extension_knobs_pipeline():
+    """BASELINE config 2/4 knobs (BP 30 iterations, OSD 40 single / 3 double flips): no reference counterpart,
+    the oracle run with the same knobs is the checker."""
+    from pyft8_amd import _lib, synth
+    audio = np.stack([synth.make_frame(70000 + i, n_signals=30, snr_range=(-20.0, -8.0)) for i in range(12)])
+    kw = dict(bp_iters_b=30, osd_single=40, osd_double=3)
+    rec, cnt, ev, evc = _decode_with(kw, audio)
+    ocfg = O.default_config(**_lib.fft_plans(), **kw)
+    for i in range(len(audio)):
+        _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
+
+
+def test_low_snr_frames():
+    """Config-4 style stress: few weak signals (-24..-18 dB); OSD does most of the decoding."""
+    from pyft8_amd import _lib, synth
+    audio = np.stack([synth.make_frame(90000 + i, n_signals=10, snr_range=(-24.0, -18.0)) for i in range(12)])
+    rec, cnt, ev, evc = _decode_with({}, audio)
+    ocfg = O.default_config(**_lib.fft_plans())
+    for i in range(len(audio)):
+        _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
+
+
+def test_reduced_search_ranges():
+    """Non-default Receiver kwargs (pyft8.py:136 intent: sync_score_min=100, max_cands=150) and a narrower search window."""
+    from pyft8_amd import _lib, synth
+    from pyft8_amd.receiver import config_from_kwargs
+    audio = synth.make_batch(60000, 4)
+    cfg = config_from_kwargs(sync_score_min=100, max_cands=150, search_freq_range=(300, 2500), search_time_range=(-1.0, 2.0))
+    h = _lib.Handle(cfg, max_frames=4)
+    rec, cnt, ev, evc = h.decode_batch(audio)
+    h.close()
+    ocfg = O.default_config(**_lib.fft_plans(), sync_score_min=100.0, max_cands=150, f0_lo=cfg.f0_lo, f0_hi=cfg.f0_hi,
+                            h0_lo=cfg.h0_lo, h0_hi=cfg.h0_hi)
+    for i in range(4):
+        _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
