@@ -94,7 +94,11 @@ FT8_DEV void log_event(ft8rx_event* ev, int32_t* evcount, int frame, int cand, i
 __global__ __launch_bounds__(256) void k_spectrogram(const int16_t* __restrict__ audio, float* __restrict__ grid, Tables T) {
     __shared__ cpx bufA[1920];
     __shared__ cpx bufB[1920];
-    const int hop = blockIdx.x + 1, f = blockIdx.y, tid = threadIdx.x;
+    // XCD-aware hop mapping: workgroup id -> XCD is id % 8 and gridDim.x = 376 = 8 * 47, so the 47 workgroups of a
+    // frame that land on one XCD take 47 consecutive hops: each XCD's L2 then sees one eighth of the frame's audio
+    // (8x overlapping windows) instead of all of it.
+    const int hop = (blockIdx.x & 7) * 47 + (blockIdx.x >> 3) + 1, f = blockIdx.y, tid = threadIdx.x;
+    if (hop > 375) return;
     const int16_t* a = audio + (size_t)f * FT8RX_NSAMP;
     const int base = 480 * hop - 3840;
     for (int m = tid; m < 1920; m += 256) {
@@ -506,7 +510,10 @@ __global__ void k_select2(ft8rx_record* rec, const int32_t* ncand, const Att* at
 __global__ __launch_bounds__(256) void k_cyc_a(const int16_t* __restrict__ audio, cpx* __restrict__ A, Tables T) {
     __shared__ cpx bufA[8 * 300];
     __shared__ cpx bufB[8 * 300];
-    const int f = blockIdx.y, tid = threadIdx.x, n2b = 8 * blockIdx.x;
+    // XCD-aware tile mapping (workgroup id % 8 = XCD, gridDim.x = 40 = 8 * 5): one XCD takes 5 adjacent column tiles,
+    // i.e. 160 contiguous bytes of every audio row, so the 128-B lines are shared inside one L2 instead of four.
+    const int tile = (blockIdx.x & 7) * 5 + (blockIdx.x >> 3);
+    const int f = blockIdx.y, tid = threadIdx.x, n2b = 8 * tile;
     const int16_t* a = audio + (size_t)f * FT8RX_NSAMP;
     for (int i = tid; i < 2400; i += 256) {
         int c = i & 7, n1 = i >> 3;
@@ -807,10 +814,8 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
                                             const int32_t* __restrict__ ncand, Att* __restrict__ attO,
                                             ft8rx_event* ev, int32_t* evcount, int singles, int doubles) {
     __shared__ float llr[176];
-    __shared__ uint8_t order[176];
+    __shared__ uint64_t skey[256];
     __shared__ uint64_t flip[64][2];
-    __shared__ int16_t tri[OSD_MAXTRIALS][2];
-    __shared__ int ntr_s;
     const int lane = threadIdx.x;
     int frame = 0, ci = 0, slot = 0; size_t vec = blockIdx.x;
     if (mode == 0) {
@@ -826,44 +831,67 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
     } else {
         for (int i = lane; i < 174; i += 64) llr[i] = llr_in[vec * 174 + i];
     }
-    if (lane == 0) {     // trial list in the reference's order: order-0, singles, restricted doubles
-        int n = 0;
-        tri[n][0] = -1; tri[n][1] = -1; n++;
-        for (int i = 0; i < singles && n < OSD_MAXTRIALS; i++) { tri[n][0] = (int16_t)i; tri[n][1] = -1; n++; }
-        for (int i = 0; i < singles; i++) for (int j = 0; j < doubles; j++) if (j < i && n < OSD_MAXTRIALS) { tri[n][0] = (int16_t)i; tri[n][1] = (int16_t)j; n++; }
-        ntr_s = n;
-    }
     __syncthreads();
-    // ---- reliability order: |llr| descending, ties and NaNs (last) by index (fixed rule for np.argsort, decoders.py:226)
-    for (int i = lane; i < 174; i += 64) {
-        float ki = __builtin_fabsf(llr[i]); bool ni = (ki != ki);
-        int rank = 0;
-        for (int j = 0; j < 174; j++) {
-            float kj = __builtin_fabsf(llr[j]); bool nj = (kj != kj);
-            bool before;
-            if (ni) before = nj ? (j < i) : true;
-            else before = nj ? false : ((kj > ki) || (kj == ki && j < i));
-            rank += before ? 1 : 0;
+    // ---- reliability order: |llr| descending, ties and NaNs (last) by index (fixed rule for np.argsort, decoders.py:226).
+    // Bitonic network over 256 composite keys ((~magnitude bits) << 32 | index) in LDS: 36 compare-exchange steps.
+    for (int i = lane; i < 256; i += 64) {
+        uint64_t key = ~0ull;
+        if (i < 174) {
+            const float x = llr[i];
+            const uint32_t k32 = (x != x) ? 0u : ((__float_as_uint(x) & 0x7fffffffu) + 1u);
+            key = ((uint64_t)(0xFFFFFFFFu - k32) << 32) | (uint32_t)i;
         }
-        order[rank] = (uint8_t)i;
+        skey[i] = key;
     }
     __syncthreads();
+    for (int size = 2; size <= 256; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) {
+                const int t = lane + 64 * h2;
+                const int pos = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                const uint64_t ka = skey[pos], kb = skey[pos + stride];
+                const bool up = ((pos & size) == 0);
+                if ((ka > kb) == up) { skey[pos] = kb; skey[pos + stride] = ka; }
+            }
+            __syncthreads();
+        }
+    }
     // ---- Gauss-Jordan over GF(2), most-reliable-basis selection.  The sorted column order and the hard
     // decisions are lifted into registers / wave-uniform masks so the dependent chain of one elimination step
     // is readlane -> bit test -> ballot -> ctz -> readlane (no LDS access on the critical path).
-    const int ord0 = order[lane], ord1 = order[64 + lane], ord2 = (lane < 46) ? order[128 + lane] : 0;
+    const int ord0 = (int)(uint32_t)skey[lane], ord1 = (int)(uint32_t)skey[64 + lane], ord2 = (lane < 46) ? (int)(uint32_t)skey[128 + lane] : 0;
     const uint64_t hard0 = __ballot(llr[lane] > 0.0f), hard1 = __ballot(llr[64 + lane] > 0.0f),
                    hard2 = __ballot(lane < 46 && llr[128 + (lane < 46 ? lane : 0)] > 0.0f);
     uint64_t a0 = d_G0[lane][0], a1 = d_G0[lane][1], a2 = d_G0[lane][2];
     const bool hasB = lane < 27;
     uint64_t b0 = hasB ? d_G0[64 + lane][0] : 0, b1 = hasB ? d_G0[64 + lane][1] : 0, b2 = hasB ? d_G0[64 + lane][2] : 0;
-    bool usedA = false, usedB = !hasB;
+    // Basis exchange.  G0 = [I | A^T] is already reduced for the systematic basis: row r owns unit column r.
+    // Columns are visited in reliability order exactly as in the reference (decoders.py:228-242) and accepted
+    // iff independent of the columns accepted so far, but
+    //   * a column that is still the unit column of a not-yet-locked row is accepted by locking that row
+    //     (no row operation, no broadcast);
+    //   * any other column is accepted iff it has a 1 in some unlocked row; then one elimination step makes
+    //     it that row's unit column (the row's previous basis column simply leaves the basis).
+    // The selected basis, the reduced rows and the acceptance order k are identical to plain Gauss-Jordan;
+    // only about half of the accepted columns need row operations.
+    int bcolA = lane, bcolB = hasB ? 64 + lane : -1;       // basis column currently owned by each row
+    bool usedA = false, usedB = !hasB;                      // "locked": the row's basis column is in the chosen set
     int kA = -1, kB = -1; bool hardA = false, hardB = false;
     int k = 0;
     for (int ic = 0; ic < 174 && k < 91; ic++) {
         const int sel = ic >> 6, il = ic & 63;
         const int col = __builtin_amdgcn_readlane(sel == 0 ? ord0 : (sel == 1 ? ord1 : ord2), il);
         const int w = col >> 6, sh = col & 63;
+        const uint64_t hw = (w == 0) ? hard0 : (w == 1) ? hard1 : hard2;
+        const bool hard = (hw >> sh) & 1ull;
+        const uint64_t uA = __ballot(bcolA == col && !usedA), uB = __ballot(bcolB == col && !usedB);
+        if (uA | uB) {                                       // still a unit column of an unlocked row: just lock it
+            if (uA) { if (bcolA == col) { usedA = true; kA = k; hardA = hard; } }
+            else    { if (bcolB == col) { usedB = true; kB = k; hardB = hard; } }
+            k++;
+            continue;
+        }
         const uint64_t wa = (w == 0) ? a0 : (w == 1) ? a1 : a2;
         const uint64_t wb = (w == 0) ? b0 : (w == 1) ? b1 : b2;
         const bool bitA = (wa >> sh) & 1ull, bitB = (wb >> sh) & 1ull;
@@ -871,21 +899,12 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
         if (!mA && !mB) continue;
         const bool inA = (mA != 0);
         const int src = inA ? __builtin_ctzll(mA) : __builtin_ctzll(mB);
-#ifndef OSD_READLANE
-#define OSD_READLANE 0   /* measured: scalar readlane 2.19 ms vs ds_bpermute shuffle 2.12 ms per launch */
-#endif
-#if OSD_READLANE
-        const uint64_t p0 = readlane64(inA ? a0 : b0, src), p1 = readlane64(inA ? a1 : b1, src), p2 = readlane64(inA ? a2 : b2, src);
-#else
         const uint64_t p0 = shfl64(inA ? a0 : b0, src), p1 = shfl64(inA ? a1 : b1, src), p2 = shfl64(inA ? a2 : b2, src);
-#endif
         const bool isPivA = inA && lane == src, isPivB = !inA && lane == src;
         if (bitA && !isPivA) { a0 ^= p0; a1 ^= p1; a2 ^= p2; }
         if (bitB && !isPivB) { b0 ^= p0; b1 ^= p1; b2 ^= p2; }
-        const uint64_t hw = (w == 0) ? hard0 : (w == 1) ? hard1 : hard2;
-        const bool hard = (hw >> sh) & 1ull;
-        if (isPivA) { usedA = true; kA = k; hardA = hard; }
-        if (isPivB) { usedB = true; kB = k; hardB = hard; }
+        if (isPivA) { usedA = true; kA = k; hardA = hard; bcolA = col; }
+        if (isPivB) { usedB = true; kB = k; hardB = hard; bcolB = col; }
         k++;
     }
     // order-0 codeword (message part = first 91 bits) and the flip rows
@@ -894,7 +913,12 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
     if (kA >= 0 && 90 - kA < 64 && 90 - kA >= 0) { flip[90 - kA][0] = a0; flip[90 - kA][1] = a1; }
     if (kB >= 0 && 90 - kB < 64 && 90 - kB >= 0) { flip[90 - kB][0] = b0; flip[90 - kB][1] = b1; }
     __syncthreads();
-    const int ntr = ntr_s;
+    // trial t in the reference's order (decoders.py:248-272): 0 = order-0, 1..S = single flips i = t-1, then the
+    // restricted double flips (i, j), i < S, j < min(i, D), i-major.
+    int npairs = 0;
+    for (int i = 0; i < singles; i++) npairs += (i < doubles) ? i : doubles;
+    const int ntr = 1 + singles + npairs;
+    const int dtri = doubles * (doubles - 1) / 2;          // pairs with i < D
     const uint64_t M1 = (1ull << 27) - 1;
     Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
     const int ipass = (slot < 5) ? 5 : 6;
@@ -902,8 +926,14 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
         const int t = base + lane;
         int r = 0; uint64_t lo = 0, hi = 0;
         if (t < ntr) {
+            int i = -1, j = -1;
+            if (t >= 1 && t <= singles) i = t - 1;
+            else if (t > singles) {
+                const int u = t - 1 - singles;
+                if (u < dtri) { i = 1; while ((i + 1) * i / 2 <= u) i++; j = u - i * (i - 1) / 2; }
+                else { const int v = u - dtri; i = doubles + v / doubles; j = v - (v / doubles) * doubles; }
+            }
             uint64_t w0 = c0, w1 = c1;
-            int i = tri[t][0], j = tri[t][1];
             if (i >= 0) { w0 ^= flip[i][0]; w1 ^= flip[i][1]; }
             if (j >= 0) { w0 ^= flip[j][0]; w1 ^= flip[j][1]; }
             r = ft8_crc_check(w0, w1 & M1, &lo, &hi);
@@ -1147,7 +1177,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
 #define STAGE(name) do { if (prof) { hipEventRecord(h->pev[h->pnames.size()], s); h->pnames.push_back(name); } } while (0)
     hipMemsetAsync(evc, 0, sizeof(int32_t) * B, s);
     STAGE("spectrogram");
-    k_spectrogram<<<dim3(375, B), 256, 0, s>>>(audio, grid, h->T);
+    k_spectrogram<<<dim3(376, B), 256, 0, s>>>(audio, grid, h->T);
     STAGE("sync");
     const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
     k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, c);
@@ -1245,7 +1275,7 @@ int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid)
     if (!h || !audio || !grid || B < 1 || B > h->max_frames) return -1;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
-    k_spectrogram<<<dim3(375, B), 256, 0, h->stream>>>(h->d_audio, h->d_grid, h->T);
+    k_spectrogram<<<dim3(376, B), 256, 0, h->stream>>>(h->d_audio, h->d_grid, h->T);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(grid, h->d_grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyDeviceToHost));
     return 0;
