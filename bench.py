@@ -90,7 +90,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 1: 256)")
-    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames generated per rank (tiled to --frames)")
+    ap.add_argument("--unique", type=int, default=64, help="(host generator only) distinct frames generated per rank, tiled to --frames")
+    ap.add_argument("--host-synth", action="store_true", help="generate frames with the numpy generator instead of the device kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams a batch is cut across (1 = one chain of whole-batch launches)")
     args = ap.parse_args()
@@ -107,13 +108,21 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from pyft8_amd import _lib, messages
     B = args.frames
-    uniq = min(args.unique, B)
-    frames = make_frames(rank * 1000000, uniq)
-    reps = (B + uniq - 1) // uniq
-    host = np.concatenate([frames] * reps)[:B]
-    d_audio = torch.from_numpy(host).cuda()
     h = _lib.Handle(device=local, max_frames=B)
     h.set_streams(args.streams)
+    if args.host_synth:
+        uniq = min(args.unique, B)
+        frames = make_frames(rank * 1000000, uniq)
+        reps = (B + uniq - 1) // uniq
+        d_audio = torch.from_numpy(np.concatenate([frames] * reps)[:B]).cuda()
+        data_desc = f"{uniq} distinct numpy-generated frames tiled to {B}"
+    else:
+        # B distinct frames per rank, generated on the GPU (k_synth: GFSK + Philox noise), config-1 recipe
+        uniq = B
+        d_audio = torch.empty((B, _lib.NSAMP), dtype=torch.int16, device="cuda")
+        h.synth_frames(d_audio.data_ptr(), rank * 1000000, B, n_signals=50, snr_range=(-10.0, 10.0))
+        frames = d_audio[:64].cpu().numpy()           # CPU-baseline sample
+        data_desc = f"{B} distinct device-generated frames"
     torch.cuda.synchronize()
 
     def barrier():
@@ -167,7 +176,7 @@ def main():
             "metric": "FT8 15-s frames decoded/sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config 1: batch of {B} synthetic 15-s frames per GPU ({uniq} distinct, tiled), 50 signals/frame, "
+            "config": {"workload": f"config 1: batch of {B} synthetic 15-s frames per GPU ({data_desc}), 50 signals/frame, "
                                    "-10..+10 dB SNR, Receiver defaults (BP 5/20 iters, OSD 30/2)",
                        "frames_per_gpu": B, "decoded_candidates_per_frame": n_dec / B,
                        "unique_messages_first16": n_msgs, "parallelism": f"frames sharded over {world} GPU(s), no collective"},

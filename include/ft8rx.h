@@ -125,6 +125,14 @@ int  ft8rx_osd(ft8rx_handle* h, const float* llr, int n, int singleflips, int do
 int  ft8rx_crc_valid(ft8rx_handle* h, const float* cw91, int n, int32_t* res, uint64_t* msg_lo, uint64_t* msg_hi);
 /* unpack() validity predicate (decoders.py:16-115) on n 77-bit words */
 int  ft8rx_valid77(ft8rx_handle* h, const uint64_t* msg_lo, const uint64_t* msg_hi, int n, int32_t* valid);
+/* Workload generator (modelled on transmitter.py:41-70): n_frames synthetic 15-s frames of
+ * n_signals GFSK signals + Philox white noise, written to the device buffer d_audio[n_frames][180000] int16.
+ * signal_table: n_frames*n_signals records laid out as pyft8_amd/synth.py:SIGNAL_DTYPE; pulse_cumsum: 5761 doubles. */
+int  ft8rx_synth_frames(ft8rx_handle* h, uint64_t seed, int first_index, int n_frames, int n_signals,
+                        const void* signal_table, int signal_bytes, const double* pulse_cumsum, int16_t* d_audio);
+/* the handle's own device audio buffer ([max_frames][180000] int16) and a D2H copy helper (tests, tools) */
+int16_t* ft8rx_staging_audio(ft8rx_handle* h);
+int  ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes);
 /* arithmetic-contract probes: which 0 = log10f, 1 = tanhf; 2 = forward FFT of length n (x = interleaved complex) */
 int  ft8rx_math_probe(ft8rx_handle* h, int which, const float* x, int n, float* y);
 

@@ -64,6 +64,8 @@ def lib():
         L.ft8rx_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.ft8rx_destroy.argtypes = [C.c_void_p]
         L.ft8rx_destroy.restype = None
+        L.ft8rx_staging_audio.restype = C.c_void_p
+        L.ft8rx_staging_audio.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -249,6 +251,25 @@ class Handle:
         out = np.zeros(len(lo), np.int32)
         self._chk(lib().ft8rx_valid77(self._h, _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), len(lo), _ptr(out, C.c_int32)), "ft8rx_valid77")
         return out
+
+    def staging_ptr(self):
+        return int(lib().ft8rx_staging_audio(self._h))
+
+    def download_audio(self, d_ptr, n_frames):
+        out = np.empty((n_frames, NSAMP), np.int16)
+        self._chk(lib().ft8rx_copy_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr), C.c_uint64(out.nbytes)), "ft8rx_copy_to_host")
+        return out
+
+    def synth_frames(self, d_audio_ptr, start, count, n_signals=50, snr_range=(-10.0, 10.0), seed=0x4654385F53594E54):
+        """Fill the device buffer at d_audio_ptr ([count][180000] int16) with synthetic frames; returns the truth list."""
+        from . import synth
+        recs, truth = synth.device_signal_table(start, count, n_signals, snr_range)
+        assert recs.dtype.itemsize == synth.SIGNAL_DTYPE.itemsize
+        q = np.ascontiguousarray(synth.pulse_cumsum(), np.float64)
+        self._chk(lib().ft8rx_synth_frames(self._h, C.c_uint64(seed), int(start), int(count), int(n_signals),
+                                           recs.ctypes.data_as(C.c_void_p), int(recs.dtype.itemsize), _ptr(q, C.c_double),
+                                           C.c_void_p(d_audio_ptr)), "ft8rx_synth_frames")
+        return truth
 
     def math_probe(self, which, x):
         if which == 2:

@@ -209,3 +209,45 @@ def make_frame(index, n_signals=50, snr_range=(-10.0, 10.0), seed_base=SEED_BASE
 
 def make_batch(start, count, **kw):
     return np.stack([make_frame(start + i, **kw) for i in range(count)])
+
+
+# ----------------------------------------------------------------------------- device generator support
+# Record layout of csrc/ft8rx.hip:SynthSig (one per signal).
+SIGNAL_DTYPE = np.dtype([("f0", "<f8"), ("cum", "<f8", (82,)), ("amp", "<f4"), ("i0", "<i4"), ("ext", "u1", (84,))], align=True)
+
+
+def pulse_cumsum():
+    """Q[k] = sum_{t<k} pulse[t], k = 0..5760 (the integrated GFSK frequency pulse)."""
+    global _PULSE
+    if _PULSE is None:
+        _PULSE = _gfsk_pulse()
+    return np.concatenate([[0.0], np.cumsum(_PULSE)])
+
+
+def device_signal_table(start, count, n_signals=50, snr_range=(-10.0, 10.0), seed_base=SEED_BASE):
+    """Signal parameters for ft8rx_synth_frames: same recipe as make_frame (messages, f0, t0, SNR drawn from the
+    per-frame Philox stream); the noise itself is generated on the device.  -> (records[count, n_signals], truth)."""
+    Q = pulse_cumsum()
+    qs = np.zeros(81)
+    qs[0], qs[1] = Q[3840], Q[1920]
+    recs = np.zeros((count, max(1, n_signals)), SIGNAL_DTYPE)
+    truth = []
+    for fi in range(count):
+        rng = np.random.Generator(np.random.Philox(key=seed_base + int(start + fi)))
+        tr = []
+        for s in range(n_signals):
+            msg = random_message(rng)
+            f0 = rng.uniform(200.0, 2800.0)
+            t0 = 0.5 + rng.uniform(-0.5, 1.0)
+            snr = rng.uniform(*snr_range)
+            tones = tones79(pack77(*msg))
+            ext = np.array([tones[0]] + list(tones) + [tones[-1]], dtype=np.float64)
+            r = recs[fi, s]
+            r["f0"] = f0
+            r["cum"][1:] = np.cumsum(ext * (Q[5760] - qs))
+            r["amp"] = np.sqrt(2.0 * (2500.0 / 6000.0) * 10.0 ** (snr / 10.0))
+            r["i0"] = int(round(t0 * FS))
+            r["ext"][:81] = ext.astype(np.uint8)
+            tr.append(dict(msg=" ".join(msg), f0=float(f0), t0=float(t0), snr=float(snr)))
+        truth.append(tr)
+    return recs, truth
