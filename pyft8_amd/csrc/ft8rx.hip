@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, fl
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nh0 = cfg.h0_hi - cfg.h0_lo;
     const int nrows = nh0 + 24;
-    float* tile = reinterpret_cast<float*>(smem);                 // [nrows][29]
+    double* T = reinterpret_cast<double*>(smem);                   // [nrows][16] 14-bin window sums (fp64)
+    float* tile = reinterpret_cast<float*>(T + nrows * 16);       // [nrows][29]
     float* redS = tile + nrows * 29;                              // [256]
     int* redH = reinterpret_cast<int*>(redS + 256);               // [256]
     const int f = blockIdx.y, tid = threadIdx.x;
@@ -150,17 +151,25 @@ __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, fl
         tile[i] = (col < FT8RX_GRID_COLS) ? grid_at(g, rlo + r, col) : 0.0f;
     }
     __syncthreads();
+    // T[r][f] = sum_{b<14} tile[r][f+b], accumulated in the contract's order (b ascending, fp64); every time offset that
+    // touches row r reuses it, so the 98-tap correlation becomes 7 window sums + 14 tone-bin reads.
+    for (int i = tid; i < nrows * 16; i += 256) {
+        const float* row = tile + (i >> 4) * 29 + (i & 15);
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < 14; b++) t += (double)row[b];
+        T[i] = t;
+    }
+    __syncthreads();
     const int f0l = tid & 15;
     float best = 0.0f; int bh = 0;
     for (int hi = tid >> 4; hi < nh0; hi += 16) {
         double s1 = 0.0, tsum = 0.0;
 #pragma unroll
         for (int s = 0; s < 7; s++) {
-            const float* row = tile + (hi + 4 * s) * 29 + f0l;
-            double t = 0.0;
-#pragma unroll
-            for (int b = 0; b < 14; b++) t += (double)row[b];
-            tsum += t;
+            const int r = hi + 4 * s;
+            const float* row = tile + r * 29 + f0l;
+            tsum += T[r * 16 + f0l];
             const int c = d_COSTAS[s];
             s1 += (double)row[2 * c] + (double)row[2 * c + 1];
         }
@@ -1053,6 +1062,7 @@ __global__ void k_valid_probe(const uint64_t* lo, const uint64_t* hi, int n, int
 // ====================================================================================== host side
 #define HIPCHK(h, x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_err(h, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); return -2; } } while (0)
 
+static size_t sync_lds_bytes(const ft8rx_config& c) { const size_t nrows = (size_t)(c.h0_hi - c.h0_lo + 24); return nrows * 16 * sizeof(double) + (nrows * 29 + 512) * sizeof(float); }
 static std::string g_create_err;
 
 struct ft8rx_handle {
@@ -1213,6 +1223,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
         ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CRC_SYN), syn, sizeof(syn)) == hipSuccess;
     }
     if (!ok) { set_err(nullptr, "ft8rx_create: device table upload failed"); ft8rx_destroy(h); return -2; }
+    if (sync_lds_bytes(*cfg) > 65536) ok &= hipFuncSetAttribute((const void*)k_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sync_lds_bytes(*cfg)) == hipSuccess;
+    if (!ok) { set_err(nullptr, "ft8rx_create: cannot reserve LDS for k_sync"); ft8rx_destroy(h); return -2; }
     // the never-written grid row 0 (receiver.py:240)
     int nfill = (int)B * FT8RX_GRID_COLS;
     k_fill_row0<<<(nfill + 255) / 256, 256, 0, h->stream>>>(h->d_grid, (int)B);
@@ -1233,7 +1245,6 @@ int ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms
     return 0;
 }
 
-static size_t sync_lds_bytes(const ft8rx_config& c) { return ((size_t)(c.h0_hi - c.h0_lo + 24) * 29 + 512) * sizeof(float); }
 
 // the kernel chain for frames [f0, f0+B) on stream s (all buffers are frame-major, so a chunk is a pointer offset)
 static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B, hipStream_t s, bool prof) {
