@@ -101,6 +101,8 @@ int  ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* m
 /* ---- stage entry points (parity tests; each mirrors one reference function) ---------------- */
 /* AudioIn.get_hop_spectrum x375 (receiver.py:288-293): grid [n][376][976] */
 int  ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int n_frames, float* grid);
+/* streaming mode: ONE call of AudioIn.get_hop_spectrum (receiver.py:288-293): the last 3840 int16 samples -> 976 dB values */
+int  ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row976);
 /* Receiver.search (receiver.py:338-367): per frame <= max_cands (f0,h0,score), sorted */
 int  ft8rx_sync_search(ft8rx_handle* h, const float* grid, int n_frames,
                        int32_t* f0_idx, int32_t* h0_idx, float* score, int32_t* counts);

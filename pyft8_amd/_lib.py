@@ -173,6 +173,13 @@ class Handle:
         self._chk(lib().ft8rx_spectrogram(self._h, _ptr(audio, C.c_int16), B, _ptr(g, C.c_float)), "ft8rx_spectrogram")
         return g
 
+    def hop_spectrum(self, window3840):
+        w = np.ascontiguousarray(window3840, np.int16)
+        assert w.shape == (3840,)
+        row = np.empty(GRID_COLS, np.float32)
+        self._chk(lib().ft8rx_hop_spectrum(self._h, _ptr(w, C.c_int16), _ptr(row, C.c_float)), "ft8rx_hop_spectrum")
+        return row
+
     def sync_search(self, grid):
         grid = np.ascontiguousarray(grid, np.float32)
         if grid.ndim == 2:

@@ -91,16 +91,9 @@ FT8_DEV void log_event(ft8rx_event* ev, int32_t* evcount, int frame, int cand, i
 }
 
 // ------------------------------------------------------------------------------------ K1 spectrogram
-__global__ __launch_bounds__(256) void k_spectrogram(const int16_t* __restrict__ audio, float* __restrict__ grid, Tables T) {
-    __shared__ cpx bufA[1920];
-    __shared__ cpx bufB[1920];
-    // XCD-aware hop mapping: workgroup id -> XCD is id % 8 and gridDim.x = 376 = 8 * 47, so the 47 workgroups of a
-    // frame that land on one XCD take 47 consecutive hops: each XCD's L2 then sees one eighth of the frame's audio
-    // (8x overlapping windows) instead of all of it.
-    const int hop = (blockIdx.x & 7) * 47 + (blockIdx.x >> 3) + 1, f = blockIdx.y, tid = threadIdx.x;
-    if (hop > 375) return;
-    const int16_t* a = audio + (size_t)f * FT8RX_NSAMP;
-    const int base = 480 * hop - 3840;
+// one hop: window samples a[base .. base+3840) (zeros before the frame start) -> 976 dB values
+FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __restrict__ out, const Tables& T,
+                             cpx* bufA, cpx* bufB, int tid) {
     for (int m = tid; m < 1920; m += 256) {
         int i0 = base + 2 * m;
         float x0 = 0.0f, x1 = 0.0f;
@@ -112,7 +105,6 @@ __global__ __launch_bounds__(256) void k_spectrogram(const int16_t* __restrict__
     }
     __syncthreads();
     cpx* z = lds_fft<1920, 8, 8, 5, 3, 2>(bufA, bufB, T.W1920, 1, tid, 256);
-    float* out = grid + ((size_t)f * FT8RX_GRID_ROWS + hop) * FT8RX_GRID_COLS;
     for (int k = tid; k < FT8RX_GRID_COLS; k += 256) {
         cpx p = z[k], q = z[(1920 - k) % 1920];
         float er = 0.5f * (p.x + q.x), ei = 0.5f * (p.y - q.y);
@@ -123,6 +115,25 @@ __global__ __launch_bounds__(256) void k_spectrogram(const int16_t* __restrict__
         float mag = sqrtf(xr * xr + xi * xi);
         out[k] = 20.0f * ft8_log10f(mag + 1e-12f);
     }
+}
+
+__global__ __launch_bounds__(256) void k_spectrogram(const int16_t* __restrict__ audio, float* __restrict__ grid, Tables T) {
+    __shared__ cpx bufA[1920];
+    __shared__ cpx bufB[1920];
+    // XCD-aware hop mapping: workgroup id -> XCD is id % 8 and gridDim.x = 376 = 8 * 47, so the 47 workgroups of a
+    // frame that land on one XCD take 47 consecutive hops: each XCD's L2 then sees one eighth of the frame's audio
+    // (8x overlapping windows) instead of all of it.
+    const int hop = (blockIdx.x & 7) * 47 + (blockIdx.x >> 3) + 1, f = blockIdx.y, tid = threadIdx.x;
+    if (hop > 375) return;
+    spectrogram_hop(audio + (size_t)f * FT8RX_NSAMP, 480 * hop - 3840,
+                    grid + ((size_t)f * FT8RX_GRID_ROWS + hop) * FT8RX_GRID_COLS, T, bufA, bufB, tid);
+}
+
+// streaming mode: one hop of the live receiver (AudioIn.get_hop_spectrum, receiver.py:288-293)
+__global__ __launch_bounds__(256) void k_hop_spectrum(const int16_t* __restrict__ win3840, float* __restrict__ row, Tables T) {
+    __shared__ cpx bufA[1920];
+    __shared__ cpx bufB[1920];
+    spectrogram_hop(win3840, 0, row, T, bufA, bufB, threadIdx.x);
 }
 
 __global__ void k_fill_row0(float* grid, int B) {
@@ -1362,6 +1373,17 @@ int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid)
     k_spectrogram<<<dim3(376, B), 256, 0, h->stream>>>(h->d_audio, h->d_grid, h->T);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(grid, h->d_grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row976) {
+    if (!h || !window3840 || !row976) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    float* d_row = h->d_best_score;                      // any 976-float scratch: not in use between batches
+    HIPCHK(h, hipMemcpyAsync(h->d_audio, window3840, sizeof(int16_t) * 3840, hipMemcpyHostToDevice, h->stream));
+    k_hop_spectrum<<<1, 256, 0, h->stream>>>(h->d_audio, d_row, h->T);
+    HIPCHK(h, hipMemcpyAsync(row976, d_row, sizeof(float) * FT8RX_GRID_COLS, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -13,6 +13,8 @@ frames ("frame-complete" semantics) in batches on the GPU.  Messages 
 `on_message(dict)` with the reference's keys, on the caller's thread, in the reference's emit order.
 There is no CPU path: without libft8rx.so and an MI355X the constructor raises.
 """
+import time as _time
+
 import numpy as np
 
 from . import _lib
@@ -45,34 +47,72 @@ class Candidate:
 
 
 class AudioIn:
-    """Holds the host views the reference's GUI reads (receiver.py:240, 272-278).  Filled per decoded frame."""
+    """Host-side state the reference keeps per receiver (receiver.py:225-306): the 15-s audio ring, the
+    750 x 976 search grid that the GUI's waterfall views in place, and the hop pointer.
+
+    Two ways to fill it:
+      * load_frame(audio)  -- frame-complete: one GPU spectrogram launch for all 375 hops;
+      * _callback(in_data, frame_count, time_info, status_flags) -- streaming: the PortAudio
+        callback signature of the reference (receiver.py:295-306).  Each call appends one 480-sample hop,
+        advances search_grid_ptr exactly like the reference (wall-clock re-sync at the grid wrap) and writes
+        that hop's 976 dB values, computed on the GPU (ft8rx_hop_spectrum), into search_grid[ptr] in place.
+    Unlike the reference, decoding is triggered when a cycle's 375 hops are complete (Receiver.poll), not at
+    hop 260 -- the frame-complete semantics of this build."""
 
     def __init__(self, search_freq_range, receiver):
         self.input_device_idx = None
         self.search_hps, self.search_bpt = 4, 2
         self.search_freq_range = search_freq_range
+        self.search_fft_len = 3840
+        self.samples_perhop = 480
         self.df = SYM_RATE / self.search_bpt
         self.search_f0_idx_range = [int(search_freq_range[0] / self.df), int(search_freq_range[1] / self.df)]
         self.search_hops_per_cycle = int(T_CYC * SYM_RATE * self.search_hps)
         self.search_hops_per_grid = 2 * self.search_hops_per_cycle
         self.dt = T_CYC / self.search_hops_per_cycle
+        self.samples_per_cycle = SAMP_RATE * T_CYC
         self.search_grid = np.ones((self.search_hops_per_grid, _lib.GRID_COLS), dtype=np.float32)
-        self.search_grid_ptr = 0
         self._rx = receiver
+        self.search_grid_ptr = int(self._grid_time() * self.search_hops_per_grid / (2 * T_CYC))
+        self.audio_buffer = np.zeros(self.samples_per_cycle, dtype=np.int16)    # reference: float32 copies of int16 samples
         self._audio = None
         self.cycle_spectrum = None
+        self.cycles_completed = 0
+        self._ready = []                 # (int16 frame, cycle start time) of completed, not yet decoded cycles
         d = WATERFALL_DOWNSAMPLE
         self.waterfall_data = {"data": self.search_grid[::d, ::d].T, "df": self.df * d, "dt": self.dt * d,
                                "sig_w": int(79 * self.search_hps / d), "sig_h": int(8 * self.search_bpt / d),
                                "pixels_per_cycle": int(self.search_hops_per_cycle / d)}
 
+    def _grid_time(self):
+        return self._rx.time_source() % (2 * T_CYC)
+
     def load_frame(self, audio_i16):
         """Frame-complete stand-in for 375 calls of _callback (receiver.py:295-306)."""
         self._audio = np.ascontiguousarray(audio_i16, np.int16).reshape(_lib.NSAMP)
+        self.audio_buffer[:] = self._audio
         g = self._rx._handle(1).spectrogram(self._audio)[0]
         self.search_grid[1:376] = g[1:376]          # in place: waterfall_data['data'] is a live view
         self.search_grid_ptr = 375
         self.cycle_spectrum = None
+
+    def _callback(self, in_data, frame_count=None, time_info=None, status_flags=None):
+        samples = np.frombuffer(in_data, dtype=np.int16)
+        n = len(samples)
+        self.audio_buffer[:-n] = self.audio_buffer[n:]
+        self.audio_buffer[-n:] = samples
+        self.search_grid_ptr = (self.search_grid_ptr + 1) % self.search_hops_per_grid
+        if self.search_grid_ptr == 0:
+            tg = self._grid_time()
+            if tg > 0.1:
+                self.search_grid_ptr = int(tg * self.search_hops_per_grid / (2 * T_CYC))
+        self.search_grid[self.search_grid_ptr, :] = self._rx._handle(1).hop_spectrum(self.audio_buffer[-self.search_fft_len:])
+        if self.search_grid_ptr % self.search_hops_per_cycle == 0:      # the 375th hop of a cycle just landed
+            self._audio = self.audio_buffer.copy()
+            self.cycle_spectrum = None
+            self.cycles_completed += 1
+            self._ready.append((self._audio, self._rx.time_source()))
+        return (None, 0)                 # (None, pyaudio.paContinue)
 
     def get_cycle_spectrum(self):
         """First 49152 bins of the reference's 96001-bin spectrum (receiver.py:280-286): all the fine sync reads."""
@@ -86,8 +126,9 @@ class AudioIn:
 class Receiver:
     def __init__(self, input_device_keywords, on_message, sync_score_min=85, max_cands=200,
                  search_freq_range=[100, 3000], search_time_range=[-2.5 + 0.5, 2.5 + 0.5], verbose=False,
-                 device=0, max_frames=1, **extension_knobs):
+                 device=0, max_frames=1, time_source=None, **extension_knobs):
         self.on_message = on_message
+        self.time_source = time_source or _time.time          # the reference's time_utils seam (time_utils.py:7-8)
         self.sync_score_min, self.max_cands = sync_score_min, max_cands
         self.verbose = verbose
         self.band = None
@@ -145,6 +186,20 @@ class Receiver:
 
     def decode_frame(self, audio_i16, cyclestart_string="700101_000015"):
         return self.decode_frames(np.asarray(audio_i16)[None], [cyclestart_string])[0]
+
+    # ---- streaming mode (stands in for the manage_cycle thread, receiver.py:372-412)
+    def poll(self):
+        """Decode every cycle that audio_in._callback has completed since the last call; messages go to on_message
+        on the caller's thread.  -> list of message dicts.  Call it from your own loop/thread (e.g. every 0.1 s)."""
+        out = []
+        while self.audio_in._ready:
+            frame, t_end = self.audio_in._ready.pop(0)
+            t0 = T_CYC * int((t_end - T_CYC / 2) / T_CYC)              # start of the cycle that just ended
+            cs = _time.strftime("%y%m%d_%H%M%S", _time.gmtime(t0))
+            rec, cnt, ev, evc = self._handle(1).decode_batch(frame[None])
+            out += _m.package_frame(rec[0], int(cnt[0]), ev[0], int(evc[0]), cyclestart_string=cs, band=self.band,
+                                    odd_even=int((t0 % (2 * T_CYC)) / T_CYC), on_message=self.on_message)
+        return out
 
 
 def decode_frames(audio_i16, on_message=None, **receiver_kwargs):

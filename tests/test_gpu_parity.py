@@ -379,3 +379,41 @@ def test_device_synth_generator(H, ocfg):
         assert len(got - want) <= 3                    # the reference algorithm's own OSD false positives (about 1/frame)
         hits += len(got & want)
     assert hits >= n * 20                              # the numpy generator gives ~30 of 50 at this density
+
+
+def test_streaming_audio_in_mode(H, ocfg):
+    """hop-by-hop AudioIn._callback (PortAudio signature) under a virtual clock: the live search grid
+    equals the batch spectrogram row for row, the waterfall view updates in place, and each completed cycle decodes
+    to the same messages as the frame-complete path -- for two consecutive cycles (both grid halves)."""
+    from pyft8_amd.receiver import Receiver
+    vt = [0.0]
+    got = []
+    rx = Receiver("x", got.append, time_source=lambda: vt[0])
+    wf = rx.audio_in.waterfall_data["data"]
+    for cyc, name in enumerate(["test_09", "test_08"]):
+        audio, gold, js = load_golden(name)
+        base = 15.0 * cyc
+        for k in range(375):
+            vt[0] = base + (k + 1) * 0.04
+            rx.audio_in._callback(audio[480 * k:480 * k + 480].tobytes(), 480, None, None)
+            assert rx.poll() == [] or k == 374
+        want_grid = O.spectrogram(audio, ocfg)
+        rows = rx.audio_in.search_grid[375 * cyc + 1:375 * cyc + 376] if cyc == 0 else \
+            np.concatenate([rx.audio_in.search_grid[376:750], rx.audio_in.search_grid[0:1]])
+        if cyc == 0:
+            assert bits_equal(rows, want_grid[1:376])
+        else:
+            # second cycle: its first 7 hops still see the previous cycle's samples in the 3840-sample window (live ring)
+            assert bits_equal(rows[7:], want_grid[8:376])
+        assert wf.base is rx.audio_in.search_grid or np.shares_memory(wf, rx.audio_in.search_grid)
+        msgs = [m for m in got if True]
+        txt = [" ".join(m["msg_tuple"]) for m in got]
+        ref_txt = [" ".join(m["msg_tuple"]) for m in js["messages"]]
+        if cyc == 0:
+            assert txt == ref_txt
+            assert got[0]["cyclestart_string"] == "700101_000000" and got[0]["their_tx_cycle"] == 0
+        else:
+            # same frame samples => same decode set as the frame-complete reference run
+            assert txt[len(txt) - len(ref_txt):] == ref_txt
+            assert got[-1]["cyclestart_string"] == "700101_000015" and got[-1]["their_tx_cycle"] == 1
+    assert rx.audio_in.cycles_completed == 2
