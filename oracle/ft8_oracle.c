@@ -67,15 +67,16 @@ float ft8o_log10f(float x) {
     return fe * 0.301025390625f + (fe * 4.6050390e-6f + lnm * 0.4342945f);
 }
 
-/* tanh: Pade(7,6) below 1, 1-2/(exp(2|x|)+1) above.  Replaces np.tanh (decoders.py:142). */
+/* tanh: one division n/d with (n, d) = Pade(7,6) numerator/denominator below 1 and (E-1, E+1), E = exp(2|x|),
+ * above.  Replaces np.tanh (decoders.py:142). */
 float ft8o_tanhf(float x) {
     if (x != x) return x;
-    float ax = fabsf(x), r;
+    float ax = fabsf(x), n, d;
     if (ax < 1.0f) {
         float x2 = ax * ax;
         float num = ((x2 + 378.0f) * x2 + 17325.0f) * x2 + 135135.0f;
-        float den = ((28.0f * x2 + 3150.0f) * x2 + 62370.0f) * x2 + 135135.0f;
-        r = (ax * num) / den;
+        d = ((28.0f * x2 + 3150.0f) * x2 + 62370.0f) * x2 + 135135.0f;
+        n = ax * num;
     } else {
         float y = 2.0f * ax;
         if (y > 20.0f) y = 20.0f;
@@ -91,8 +92,9 @@ float ft8o_tanhf(float x) {
         p = p * t + 1.0f;
         p = p * t + 1.0f;
         float E = p * f_from_bits((uint32_t)(k + 127) << 23);
-        r = 1.0f - 2.0f / (E + 1.0f);
+        n = E - 1.0f; d = E + 1.0f;
     }
+    float r = n / d;
     return (x < 0.0f) ? -r : r;
 }
 
@@ -694,8 +696,10 @@ static int ldpc_core(float* llr, int max_nc0, int max_iters, accept_fn acc, void
                 P = (j == 0) ? t[0] : P * t[j];
             }
             for (int j = 0; j < n; j++) {
-                float e = P / t[j];
-                float nm = e / ((e - 1.18f) * (1.18f + e));
+                /* reference: e = P/t; m = e/((e-1.18)(1.18+e)) (decoders.py:146-149).  Contract: the same quantity with
+                 * numerator and denominator multiplied by t^2 -- one division; t == 0 (=> P == 0) still gives 0/0 = NaN */
+                float u = 1.18f * t[j];
+                float nm = (P * t[j]) / ((P - u) * (u + P));
                 newm[e0 + j] = nm;
                 delta[e0 + j] = nm - mc2v[e0 + j];
             }

@@ -37,12 +37,12 @@ FT8_DEV float ft8_log10f(float x) {
 
 FT8_DEV float ft8_tanhf(float x) {
     if (x != x) return x;
-    float ax = __builtin_fabsf(x), r;
+    float ax = __builtin_fabsf(x), n, d;
     if (ax < 1.0f) {
         float x2 = ax * ax;
         float num = ((x2 + 378.0f) * x2 + 17325.0f) * x2 + 135135.0f;
-        float den = ((28.0f * x2 + 3150.0f) * x2 + 62370.0f) * x2 + 135135.0f;
-        r = (ax * num) / den;
+        d = ((28.0f * x2 + 3150.0f) * x2 + 62370.0f) * x2 + 135135.0f;
+        n = ax * num;
     } else {
         float y = 2.0f * ax;
         if (y > 20.0f) y = 20.0f;
@@ -58,8 +58,9 @@ FT8_DEV float ft8_tanhf(float x) {
         p = p * t + 1.0f;
         p = p * t + 1.0f;
         float E = p * __uint_as_float((uint32_t)(k + 127) << 23);
-        r = 1.0f - 2.0f / (E + 1.0f);
+        n = E - 1.0f; d = E + 1.0f;
     }
+    float r = n / d;           // one IEEE division for both branches
     return (x < 0.0f) ? -r : r;
 }
 

@@ -445,8 +445,8 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
         for (int i = 0; i < 9; i++) {
             int e = lane + 64 * i;
             if (e < 522) {
-                float ee = P[ec_[i]] / tt[i];
-                float nm = ee / ((ee - 1.18f) * (1.18f + ee));
+                const float Pc = P[ec_[i]], u = 1.18f * tt[i];
+                float nm = (Pc * tt[i]) / ((Pc - u) * (u + Pc));     // = e/((e-1.18)(1.18+e)), e = P/t, in one division
                 dl[e] = nm - mc[i];
                 mc[i] = nm;
             }
