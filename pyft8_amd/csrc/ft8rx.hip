@@ -583,7 +583,12 @@ __global__ __launch_bounds__(256) void k_cyc_c(const cpx* __restrict__ Z, cpx* _
 // one LDS buffer as three register-fused stages [8] | [4,4] | [5,5]; stage 1 reads the tapered spectrum
 // slice straight from global memory and knows that only 1000 of the 3200 bins are non-zero.  The 1/3200
 // scale and the output conjugation are applied where the series is consumed.
+#ifndef FINE_NT
 #define FINE_NT 128
+#endif
+#ifndef FINE_WV
+#define FINE_WV 2
+#endif
 #define FINE_INV 0.0003125f
 
 // conj(taper * spec) for bin k of the rolled 3200-bin slice (receiver.py:180-185); k < 850 or k >= 3050
@@ -602,35 +607,53 @@ FT8_DEV cpx fine_input(const cpx* __restrict__ S, int fb, int k, const double* _
 #define FINE_ZLEN 3200
 FT8_DEV int mapC(int i) { return i; }
 
+// The stages are written for any FINE_NT in {64, 128}: a thread owns ceil(groups / FINE_NT) groups of each stage,
+// loads all of them, passes the barrier, then computes and stores them (in place).  With FINE_NT = 64 the block is a
+// single wavefront, the "barriers" are free and every lane carries 3-4 independent groups (ILP instead of TLP).
 FT8_DEV void fine_stage1(const cpx* __restrict__ S, int fb, cpx* z, const cpx* __restrict__ W,
                          const double* __restrict__ taper, int tid) {
-#pragma unroll 1
-    for (int p = tid; p < 400; p += FINE_NT) {                    // pass [8]: n = 3200, s = 1, m = 400
-        cpx a[8];
-        const cpx zero = make_float2(0.0f, 0.0f);
-        a[0] = fine_input(S, fb, p, taper);
-        a[1] = fine_input(S, fb, p + 400, taper);
-        a[2] = (p < 50) ? fine_input(S, fb, p + 800, taper) : zero;
-        a[3] = zero; a[4] = zero; a[5] = zero; a[6] = zero;
-        a[7] = (p >= 250) ? fine_input(S, fb, p + 2800, taper) : zero;
-        dft<8>(a);
-        z[8 * p] = a[0];
+    // pass [8]: n = 3200, s = 1, m = 400: butterfly p reads bins p + 400 j; only j = 0, 1, (2 if p < 50), (7 if p >= 250)
+    // are non-zero.  All global loads of the thread are issued before the first butterfly.
+    constexpr int R = (400 + FINE_NT - 1) / FINE_NT;
+    const cpx zero = make_float2(0.0f, 0.0f);
+    cpx in0[R], in1[R], in7[R], in2;
 #pragma unroll
-        for (int j = 1; j < 8; j++) { cpx v = a[j]; if (p != 0) v = cmul(v, W[j * p]); z[8 * p + j] = v; }
+    for (int i = 0; i < R; i++) {
+        const int p = tid + FINE_NT * i;
+        const bool on = p < 400;
+        in0[i] = on ? fine_input(S, fb, p, taper) : zero;
+        in1[i] = on ? fine_input(S, fb, p + 400, taper) : zero;
+        in7[i] = (on && p >= 250) ? fine_input(S, fb, p + 2800, taper) : zero;
+    }
+    in2 = (tid < 50) ? fine_input(S, fb, tid + 800, taper) : zero;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int p = tid + FINE_NT * i;
+        if (p < 400) {
+            cpx a[8];
+            a[0] = in0[i]; a[1] = in1[i]; a[2] = (i == 0) ? in2 : zero;
+            a[3] = zero; a[4] = zero; a[5] = zero; a[6] = zero; a[7] = in7[i];
+            dft<8>(a);
+            z[8 * p] = a[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) { cpx v = a[j]; if (p != 0) v = cmul(v, W[j * p]); z[8 * p + j] = v; }
+        }
     }
     __syncthreads();
 }
 FT8_DEV void fine_stage2(cpx* z, const cpx* __restrict__ W, int tid) {
     typedef Fused2<3200, 400, 8, 4, 4> F;                         // passes [4,4]: n = 400, s = 8; 200 groups
-    cpx a0[4][4], a1[4][4];
-    const int u1 = tid + FINE_NT;
-    const bool two = u1 < F::groups;
+    constexpr int R = (F::groups + FINE_NT - 1) / FINE_NT;
+    cpx a[R][4][4];
     // group g = (pp = g / 8, q = g % 8): in  q + 8(pp + 25 j' + 100 j),  out  q + 8 j + 32 (4 pp + j')
-    F::load_affine<200, 800>(z, tid, a0);
-    if (two) F::load_affine<200, 800>(z, u1, a1);
+#pragma unroll
+    for (int r = 0; r < R; r++) { const int g = tid + FINE_NT * r; if (g < F::groups) F::load_affine<200, 800>(z, g, a[r]); }
     __syncthreads();
-    F::compute_pp(tid >> 3, a0, W); F::store_affine<32, 8>(z, (tid & 7) + 128 * (tid >> 3), a0);
-    if (two) { F::compute_pp(u1 >> 3, a1, W); F::store_affine<32, 8>(z, (u1 & 7) + 128 * (u1 >> 3), a1); }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int g = tid + FINE_NT * r;
+        if (g < F::groups) { F::compute_pp(g >> 3, a[r], W); F::store_affine<32, 8>(z, (g & 7) + 128 * (g >> 3), a[r]); }
+    }
     __syncthreads();
 }
 // Only output samples in [lo, hi) are needed (the scoring IFFTs read one Costas block = ~230 samples): a final
@@ -638,22 +661,28 @@ FT8_DEV void fine_stage2(cpx* z, const cpx* __restrict__ W, int tid) {
 // shorter than 640, so butterflies with no sample in the window are skipped.  Needed outputs are bit-identical.
 FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int hi) {
     typedef Fused2<3200, 25, 128, 5, 5> F;                        // passes [5,5]: n = 25, s = 128; 128 groups
-    cpx a[5][5];
+    constexpr int R = F::groups / FINE_NT;
+    cpx a[R][5][5];
     // group q: in  q + 128 (j' + 5 j),  out  q + 128 j + 640 j'
-    F::load_affine<128, 640>(z, tid, a);
+#pragma unroll
+    for (int r = 0; r < R; r++) F::load_affine<128, 640>(z, tid + FINE_NT * r, a[r]);
     __syncthreads();
-    F::compute_passA(0, a, W);
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int r = tid + 128 * j;
-        const int first = (lo <= r) ? r : r + 640 * ((lo - r + 639) / 640);   // smallest r + 640 j' >= lo
-        if (first < hi && first < 3200) {
-            cpx b[5];
+    for (int r = 0; r < R; r++) {
+        const int q = tid + FINE_NT * r;
+        F::compute_passA(0, a[r], W);
 #pragma unroll
-            for (int jp = 0; jp < 5; jp++) b[jp] = a[jp][j];
-            dft<5>(b);                                             // last pass: no twiddles
+        for (int j = 0; j < 5; j++) {
+            const int rr = q + 128 * j;
+            const int first = (lo <= rr) ? rr : rr + 640 * ((lo - rr + 639) / 640);   // smallest rr + 640 j' >= lo
+            if (first < hi && first < 3200) {
+                cpx b[5];
 #pragma unroll
-            for (int jp = 0; jp < 5; jp++) z[r + 640 * jp] = b[jp];
+                for (int jp = 0; jp < 5; jp++) b[jp] = a[r][jp][j];
+                dft<5>(b);                                         // last pass: no twiddles
+#pragma unroll
+                for (int jp = 0; jp < 5; jp++) z[rr + 640 * jp] = b[jp];
+            }
         }
     }
     __syncthreads();
@@ -680,7 +709,7 @@ FT8_DEV float fine_score_from(const float* mg /*[7][7]*/) {
     return (float)(s1 + W6 * s2);
 }
 
-__global__ __launch_bounds__(FINE_NT, 2) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
+__global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
                                                   const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
                                                   const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
                                                   float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
@@ -709,7 +738,7 @@ __global__ __launch_bounds__(FINE_NT, 2) void k_fine(const cpx* __restrict__ spe
     // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
     fine_fft(S, fb0, z, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43);   // the 8 time tweaks of the middle Costas block
 #pragma unroll 1
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < (224 + FINE_NT - 1) / FINE_NT; r++) {
         const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
         const bool valid = qd < 56;
         const int ti = valid ? qd / 7 : 0, a = valid ? qd - 7 * ti : 0;
@@ -760,7 +789,7 @@ __global__ __launch_bounds__(FINE_NT, 2) void k_fine(const cpx* __restrict__ spe
     }
     fine_fft(S, fb0 + ft, z, T, tid, 0, 3200);   // full series for the 79 x 8 grid
 #pragma unroll 1
-    for (int r = 0; r < 3; r++) {                 // full 79 x 8 grid
+    for (int r = 0; r < (316 + FINE_NT - 1) / FINE_NT; r++) {                 // full 79 x 8 grid
         const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;
         const bool valid = sy < 79;
         float mag[8];
