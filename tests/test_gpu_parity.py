@@ -417,3 +417,42 @@ def test_streaming_audio_in_mode(H, ocfg):
             assert txt[len(txt) - len(ref_txt):] == ref_txt
             assert got[-1]["cyclestart_string"] == "700101_000015" and got[-1]["their_tx_cycle"] == 1
     assert rx.audio_in.cycles_completed == 2
+
+
+def test_error_paths_and_lifecycle():
+    """C ABI error convention: negative return + ft8rx_last_error text, surfaced as Ft8rxError; never a crash."""
+    from pyft8_amd import _lib
+    with pytest.raises(_lib.Ft8rxError, match="configuration"):
+        _lib.Handle(_lib.default_config(max_cands=1000))
+    with pytest.raises(_lib.Ft8rxError, match="configuration"):
+        _lib.Handle(_lib.default_config(f0_lo=0))
+    with pytest.raises(_lib.Ft8rxError, match="device"):
+        _lib.Handle(device=99)
+    h = _lib.Handle(max_frames=2)
+    with pytest.raises(_lib.Ft8rxError, match="n_frames"):
+        h.decode_batch(np.zeros((3, 180000), np.int16))
+    with pytest.raises(_lib.Ft8rxError):
+        h.osd(np.zeros((1, 174), np.float32), 100, 2)
+    rec, cnt, ev, evc = h.decode_batch(np.zeros((2, 180000), np.int16))      # still usable after errors
+    assert list(cnt) == [0, 0]
+    h.close()
+    h.close()                                                              # idempotent
+
+
+def test_repeatable_across_runs_and_stream_counts(ocfg):
+    """Same input => same records regardless of how many streams/chunks the batch is cut into; events may arrive in a
+    different order (atomics) but package_frame orders them."""
+    from pyft8_amd import _lib, synth, messages as M
+    audio = synth.make_batch(81000, 16)
+    outs = []
+    for ns in (1, 2, 4, 1):
+        h = _lib.Handle(max_frames=16)
+        h.set_streams(ns)
+        rec, cnt, ev, evc = h.decode_batch(audio)
+        outs.append((rec.copy(), cnt.copy(), [[" ".join(m["msg_tuple"]) for m in M.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]))]
+                                              for f in range(16)]))
+        h.close()
+    for rec, cnt, msgs in outs[1:]:
+        assert np.array_equal(cnt, outs[0][1]) and msgs == outs[0][2]
+        for f in range(16):
+            assert rec[f][:cnt[f]].tobytes() == outs[0][0][f][:cnt[f]].tobytes()
