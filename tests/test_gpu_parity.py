@@ -3,6 +3,7 @@
 included, because both sides implement the same explicitly ordered IEEE arithmetic -- and
 with the golden vectors captured from the reference (tolerance 1e-4 where floats are involved)."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -456,3 +457,27 @@ def test_repeatable_across_runs_and_stream_counts(ocfg):
         assert np.array_equal(cnt, outs[0][1]) and msgs == outs[0][2]
         for f in range(16):
             assert rec[f][:cnt[f]].tobytes() == outs[0][0][f][:cnt[f]].tobytes()
+
+
+def test_bench_contract_line():
+    """bench.py must print exactly one JSON line with the driver's keys plus roofline and cpu_baseline."""
+    import json as _json
+    import subprocess
+    import sys as _sys
+    from conftest import ROOT
+    out = subprocess.run([_sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "32"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = _json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["unit"] == "frames/s" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s"
+    assert d["value"] > 1000
