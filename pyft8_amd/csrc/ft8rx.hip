@@ -391,9 +391,15 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
     const int n0 = d_CHK_N[c0], e00 = d_CHK_E0[c0];
     const int n1 = (c1 < 83) ? d_CHK_N[c1] : 0, e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
     // membership masks of this lane's two checks over the 174 variables (3 x 64 bits each)
-    uint64_t cm0[3] = {0, 0, 0}, cm1[3] = {0, 0, 0};
-    for (int j = 0; j < n0; j++) { int v = d_CHK_V[c0][j]; cm0[v >> 6] |= 1ull << (v & 63); }
-    for (int j = 0; j < n1; j++) { int v = d_CHK_V[c1][j]; cm1[v >> 6] |= 1ull << (v & 63); }
+    // (built with selects, not a runtime array index, so the six words stay in registers)
+    uint64_t cm00 = 0, cm01 = 0, cm02 = 0, cm10 = 0, cm11 = 0, cm12 = 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        if (j < n0) { const int v = d_CHK_V[c0][j]; const uint64_t bit = 1ull << (v & 63); const int w = v >> 6;
+                      cm00 |= (w == 0) ? bit : 0; cm01 |= (w == 1) ? bit : 0; cm02 |= (w == 2) ? bit : 0; }
+        if (j < n1) { const int v = d_CHK_V[c1][j]; const uint64_t bit = 1ull << (v & 63); const int w = v >> 6;
+                      cm10 |= (w == 0) ? bit : 0; cm11 |= (w == 1) ? bit : 0; cm12 |= (w == 2) ? bit : 0; }
+    }
     float mc[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) mc[i] = 0.0f;
@@ -403,8 +409,8 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
         // parity of every check from the hard decisions
         const uint64_t h0 = __ballot(llr[lane] > 0.0f), h1 = __ballot(llr[64 + lane] > 0.0f),
                        h2 = __ballot(lane < 46 && llr[128 + (lane < 46 ? lane : 0)] > 0.0f);
-        const int par0 = (__popcll(h0 & cm0[0]) + __popcll(h1 & cm0[1]) + __popcll(h2 & cm0[2])) & 1;
-        const int par1 = (__popcll(h0 & cm1[0]) + __popcll(h1 & cm1[1]) + __popcll(h2 & cm1[2])) & 1;
+        const int par0 = (__popcll(h0 & cm00) + __popcll(h1 & cm01) + __popcll(h2 & cm02)) & 1;
+        const int par1 = (__popcll(h0 & cm10) + __popcll(h1 & cm11) + __popcll(h2 & cm12)) & 1;
         int ncheck = __popcll(__ballot(par0)) + __popcll(__ballot(par1));
         if (it == 0) { res.nc0 = (uint8_t)ncheck; if (ncheck > max_nc0) { res.has_out = 0; break; } }
         if (ncheck == 0) {
