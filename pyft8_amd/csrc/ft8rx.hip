@@ -924,49 +924,57 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
     // Basis exchange.  G0 = [I | A^T] is already reduced for the systematic basis: row r owns unit column r.
     // Columns are visited in reliability order exactly as in the reference (decoders.py:228-242) and accepted
     // iff independent of the columns accepted so far, but
-    //   * a column that is still the unit column of a not-yet-locked row is accepted by locking that row
-    //     (no row operation, no broadcast);
-    //   * any other column is accepted iff it has a 1 in some unlocked row; then one elimination step makes
-    //     it that row's unit column (the row's previous basis column simply leaves the basis).
-    // The selected basis, the reduced rows and the acceptance order k are identical to plain Gauss-Jordan;
-    // only about half of the accepted columns need row operations.
-    int bcolA = lane, bcolB = hasB ? 64 + lane : -1;       // basis column currently owned by each row
-    bool usedA = false, usedB = !hasB;                      // "locked": the row's basis column is in the chosen set
-    int kA = -1, kB = -1; bool hardA = false, hardB = false;
+    //   * a row is "locked" once its basis column has been accepted; an UNLOCKED row r always still owns its original
+    //     column r (rows only change basis column at the moment they are locked), so "column c is the unit column of
+    //     an unlocked row" is the wave-uniform test  c < 91 && !locked(c): such a column is accepted by setting one
+    //     bit -- no row operation, no ballot, no broadcast;
+    //   * any other column is accepted iff it has a 1 in some unlocked row; one elimination step then makes it that
+    //     row's unit column.
+    // The selected basis, the reduced rows and the acceptance order k are identical to plain Gauss-Jordan; about 40 %
+    // of the accepted columns need no row operation.  All bookkeeping is wave-uniform (scalar registers):
+    // lockA/lockB = locked rows 0..63 / 64..90, hmA/hmB = locked rows whose accepted column has hard decision 1.
+    uint64_t lockA = 0, lockB = ~((1ull << 27) - 1), hmA = 0, hmB = 0;
+    __shared__ uint8_t prow[96];                             // prow[k] = row locked by the k-th accepted column
     int k = 0;
     for (int ic = 0; ic < 174 && k < 91; ic++) {
         const int sel = ic >> 6, il = ic & 63;
         const int col = __builtin_amdgcn_readlane(sel == 0 ? ord0 : (sel == 1 ? ord1 : ord2), il);
         const int w = col >> 6, sh = col & 63;
         const uint64_t hw = (w == 0) ? hard0 : (w == 1) ? hard1 : hard2;
-        const bool hard = (hw >> sh) & 1ull;
-        const uint64_t uA = __ballot(bcolA == col && !usedA), uB = __ballot(bcolB == col && !usedB);
-        if (uA | uB) {                                       // still a unit column of an unlocked row: just lock it
-            if (uA) { if (bcolA == col) { usedA = true; kA = k; hardA = hard; } }
-            else    { if (bcolB == col) { usedB = true; kB = k; hardB = hard; } }
-            k++;
-            continue;
+        const uint64_t hard = (hw >> sh) & 1ull;
+        int row = -1;
+        if (col < 91 && !(((col < 64 ? lockA : lockB) >> (col & 63)) & 1ull)) row = col;      // still a unit column
+        else {
+            const uint64_t wa = (w == 0) ? a0 : (w == 1) ? a1 : a2;
+            const uint64_t wb = (w == 0) ? b0 : (w == 1) ? b1 : b2;
+            const bool bitA = (wa >> sh) & 1ull, bitB = (wb >> sh) & 1ull;
+            const uint64_t mA = __ballot(bitA) & ~lockA, mB = __ballot(bitB) & ~lockB;
+            if (!mA && !mB) continue;                        // dependent on the accepted columns
+            const bool inA = (mA != 0);
+            const int src = inA ? __builtin_ctzll(mA) : __builtin_ctzll(mB);
+            const uint64_t p0 = shfl64(inA ? a0 : b0, src), p1 = shfl64(inA ? a1 : b1, src), p2 = shfl64(inA ? a2 : b2, src);
+            if (bitA && !(inA && lane == src)) { a0 ^= p0; a1 ^= p1; a2 ^= p2; }
+            if (bitB && !(!inA && lane == src)) { b0 ^= p0; b1 ^= p1; b2 ^= p2; }
+            row = inA ? src : 64 + src;
         }
-        const uint64_t wa = (w == 0) ? a0 : (w == 1) ? a1 : a2;
-        const uint64_t wb = (w == 0) ? b0 : (w == 1) ? b1 : b2;
-        const bool bitA = (wa >> sh) & 1ull, bitB = (wb >> sh) & 1ull;
-        const uint64_t mA = __ballot(bitA && !usedA), mB = __ballot(bitB && !usedB);
-        if (!mA && !mB) continue;
-        const bool inA = (mA != 0);
-        const int src = inA ? __builtin_ctzll(mA) : __builtin_ctzll(mB);
-        const uint64_t p0 = shfl64(inA ? a0 : b0, src), p1 = shfl64(inA ? a1 : b1, src), p2 = shfl64(inA ? a2 : b2, src);
-        const bool isPivA = inA && lane == src, isPivB = !inA && lane == src;
-        if (bitA && !isPivA) { a0 ^= p0; a1 ^= p1; a2 ^= p2; }
-        if (bitB && !isPivB) { b0 ^= p0; b1 ^= p1; b2 ^= p2; }
-        if (isPivA) { usedA = true; kA = k; hardA = hard; bcolA = col; }
-        if (isPivB) { usedB = true; kB = k; hardB = hard; bcolB = col; }
+        if (row < 64) { lockA |= 1ull << row; hmA |= hard << row; }
+        else { lockB |= 1ull << (row - 64); hmB |= hard << (row - 64); }
+        if (lane == 0) prow[k] = (uint8_t)row;
         k++;
     }
-    // order-0 codeword (message part = first 91 bits) and the flip rows
+    // order-0 codeword (message part = first 91 bits): XOR of the locked rows whose accepted column has hard bit 1
+    const bool hardA = (hmA >> lane) & 1ull, hardB = (hmB >> lane) & 1ull;
     uint64_t c0 = (hardA ? a0 : 0) ^ (hardB ? b0 : 0), c1 = (hardA ? a1 : 0) ^ (hardB ? b1 : 0);
     c0 = xor_reduce64(c0); c1 = xor_reduce64(c1);
-    if (kA >= 0 && 90 - kA < 64 && 90 - kA >= 0) { flip[90 - kA][0] = a0; flip[90 - kA][1] = a1; }
-    if (kB >= 0 && 90 - kB < 64 && 90 - kB >= 0) { flip[90 - kB][0] = b0; flip[90 - kB][1] = b1; }
+    __syncthreads();
+    // flip rows: flip[i] = row locked by accepted column 90 - i (the least reliable basis members first)
+    {
+        const int i = lane;
+        const int r = (i < 64 && 90 - i >= 0 && 90 - i < k) ? prow[90 - i] : 0;
+        const uint64_t fa0 = shfl64(a0, r & 63), fa1 = shfl64(a1, r & 63), fb0 = shfl64(b0, r & 63), fb1 = shfl64(b1, r & 63);
+        flip[i][0] = (r < 64) ? fa0 : fb0;
+        flip[i][1] = (r < 64) ? fa1 : fb1;
+    }
     __syncthreads();
     // trial t in the reference's order (decoders.py:248-272): 0 = order-0, 1..S = single flips i = t-1, then the
     // restricted double flips (i, j), i < S, j < min(i, D), i-major.
