@@ -67,6 +67,16 @@ typedef struct {
     uint16_t valid;                  /* unpack() would have returned a tuple */
 } ft8rx_event;
 
+/* One emitted message (the argument of the reference's on_message callback, receiver.py:61-65, before string
+ * formatting).  64 bytes. */
+typedef struct {
+    char     f[3][16];               /* msg_tuple */
+    int16_t  cand, f0_idx, h0_idx;
+    int8_t   snr, ttweak, ftweak;
+    uint8_t  ipass, ap, method, fine;
+    uint8_t  pad[3];
+} ft8rx_message;
+
 typedef struct ft8rx_handle ft8rx_handle;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -132,6 +142,13 @@ int  ft8rx_valid77(ft8rx_handle* h, const uint64_t* msg_lo, const uint64_t* msg_
  * signal_table: n_frames*n_signals records laid out as pyft8_amd/synth.py:SIGNAL_DTYPE; pulse_cumsum: 5761 doubles. */
 int  ft8rx_synth_frames(ft8rx_handle* h, uint64_t seed, int first_index, int n_frames, int n_signals,
                         const void* signal_table, int signal_bytes, const double* pulse_cumsum, int16_t* d_audio);
+/* Host message layer (pure host code, no GPU needed): replays each frame's records + events in the reference's emit
+ * order -- hash-table side effects of every unpack() call (decoders.py:44,92; databases.py:10-26), duplicate filter
+ * (receiver.py:51-66), round/llr_sd ordering of manage_cycle (receiver.py:389-398) -- and renders the message tuples.
+ * records [n_frames][max_cands], events [n_frames][FT8RX_EVENT_CAP]; out [n_frames][max_msgs]; frames are spread over
+ * n_threads host threads.  out_counts[f] may exceed max_msgs (truncated). */
+int  ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, const ft8rx_event* events, const int32_t* event_counts,
+                         int n_frames, int max_cands, ft8rx_message* out, int max_msgs, int32_t* out_counts, int n_threads);
 /* the handle's own device audio buffer ([max_frames][180000] int16) and a D2H copy helper (tests, tools) */
 int16_t* ft8rx_staging_audio(ft8rx_handle* h);
 int  ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes);

@@ -28,7 +28,9 @@ RECORD_DTYPE = np.dtype([("msg_lo", "<u8"), ("msg_hi", "<u8"), ("score", "<f4"),
                          ("n_its", "<i2"), ("nsync", "u1"), ("pad", "u1"), ("pad2", "<u4")])
 EVENT_DTYPE = np.dtype([("msg_lo", "<u8"), ("msg_hi", "<u8"), ("cand", "<u2"), ("ipass", "u1"), ("slot", "u1"),
                         ("seq", "<u2"), ("valid", "<u2")])
-assert RECORD_DTYPE.itemsize == 48 and EVENT_DTYPE.itemsize == 24
+MESSAGE_DTYPE = np.dtype([("f", "S16", (3,)), ("cand", "<i2"), ("f0_idx", "<i2"), ("h0_idx", "<i2"), ("snr", "i1"), ("ttweak", "i1"),
+                          ("ftweak", "i1"), ("ipass", "u1"), ("ap", "u1"), ("method", "u1"), ("fine", "u1"), ("pad", "u1", (3,))])
+assert RECORD_DTYPE.itemsize == 48 and EVENT_DTYPE.itemsize == 24 and MESSAGE_DTYPE.itemsize == 64
 
 ST_ACTIVE, ST_DECODED, ST_STOP_GRID_SD, ST_STOP_COSTAS, ST_STOP_FINE_SD, ST_EXHAUSTED = range(6)
 M_GOOD91, M_LDPC_A, M_LDPC_B, M_OSD, M_LDPC_B_OSD = range(5)
@@ -288,6 +290,26 @@ class Handle:
         y = np.empty_like(x)
         self._chk(lib().ft8rx_math_probe(self._h, int(which), _ptr(x, C.c_float), x.size, _ptr(y, C.c_float)), "ft8rx_math_probe")
         return y
+
+
+def package_batch(rec, cnt, ev, evc, max_msgs=128, n_threads=None):
+    """Native host message layer (ft8rx_package_batch): records/events of B frames -> (messages[B, max_msgs], counts[B]).
+    Pure host code: works without a GPU."""
+    rec = np.ascontiguousarray(rec)
+    ev = np.ascontiguousarray(ev)
+    cnt = np.ascontiguousarray(cnt, np.int32)
+    evc = np.ascontiguousarray(evc, np.int32)
+    B, mc = rec.shape
+    assert ev.shape == (B, EVENT_CAP) and rec.dtype == RECORD_DTYPE and ev.dtype == EVENT_DTYPE
+    out = np.zeros((B, max_msgs), MESSAGE_DTYPE)
+    oc = np.zeros(B, np.int32)
+    if n_threads is None:
+        n_threads = min(32, os.cpu_count() or 1)
+    rc = lib().ft8rx_package_batch(rec.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32), ev.ctypes.data_as(C.c_void_p), _ptr(evc, C.c_int32),
+                                   int(B), int(mc), out.ctypes.data_as(C.c_void_p), int(max_msgs), _ptr(oc, C.c_int32), int(n_threads))
+    if rc != 0:
+        raise Ft8rxError(f"ft8rx_package_batch failed ({rc})")
+    return out, oc
 
 
 _default = {}

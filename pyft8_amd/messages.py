@@ -218,3 +218,28 @@ def package_frame(rec, count, events, n_events, cyclestart_string="", band=None,
                 if on_message is not None:
                     on_message(m)
     return out
+
+
+def message_dicts(msgs, count, cyclestart_string="", band=None, odd_even=0, on_message=None):
+    """Rows of the native packager (ft8rx_package_batch, _lib.MESSAGE_DTYPE) -> the reference's message dicts
+    (receiver.py:57-65).  Same formatting as package_frame above."""
+    out = []
+    now = time.time()
+    for m in msgs[:min(int(count), len(msgs))]:
+        text = tuple(x.decode() for x in m["f"])
+        fine = bool(m["fine"])
+        tsec = int(m["h0_idx"]) / 25.0
+        fHz = 3.125 * int(m["f0_idx"])
+        if fine:
+            tsec = float(tsec + int(m["ttweak"]) / 200)
+            fHz = float(fHz + int(m["ftweak"]) / 16)
+        snr = "%+03d" % int(m["snr"])
+        rec = {"ipass": int(m["ipass"]), "method": int(m["method"]), "ap": int(m["ap"]), "ttweak": int(m["ttweak"]), "ftweak": int(m["ftweak"])}
+        notes, tw = decode_notes(rec)
+        d = {"band": band, "tsec": tsec, "fHz": fHz, "msg_tuple": text, "their_snr": snr, "their_tx_cycle": odd_even,
+             "all_txt_format": f"{cyclestart_string} {snr} {(tsec - 0.6):4.1f} {fHz:4.0f} ~ {' '.join(text)}",
+             "cyclestart_string": cyclestart_string, "decode_completed": now, "tweaks": tw, "decode_notes": notes + tw}
+        out.append(d)
+        if on_message is not None:
+            on_message(d)
+    return out

@@ -177,12 +177,23 @@ class Receiver:
             audio = audio[None]
         B = audio.shape[0]
         rec, cnt, ev, evc = self._handle(B).decode_batch(audio)
+        # host message layer: native, multithreaded (ft8rx_package_batch); messages.package_frame is its Python twin
+        msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc)
         out = []
         for f in range(B):
             cs = cyclestart_strings[f] if cyclestart_strings is not None else "700101_000015"
-            out.append(_m.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]), cyclestart_string=cs, band=self.band,
-                                        odd_even=0, on_message=self.on_message))
+            out.append(_m.message_dicts(msgs[f], mcnt[f], cyclestart_string=cs, band=self.band, odd_even=0, on_message=self.on_message))
         return (out, rec, cnt) if return_records else out
+
+    def decode_frames_arrays(self, audio_i16, n_threads=None):
+        """High-throughput variant of decode_frames: no Python dicts.  -> (messages[B, 128] of _lib.MESSAGE_DTYPE,
+        counts[B], records[B, max_cands], record_counts[B]); rows are in the reference's emit order."""
+        audio = np.ascontiguousarray(audio_i16, np.int16)
+        if audio.ndim == 1:
+            audio = audio[None]
+        rec, cnt, ev, evc = self._handle(audio.shape[0]).decode_batch(audio)
+        msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=n_threads)
+        return msgs, mcnt, rec, cnt
 
     def decode_frame(self, audio_i16, cyclestart_string="700101_000015"):
         return self.decode_frames(np.asarray(audio_i16)[None], [cyclestart_string])[0]
@@ -197,7 +208,8 @@ class Receiver:
             t0 = T_CYC * int((t_end - T_CYC / 2) / T_CYC)              # start of the cycle that just ended
             cs = _time.strftime("%y%m%d_%H%M%S", _time.gmtime(t0))
             rec, cnt, ev, evc = self._handle(1).decode_batch(frame[None])
-            out += _m.package_frame(rec[0], int(cnt[0]), ev[0], int(evc[0]), cyclestart_string=cs, band=self.band,
+            msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=1)
+            out += _m.message_dicts(msgs[0], mcnt[0], cyclestart_string=cs, band=self.band,
                                     odd_even=int((t0 % (2 * T_CYC)) / T_CYC), on_message=self.on_message)
         return out
 

@@ -122,3 +122,42 @@ def test_gather_two_ranks_gloo(tmp_path):
     res = json.load(open(out))
     want = [[" ".join(m["msg_tuple"]) for m in load_golden(nm)[2]["messages"]] for nm in ["synth_200000", "synth_100000", "synth_200000"]]
     assert res == want
+
+
+@pytest.mark.parametrize("name", GOLDEN_FRAMES)
+def test_native_packager_matches_python_and_reference(name):
+    """ft8rx_package_batch (C++, pure host) == messages.package_frame (Python) == the reference's dicts."""
+    from pyft8_amd import _lib, messages as M
+    audio, gold, js = load_golden(name)
+    rec, n, ev, nev = records_from_oracle(oracle_frame(audio))
+    evp = np.zeros(_lib.EVENT_CAP, _lib.EVENT_DTYPE)
+    evp[:len(ev)] = ev[:_lib.EVENT_CAP]
+    # two frames in one call (the second truncated to 5 events) to exercise batching / threads
+    recs = np.stack([rec, rec]); evs = np.stack([evp, evp])
+    msgs, cnt = _lib.package_batch(recs, np.array([n, n], np.int32), evs, np.array([nev, 5], np.int32), n_threads=2)
+    got = M.message_dicts(msgs[0], cnt[0], cyclestart_string="700101_000015")
+    py = M.package_frame(rec, n, ev, nev, cyclestart_string="700101_000015")
+    assert len(got) == len(py) == len(js["messages"])
+    for a, b, ref in zip(got, py, js["messages"]):
+        for key, val in ref.items():
+            assert (list(a[key]) if key == "msg_tuple" else a[key]) == val, (key, a[key], val)
+            assert a[key] == b[key]
+    trunc = sorted(" ".join(x.decode() for x in m["f"]).replace("<...>", "#") for m in msgs[1][:cnt[1]])
+    assert trunc == sorted(" ".join(m["msg_tuple"]).replace("<...>", "#") for m in js["messages"])
+
+
+def test_native_packager_throughput():
+    import time
+    from pyft8_amd import _lib
+    audio, gold, js = load_golden("synth_000000")
+    rec, n, ev, nev = records_from_oracle(oracle_frame(audio))
+    evp = np.zeros(_lib.EVENT_CAP, _lib.EVENT_DTYPE); evp[:len(ev)] = ev
+    B = 256
+    recs = np.stack([rec] * B); evs = np.stack([evp] * B)
+    cnt = np.full(B, n, np.int32); evc = np.full(B, nev, np.int32)
+    _lib.package_batch(recs, cnt, evs, evc, n_threads=1)
+    t0 = time.perf_counter()
+    msgs, mc = _lib.package_batch(recs, cnt, evs, evc, n_threads=1)
+    dt = time.perf_counter() - t0
+    assert (mc == len(js["messages"])).all()
+    assert B / dt > 3000, f"native packager only {B / dt:.0f} frames/s on one thread"
