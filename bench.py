@@ -157,12 +157,16 @@ def main():
     h.set_profiling(False)
     rec, cnt, ev, evc = h.fetch(B)
     # informational: audio in HBM -> kernels -> D2H of records/events -> native host message layer (all messages rendered)
+    # The host layer of batch k-1 (C++ threads, GIL released) overlaps the GPU work of batch k.
     t1 = time.perf_counter()
-    for _ in range(3):
+    prev = None
+    for _ in range(6):
         h.enqueue(d_audio.data_ptr(), B)
-        r_ = h.fetch(B)
-        msgs_, mc_ = _lib.package_batch(*r_)
-    e2e = 3 * B / (time.perf_counter() - t1)
+        if prev is not None:
+            msgs_, mc_ = _lib.package_batch(*prev)
+        prev = h.fetch(B)
+    msgs_, mc_ = _lib.package_batch(*prev)
+    e2e = 6 * B / (time.perf_counter() - t1)
     n_dec = int(sum((rec[f][:cnt[f]]["status"] == 1).sum() for f in range(B)))
     n_msgs = sum(len(messages.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]))) for f in range(min(B, 16)))
 
