@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--unique", type=int, default=64, help="(host generator only) distinct frames generated per rank, tiled to --frames")
     ap.add_argument("--host-synth", action="store_true", help="generate frames with the numpy generator instead of the device kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for flow tests on one GPU)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams a batch is cut across (1 = one chain of whole-batch launches)")
     args = ap.parse_args()
 
@@ -103,9 +104,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if args.backend != "nccl":
+        local = local % torch.cuda.device_count()          # flow test: several ranks may share one GPU
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     from pyft8_amd import _lib, messages
     B = args.frames
     h = _lib.Handle(device=local, max_frames=B)
@@ -140,7 +146,7 @@ def main():
     h.sync()
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())

@@ -17,6 +17,14 @@ GOLDEN_FRAMES = ["test_08", "test_09", "synth_000000", "synth_100000", "synth_20
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the host-layer tests load libft8rx.so (pure host entry points, symbol table): build it if this is a fresh checkout
+    try:
+        from pyft8_amd import _lib
+        import shutil
+        if not os.path.exists(_lib.LIB_PATH) and shutil.which("hipcc"):
+            _lib.build()
+    except Exception as e:      # the tests that need it will report the real error
+        print("note: could not pre-build libft8rx.so:", e)
     config.addinivalue_line("markers", "ref: needs /root/reference (build container only)")
 
 
