@@ -251,21 +251,8 @@ FT8_DEV void sym32_quad(cpx* x, int n2, int lane, const cpx* __restrict__ w32, f
 // only bit `pos` (0 = least significant of the 77-bit integer) set; filled by the host at create time with the
 // bit-serial definition.
 __device__ uint16_t d_CRC_SYN[77];
-#ifndef FT8_LINCRC
-#define FT8_LINCRC 1
-#endif
 FT8_DEV unsigned ft8_crc14(uint64_t lo, uint64_t hi) {
     unsigned r = 0;
-#if !FT8_LINCRC
-    for (int i = 0; i < 96; i++) {
-        unsigned b = 0;
-        if (i < 77) { int pos = 76 - i; b = (unsigned)((pos >= 64 ? (hi >> (pos - 64)) : (lo >> pos)) & 1u); }
-        unsigned top = (r >> 13) & 1u;
-        r = ((r << 1) & 0x3FFFu) | b;
-        if (top) r ^= 0x2757u;
-    }
-    return r;
-#endif
 #pragma unroll 8
     for (int pos = 0; pos < 64; pos++) r ^= ((lo >> pos) & 1ull) ? (unsigned)d_CRC_SYN[pos] : 0u;
 #pragma unroll

@@ -69,7 +69,6 @@ struct Att {               // one decode attempt's outcome
     uint8_t pad[2];
 };
 
-static const double W6_HOST = (double)(-0.16666667163372040f);
 #define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */
 
 // grid row accessor with the reference's modulo-750 wrap (receiver.py:240,347,360)
@@ -610,8 +609,6 @@ FT8_DEV cpx fine_input(const cpx* __restrict__ S, int fb, int k, const double* _
 // forward FFT of the conjugated slice into z (unscaled, unconjugated), natural Stockham layout, in place.
 // (Measured alternatives, profiles/r01_notes.md: 256-thread blocks 7.96 ms, bank-conflict-free padded/transposed
 // inter-stage layouts 6.92 ms, this version 6.36 ms per 256 frames: the kernel is latency/barrier bound.)
-#define FINE_ZLEN 3200
-FT8_DEV int mapC(int i) { return i; }
 
 // The stages are written for any FINE_NT in {64, 128}: a thread owns ceil(groups / FINE_NT) groups of each stage,
 // loads all of them, passes the barrier, then computes and stores them (in place).  With FINE_NT = 64 the block is a
@@ -705,7 +702,7 @@ FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, int lane, const cpx* w3
     if (i0 > 3168) i0 = 3168;
     cpx x[8];
 #pragma unroll
-    for (int n1 = 0; n1 < 8; n1++) { cpx v = z[mapC(i0 + 4 * n1 + n2)]; x[n1] = make_float2(v.x * FINE_INV, -(v.y * FINE_INV)); }
+    for (int n1 = 0; n1 < 8; n1++) { cpx v = z[i0 + 4 * n1 + n2]; x[n1] = make_float2(v.x * FINE_INV, -(v.y * FINE_INV)); }
     sym32_quad(x, n2, lane, w32, mag);
 }
 
@@ -719,7 +716,7 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
                                                   const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
                                                   const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
                                                   float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
-    __shared__ cpx z[FINE_ZLEN];
+    __shared__ cpx z[3200];
     __shared__ float mg[640];          // [8][49] scoring magnitudes, later the [79][8] grid
     __shared__ float p[464];
     __shared__ float llr[176];
@@ -846,12 +843,6 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
 // One wavefront per attempt.  Lane r holds generator row r (and row 64+r for r<27) in registers.
 FT8_DEV uint64_t shfl64(uint64_t v, int src) {
     uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
-    return ((uint64_t)hi << 32) | lo;
-}
-// broadcast from a wave-uniform source lane through the scalar unit (v_readlane) instead of the LDS crossbar
-FT8_DEV uint64_t readlane64(uint64_t v, int src) {
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
 }
 FT8_DEV uint64_t xor_reduce64(uint64_t v) {
