@@ -596,11 +596,14 @@ __global__ __launch_bounds__(256) void k_cyc_c(const cpx* __restrict__ Z, cpx* _
 #endif
 #define FINE_INV 0.0003125f
 
-// conj(taper * spec) for bin k of the rolled 3200-bin slice (receiver.py:180-185); k < 850 or k >= 3050
-FT8_DEV cpx fine_input(const cpx* __restrict__ S, int fb, int k, const double* __restrict__ taper) {
+// conj(taper * spec) for bin k of the rolled 3200-bin slice (receiver.py:180-185); k < 850 or k >= 3050.
+// `sl` is the candidate's spectrum window staged in LDS: sl[i] = spec[fb0 - 182 + i], i < 1064 (covers every ftweak);
+// off = ftweak + 182.
+#define FINE_SLICE 1064
+FT8_DEV cpx fine_input(const cpx* sl, int off, int k, const double* __restrict__ taper) {
     cpx v; int ti;
-    if (k < 850) { v = S[fb + k]; ti = (k >= 750) ? k - 750 : -1; }
-    else { const int j = k - 3050; v = S[fb - 150 + j]; ti = (j < 100) ? j : -1; }
+    if (k < 850) { v = sl[off + k]; ti = (k >= 750) ? k - 750 : -1; }
+    else { const int j = k - 3050; v = sl[off - 150 + j]; ti = (j < 100) ? j : -1; }
     if (ti >= 0) { const double t = taper[ti]; v.x = (float)((double)v.x * t); v.y = (float)((double)v.y * t); }
     v.y = -v.y;
     return v;
@@ -613,7 +616,7 @@ FT8_DEV cpx fine_input(const cpx* __restrict__ S, int fb, int k, const double* _
 // The stages are written for any FINE_NT in {64, 128}: a thread owns ceil(groups / FINE_NT) groups of each stage,
 // loads all of them, passes the barrier, then computes and stores them (in place).  With FINE_NT = 64 the block is a
 // single wavefront, the "barriers" are free and every lane carries 3-4 independent groups (ILP instead of TLP).
-FT8_DEV void fine_stage1(const cpx* __restrict__ S, int fb, cpx* z, const cpx* __restrict__ W,
+FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W,
                          const double* __restrict__ taper, int tid) {
     // pass [8]: n = 3200, s = 1, m = 400: butterfly p reads bins p + 400 j; only j = 0, 1, (2 if p < 50), (7 if p >= 250)
     // are non-zero.  All global loads of the thread are issued before the first butterfly.
@@ -690,7 +693,7 @@ FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int
     }
     __syncthreads();
 }
-FT8_DEV void fine_fft(const cpx* __restrict__ S, int fb, cpx* z, const Tables& T, int tid, int lo, int hi) {
+FT8_DEV void fine_fft(const cpx* S, int fb, cpx* z, const Tables& T, int tid, int lo, int hi) {
     fine_stage1(S, fb, z, T.W3200, T.taper, tid);
     fine_stage2(z, T.W3200, tid);
     fine_stage3(z, T.W3200, tid, lo, hi);
@@ -717,10 +720,11 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
                                                   const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
                                                   float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
     __shared__ cpx z[3200];
+    __shared__ cpx slice[FINE_SLICE];  // the candidate's 1064 spectrum bins, read by the first stage of all ten IFFTs
     __shared__ float mg[640];          // [8][49] scoring magnitudes, later the [79][8] grid
-    __shared__ float p[464];
-    __shared__ float llr[176];
-    __shared__ float sq[176];
+    float* p = reinterpret_cast<float*>(slice);      // [464] the slice is dead once the last IFFT has run: reuse it
+    float* llr = p + 464;                            // [176]
+    float* sq = llr + 176;                           // [176]
     __shared__ float sc[16];
     __shared__ int ish[4];
     __shared__ cpx w32[32];
@@ -735,11 +739,16 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         f0 = r.f0_idx; h0 = r.h0_idx;
     }
     if (tid < 32) w32[tid] = T.W32[tid];
-    const cpx* S = spec + (size_t)frame * FT8RX_SPEC_BINS;
     const int fb0 = 50 * f0;                                      // int(0.5 + fHz*16)
+    {
+        const cpx* __restrict__ Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
+        for (int i = tid; i < FINE_SLICE; i += FINE_NT) slice[i] = Sg[i];
+        __syncthreads();
+    }
+    const cpx* S = slice;
     const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
     // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
-    fine_fft(S, fb0, z, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43);   // the 8 time tweaks of the middle Costas block
+    fine_fft(S, 182, z, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43);   // the 8 time tweaks of the middle Costas block
 #pragma unroll 1
     for (int r = 0; r < (224 + FINE_NT - 1) / FINE_NT; r++) {
         const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         float s;
         if (fcur == 0) s = score_f0;             // same series, same offset: identical value
         else {
-            fine_fft(S, fb0 + fcur, z, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43);
+            fine_fft(S, 182 + fcur, z, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43);
             last_ft = fcur;
             if (tid < 64) {                       // 7 symbols x 4 lanes on wavefront 0
                 const int qd = tid >> 2, n2 = tid & 3;
@@ -790,7 +799,7 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         }
         if (i == 0 || s > best) { best = s; ft = fcur; }
     }
-    fine_fft(S, fb0 + ft, z, T, tid, 0, 3200);   // full series for the 79 x 8 grid
+    fine_fft(S, 182 + ft, z, T, tid, 0, 3200);   // full series for the 79 x 8 grid
 #pragma unroll 1
     for (int r = 0; r < (316 + FINE_NT - 1) / FINE_NT; r++) {                 // full 79 x 8 grid
         const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;
