@@ -647,7 +647,7 @@ FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W
     }
     __syncthreads();
 }
-FT8_DEV void fine_stage2(cpx* z, const cpx* __restrict__ W, int tid) {
+FT8_DEV void fine_stage2(cpx* z, const cpx* w400, int tid) {
     typedef Fused2<3200, 400, 8, 4, 4> F;                         // passes [4,4]: n = 400, s = 8; 200 groups
     constexpr int R = (F::groups + FINE_NT - 1) / FINE_NT;
     cpx a[R][4][4];
@@ -658,7 +658,34 @@ FT8_DEV void fine_stage2(cpx* z, const cpx* __restrict__ W, int tid) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int g = tid + FINE_NT * r;
-        if (g < F::groups) { F::compute_pp(g >> 3, a[r], W); F::store_affine<32, 8>(z, (g & 7) + 128 * (g >> 3), a[r]); }
+        if (g < F::groups) {
+            // same arithmetic as F::compute_pp; every twiddle index of this stage is a multiple of 8, so the factors come
+            // from the 400-entry LDS copy w400[t] = W3200[8 t]:  pass A  W3200[j p 8] = w400[j p],  pass B  W3200[j' pp 32] = w400[4 j' pp]
+            const int pp = g >> 3;
+#pragma unroll
+            for (int jp = 0; jp < 4; jp++) {
+                dft<4>(a[r][jp]);
+                const int pq = pp + 25 * jp;
+                if (pq != 0) {
+#pragma unroll
+                    for (int j = 1; j < 4; j++) a[r][jp][j] = cmul(a[r][jp][j], w400[j * pq]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cpx b[4];
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) b[jp] = a[r][jp][j];
+                dft<4>(b);
+                if (pp != 0) {
+#pragma unroll
+                    for (int jp = 1; jp < 4; jp++) b[jp] = cmul(b[jp], w400[4 * jp * pp]);
+                }
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) a[r][jp][j] = b[jp];
+            }
+            F::store_affine<32, 8>(z, (g & 7) + 128 * (g >> 3), a[r]);
+        }
     }
     __syncthreads();
 }
@@ -693,9 +720,9 @@ FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int
     }
     __syncthreads();
 }
-FT8_DEV void fine_fft(const cpx* S, int fb, cpx* z, const Tables& T, int tid, int lo, int hi) {
+FT8_DEV void fine_fft(const cpx* S, int fb, cpx* z, const cpx* w400, const Tables& T, int tid, int lo, int hi) {
     fine_stage1(S, fb, z, T.W3200, T.taper, tid);
-    fine_stage2(z, T.W3200, tid);
+    fine_stage2(z, w400, tid);
     fine_stage3(z, T.W3200, tid, lo, hi);
 }
 
@@ -722,6 +749,7 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
     __shared__ cpx z[3200];
     __shared__ cpx slice[FINE_SLICE];  // the candidate's 1064 spectrum bins, read by the first stage of all ten IFFTs
     __shared__ float mg[640];          // [8][49] scoring magnitudes, later the [79][8] grid
+    __shared__ cpx w400[400];          // W3200[8 t]: every twiddle of the [4,4] stage
     float* p = reinterpret_cast<float*>(slice);      // [464] the slice is dead once the last IFFT has run: reuse it
     float* llr = p + 464;                            // [176]
     float* sq = llr + 176;                           // [176]
@@ -743,12 +771,13 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
     {
         const cpx* __restrict__ Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
         for (int i = tid; i < FINE_SLICE; i += FINE_NT) slice[i] = Sg[i];
+        for (int i = tid; i < 400; i += FINE_NT) w400[i] = T.W3200[8 * i];
         __syncthreads();
     }
     const cpx* S = slice;
     const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
     // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
-    fine_fft(S, 182, z, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43);   // the 8 time tweaks of the middle Costas block
+    fine_fft(S, 182, z, w400, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43);   // the 8 time tweaks of the middle Costas block
 #pragma unroll 1
     for (int r = 0; r < (224 + FINE_NT - 1) / FINE_NT; r++) {
         const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
@@ -780,7 +809,7 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         float s;
         if (fcur == 0) s = score_f0;             // same series, same offset: identical value
         else {
-            fine_fft(S, 182 + fcur, z, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43);
+            fine_fft(S, 182 + fcur, z, w400, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43);
             last_ft = fcur;
             if (tid < 64) {                       // 7 symbols x 4 lanes on wavefront 0
                 const int qd = tid >> 2, n2 = tid & 3;
@@ -799,7 +828,7 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         }
         if (i == 0 || s > best) { best = s; ft = fcur; }
     }
-    fine_fft(S, 182 + ft, z, T, tid, 0, 3200);   // full series for the 79 x 8 grid
+    fine_fft(S, 182 + ft, z, w400, T, tid, 0, 3200);   // full series for the 79 x 8 grid
 #pragma unroll 1
     for (int r = 0; r < (316 + FINE_NT - 1) / FINE_NT; r++) {                 // full 79 x 8 grid
         const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;
