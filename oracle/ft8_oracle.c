@@ -426,10 +426,15 @@ static void fine_symbol(const cpx* z, int tb, int s, float* g8) {
 }
 
 static float fine_score(const cpx* z, int tb) {                    /* receiver.py:197-206: middle Costas only */
+    /* contract: per symbol a, on = g[a][costas[a]] and off_a = sum over the other six tones b < 7 (b ascending, fp64);
+     * S1 = sum_a on_a, S2 = sum_a off_a (a ascending); score = (float)(S1 + w6 * S2) */
     double s1 = 0.0, s2 = 0.0;
     for (int a = 0; a < 7; a++) {
         float g[8]; fine_symbol(z, tb, 36 + a, g);
-        for (int b = 0; b < 7; b++) { if (b == COSTAS[a]) s1 += (double)g[b]; else s2 += (double)g[b]; }
+        double off = 0.0;
+        for (int b = 0; b < 7; b++) if (b != COSTAS[a]) off += (double)g[b];
+        s1 += (double)g[COSTAS[a]];
+        s2 += off;
     }
     return (float)(s1 + W6 * s2);
 }

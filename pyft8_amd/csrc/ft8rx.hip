@@ -736,19 +736,13 @@ FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, int lane, const cpx* w3
     sym32_quad(x, n2, lane, w32, mag);
 }
 
-FT8_DEV float fine_score_from(const float* mg /*[7][7]*/) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int a = 0; a < 7; a++) for (int b = 0; b < 7; b++) { if (b == d_COSTAS[a]) s1 += (double)mg[a * 7 + b]; else s2 += (double)mg[a * 7 + b]; }
-    return (float)(s1 + W6 * s2);
-}
-
 __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
                                                   const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
                                                   const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
                                                   float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
     __shared__ cpx z[3200];
     __shared__ cpx slice[FINE_SLICE];  // the candidate's 1064 spectrum bins, read by the first stage of all ten IFFTs
-    __shared__ float mg[640];          // [8][49] scoring magnitudes, later the [79][8] grid
+    __shared__ __attribute__((aligned(8))) float mg[640];   // scoring (on, off) sums as fp64, later the [79][8] grid
     __shared__ cpx w400[400];          // W3200[8 t]: every twiddle of the [4,4] stage
     float* p = reinterpret_cast<float*>(slice);      // [464] the slice is dead once the last IFFT has run: reuse it
     float* llr = p + 464;                            // [176]
@@ -776,6 +770,10 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
     }
     const cpx* S = slice;
     const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
+    // Score of one Costas block (contract): per symbol a the quad leader forms on_a = |tone costas[a]| and off_a = sum of
+    // the other six tones (b ascending) in fp64 from its registers; after ONE barrier every thread combines
+    // S1 = sum_a on_a, S2 = sum_a off_a (a ascending) and score = (float)(S1 + w6 S2) -- no serial chain, no broadcast.
+    double* dsum = reinterpret_cast<double*>(mg);              // [8][7][2] (on, off); mg is free until the final grid
     // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
     fine_fft(S, 182, z, w400, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43);   // the 8 time tweaks of the middle Costas block
 #pragma unroll 1
@@ -786,23 +784,24 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         float mag[8];
         fine_sym_quad(z, tb0 - 8 + 2 * ti + 32 * (36 + a), n2, lane, w32, mag);
         if (valid && n2 == 0) {
+            const int c = d_COSTAS[a];
+            double off = 0.0, on = 0.0;
 #pragma unroll
-            for (int b = 0; b < 7; b++) mg[ti * 49 + a * 7 + b] = mag[b];
+            for (int b = 0; b < 7; b++) { if (b == c) on = (double)mag[b]; else off += (double)mag[b]; }
+            dsum[(ti * 7 + a) * 2] = on; dsum[(ti * 7 + a) * 2 + 1] = off;
         }
     }
     __syncthreads();
-    if (tid < 8) sc[tid] = fine_score_from(mg + 49 * tid);
-    __syncthreads();
-    if (tid == 0) {
-        int bi = 0; float best = sc[0];
-        for (int i = 1; i < 8; i++) if (sc[i] > best) { best = sc[i]; bi = i; }
-        ish[0] = -8 + 2 * bi; sc[8] = best;
+    int tt = -8; float score_f0 = 0.0f;
+    for (int ti = 0; ti < 8; ti++) {                           // every thread: same values, same result
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 7; a++) { s1 += dsum[(ti * 7 + a) * 2]; s2 += dsum[(ti * 7 + a) * 2 + 1]; }
+        const float sct = (float)(s1 + W6 * s2);
+        if (ti == 0 || sct > score_f0) { score_f0 = sct; tt = -8 + 2 * ti; }     // first maximum (np.argmax)
     }
-    __syncthreads();
-    const int tt = ish[0];
-    const float score_f0 = sc[8];
     // --- frequency tweaks: range(-32,33,8)
-    float best = 0.0f; int ft = 0, last_ft = 0;
+    float best = 0.0f; int ft = 0;
 #pragma unroll 1
     for (int i = 0; i < 9; i++) {
         const int fcur = -32 + 8 * i;
@@ -810,21 +809,24 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         if (fcur == 0) s = score_f0;             // same series, same offset: identical value
         else {
             fine_fft(S, 182 + fcur, z, w400, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43);
-            last_ft = fcur;
             if (tid < 64) {                       // 7 symbols x 4 lanes on wavefront 0
                 const int qd = tid >> 2, n2 = tid & 3;
                 const bool valid = qd < 7;
                 float mag[8];
                 fine_sym_quad(z, tb0 + tt + 32 * (36 + (valid ? qd : 0)), n2, lane, w32, mag);
                 if (valid && n2 == 0) {
+                    const int c = d_COSTAS[qd];
+                    double off = 0.0, on = 0.0;
 #pragma unroll
-                    for (int b = 0; b < 7; b++) mg[qd * 7 + b] = mag[b];
+                    for (int b = 0; b < 7; b++) { if (b == c) on = (double)mag[b]; else off += (double)mag[b]; }
+                    dsum[qd * 2] = on; dsum[qd * 2 + 1] = off;
                 }
             }
             __syncthreads();
-            if (tid == 0) sc[9] = fine_score_from(mg);
-            __syncthreads();
-            s = sc[9];
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 7; a++) { s1 += dsum[a * 2]; s2 += dsum[a * 2 + 1]; }
+            s = (float)(s1 + W6 * s2);
         }
         if (i == 0 || s > best) { best = s; ft = fcur; }
     }
