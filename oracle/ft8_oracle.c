@@ -35,7 +35,7 @@ void ft8o_default_config(ft8o_config* c) {
     c->bp_nc0_b = 90; c->bp_iters_b = 20;                        /* receiver.py:95 */
     c->osd_single = 30; c->osd_double = 2;                       /* decoders.py:223 */
     c->llr_sd_min = 5.0f;                                        /* receiver.py:30 */
-    int p1920[] = {8, 8, 5, 3, 2, 0}, p3200[] = {8, 4, 4, 5, 5, 0}, p300[] = {5, 5, 4, 3, 0}, p320[] = {8, 8, 5, 0};
+    int p1920[] = {8, 4, 4, 5, 3, 0}, p3200[] = {8, 4, 4, 5, 5, 0}, p300[] = {5, 5, 4, 3, 0}, p320[] = {8, 8, 5, 0};
     memcpy(c->plan1920, p1920, sizeof(p1920)); memcpy(c->plan3200, p3200, sizeof(p3200));
     memcpy(c->plan300, p300, sizeof(p300));    memcpy(c->plan320, p320, sizeof(p320));
 }

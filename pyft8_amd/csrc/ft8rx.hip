@@ -90,21 +90,90 @@ FT8_DEV void log_event(ft8rx_event* ev, int32_t* evcount, int frame, int cand, i
 }
 
 // ------------------------------------------------------------------------------------ K1 spectrogram
-// one hop: window samples a[base .. base+3840) (zeros before the frame start) -> 976 dB values
+// one hop: window samples a[base .. base+3840) (zeros before the frame start) -> 976 dB values.
+// 128 threads; 1920-point complex FFT (plan [8,4,4,5,3]) in place in one LDS image as three register-fused stages:
+//   [8]    240 butterflies straight from global memory (int16 -> f32, Hann window fused in),
+//   [4,4]  120 groups of 16 (one per thread), twiddles from the LDS table w240[t] = W1920[8 t],
+//   [5,3]  128 groups of 15 (one per thread), compile-time twiddles,
+// then the real-FFT split and 20 log10|.|.
+#define SPEC_NT 128
 FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __restrict__ out, const Tables& T,
-                             cpx* bufA, cpx* bufB, int tid) {
-    for (int m = tid; m < 1920; m += 256) {
-        int i0 = base + 2 * m;
-        float x0 = 0.0f, x1 = 0.0f;
-        if (i0 >= 0) {
-            short2 v = *reinterpret_cast<const short2*>(a + i0);
-            x0 = (float)v.x * T.win[2 * m]; x1 = (float)v.y * T.win[2 * m + 1];
+                             cpx* z, cpx* w240, int tid) {
+    const cpx* __restrict__ W = T.W1920;
+    for (int i = tid; i < 240; i += SPEC_NT) w240[i] = W[8 * i];
+    {   // pass [8]: n = 1920, s = 1, m = 240: butterfly p reads samples m = p + 240 j
+        cpx v[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int p = tid + SPEC_NT * i;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int m = p + 240 * j, i0 = base + 2 * m;
+                float x0 = 0.0f, x1 = 0.0f;
+                if (p < 240 && i0 >= 0) {
+                    const short2 sm = *reinterpret_cast<const short2*>(a + i0);
+                    const float2 w = *reinterpret_cast<const float2*>(T.win + 2 * m);
+                    x0 = (float)sm.x * w.x; x1 = (float)sm.y * w.y;
+                }
+                v[i][j] = make_float2(x0, x1);
+            }
         }
-        bufA[m] = make_float2(x0, x1);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int p = tid + SPEC_NT * i;
+            if (p < 240) {
+                dft<8>(v[i]);
+                z[8 * p] = v[i][0];
+#pragma unroll
+                for (int j = 1; j < 8; j++) { cpx t = v[i][j]; if (p != 0) t = cmul(t, W[j * p]); z[8 * p + j] = t; }
+            }
+        }
     }
     __syncthreads();
-    cpx* z = lds_fft<1920, 8, 8, 5, 3, 2>(bufA, bufB, T.W1920, 1, tid, 256);
-    for (int k = tid; k < FT8RX_GRID_COLS; k += 256) {
+    {   // passes [4,4]: n = 240, s = 8; group g = (pp = g / 8, q = g % 8): in q + 8(pp + 15 j' + 60 j), out q + 8 j + 32(4 pp + j')
+        typedef Fused2<1920, 240, 8, 4, 4> F;
+        cpx v[4][4];
+        const bool on = tid < F::groups;
+        if (on) F::load_affine<120, 480>(z, tid, v);
+        __syncthreads();
+        if (on) {
+            const int pp = tid >> 3;
+#pragma unroll
+            for (int jp = 0; jp < 4; jp++) {
+                dft<4>(v[jp]);
+                const int pq = pp + 15 * jp;
+                if (pq != 0) {
+#pragma unroll
+                    for (int j = 1; j < 4; j++) v[jp][j] = cmul(v[jp][j], w240[j * pq]);          // W1920[j p 8]
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cpx u[4];
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) u[jp] = v[jp][j];
+                dft<4>(u);
+                if (pp != 0) {
+#pragma unroll
+                    for (int jp = 1; jp < 4; jp++) u[jp] = cmul(u[jp], w240[4 * jp * pp]);        // W1920[j' pp 32]
+                }
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) v[jp][j] = u[jp];
+            }
+            F::store_affine<32, 8>(z, (tid & 7) + 128 * (tid >> 3), v);
+        }
+        __syncthreads();
+    }
+    {   // passes [5,3]: n = 15, s = 128; group q: in q + 128 (j' + 3 j), out q + 128 j + 640 j'
+        typedef Fused2<1920, 15, 128, 5, 3> F;
+        cpx v[3][5];
+        F::load_affine<128, 384>(z, tid, v);
+        __syncthreads();
+        F::compute_pp(0, v, W);
+        F::store_affine<640, 128>(z, tid, v);
+        __syncthreads();
+    }
+    for (int k = tid; k < FT8RX_GRID_COLS; k += SPEC_NT) {
         cpx p = z[k], q = z[(1920 - k) % 1920];
         float er = 0.5f * (p.x + q.x), ei = 0.5f * (p.y - q.y);
         float orr = 0.5f * (p.y + q.y), oi = 0.5f * (q.x - p.x);
@@ -116,23 +185,23 @@ FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __r
     }
 }
 
-__global__ __launch_bounds__(256) void k_spectrogram(const int16_t* __restrict__ audio, float* __restrict__ grid, Tables T) {
-    __shared__ cpx bufA[1920];
-    __shared__ cpx bufB[1920];
+__global__ __launch_bounds__(SPEC_NT) void k_spectrogram(const int16_t* __restrict__ audio, float* __restrict__ grid, Tables T) {
+    __shared__ cpx z[1920];
+    __shared__ cpx w240[240];
     // XCD-aware hop mapping: workgroup id -> XCD is id % 8 and gridDim.x = 376 = 8 * 47, so the 47 workgroups of a
     // frame that land on one XCD take 47 consecutive hops: each XCD's L2 then sees one eighth of the frame's audio
     // (8x overlapping windows) instead of all of it.
     const int hop = (blockIdx.x & 7) * 47 + (blockIdx.x >> 3) + 1, f = blockIdx.y, tid = threadIdx.x;
     if (hop > 375) return;
     spectrogram_hop(audio + (size_t)f * FT8RX_NSAMP, 480 * hop - 3840,
-                    grid + ((size_t)f * FT8RX_GRID_ROWS + hop) * FT8RX_GRID_COLS, T, bufA, bufB, tid);
+                    grid + ((size_t)f * FT8RX_GRID_ROWS + hop) * FT8RX_GRID_COLS, T, z, w240, tid);
 }
 
 // streaming mode: one hop of the live receiver (AudioIn.get_hop_spectrum, receiver.py:288-293)
-__global__ __launch_bounds__(256) void k_hop_spectrum(const int16_t* __restrict__ win3840, float* __restrict__ row, Tables T) {
-    __shared__ cpx bufA[1920];
-    __shared__ cpx bufB[1920];
-    spectrogram_hop(win3840, 0, row, T, bufA, bufB, threadIdx.x);
+__global__ __launch_bounds__(SPEC_NT) void k_hop_spectrum(const int16_t* __restrict__ win3840, float* __restrict__ row, Tables T) {
+    __shared__ cpx z[1920];
+    __shared__ cpx w240[240];
+    spectrogram_hop(win3840, 0, row, T, z, w240, threadIdx.x);
 }
 
 __global__ void k_fill_row0(float* grid, int B) {
@@ -1385,7 +1454,7 @@ int ft8rx_default_config(ft8rx_config* c) {
 int ft8rx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 int ft8rx_get_fft_plans(int32_t* p1920, int32_t* p3200, int32_t* p300, int32_t* p320) {
-    const int32_t a[8] = {8, 8, 5, 3, 2, 0, 0, 0}, b[8] = {8, 4, 4, 5, 5, 0, 0, 0}, c[8] = {5, 5, 4, 3, 0, 0, 0, 0}, d[8] = {8, 8, 5, 0, 0, 0, 0, 0};
+    const int32_t a[8] = {8, 4, 4, 5, 3, 0, 0, 0}, b[8] = {8, 4, 4, 5, 5, 0, 0, 0}, c[8] = {5, 5, 4, 3, 0, 0, 0, 0}, d[8] = {8, 8, 5, 0, 0, 0, 0, 0};
     if (p1920) memcpy(p1920, a, sizeof(a));
     if (p3200) memcpy(p3200, b, sizeof(b));
     if (p300) memcpy(p300, c, sizeof(c));
@@ -1510,7 +1579,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
 #define STAGE(name) do { if (prof) { hipEventRecord(h->pev[h->pnames.size()], s); h->pnames.push_back(name); } } while (0)
     hipMemsetAsync(evc, 0, sizeof(int32_t) * B, s);
     STAGE("spectrogram");
-    k_spectrogram<<<dim3(376, B), 256, 0, s>>>(audio, grid, h->T);
+    k_spectrogram<<<dim3(376, B), SPEC_NT, 0, s>>>(audio, grid, h->T);
     STAGE("sync");
     const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
     k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, c);
@@ -1608,7 +1677,7 @@ int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid)
     if (!h || !audio || !grid || B < 1 || B > h->max_frames) return -1;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
-    k_spectrogram<<<dim3(376, B), 256, 0, h->stream>>>(h->d_audio, h->d_grid, h->T);
+    k_spectrogram<<<dim3(376, B), SPEC_NT, 0, h->stream>>>(h->d_audio, h->d_grid, h->T);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(grid, h->d_grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyDeviceToHost));
     return 0;
@@ -1619,7 +1688,7 @@ int ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row976
     HIPCHK(h, hipSetDevice(h->device));
     float* d_row = h->d_best_score;                      // any 976-float scratch: not in use between batches
     HIPCHK(h, hipMemcpyAsync(h->d_audio, window3840, sizeof(int16_t) * 3840, hipMemcpyHostToDevice, h->stream));
-    k_hop_spectrum<<<1, 256, 0, h->stream>>>(h->d_audio, d_row, h->T);
+    k_hop_spectrum<<<1, SPEC_NT, 0, h->stream>>>(h->d_audio, d_row, h->T);
     HIPCHK(h, hipMemcpyAsync(row976, d_row, sizeof(float) * FT8RX_GRID_COLS, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -1823,7 +1892,7 @@ int ft8rx_math_probe(ft8rx_handle* h, int which, const float* x, int n, float* y
         cpx* d_x = S.put((const cpx*)x, n); NEED(d_x);
         cpx* d_y = S.get<cpx>(n); NEED(d_y);
         const size_t lds = 2 * (size_t)n * sizeof(cpx);
-        if (n == 1920) k_fft_probe<1920, 8, 8, 5, 3, 2><<<1, 256, lds, h->stream>>>(d_x, d_y, h->T.W1920);
+        if (n == 1920) k_fft_probe<1920, 8, 4, 4, 5, 3><<<1, 256, lds, h->stream>>>(d_x, d_y, h->T.W1920);
         else if (n == 3200) k_fft_probe<3200, 8, 4, 4, 5, 5><<<1, 256, lds, h->stream>>>(d_x, d_y, h->T.W3200);
         else if (n == 300) k_fft_probe<300, 5, 5, 4, 3><<<1, 256, lds, h->stream>>>(d_x, d_y, h->T.W300);
         else if (n == 320) k_fft_probe<320, 8, 8, 5><<<1, 256, lds, h->stream>>>(d_x, d_y, h->T.W320);
