@@ -58,6 +58,7 @@ __device__ uint8_t  d_EDGE_V[522];
 __device__ uint8_t  d_EDGE_C[522];
 __device__ uint16_t d_VAR_E[174][3];
 __device__ uint64_t d_G0[91][3];
+__device__ uint64_t d_CHK_MASK[128][3];   // membership mask of check c over the 174 variables (rows >= 83 are zero)
 
 struct Att {               // one decode attempt's outcome
     uint64_t lo, hi;
@@ -451,23 +452,15 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
         if (r) { if (lane == 0) log_event(ev, evcount, frame, ci, ipG, ap, 0, lo, hi, r == 2); }
         if (r == 2) { resG.ok = 1; resG.lo = lo; resG.hi = hi; resG.n_its = 0; resG.method = FT8RX_M_GOOD91; doneG = true; }
     }
-    // per-lane static tables
-    int ev_[9], ec_[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) { int e = lane + 64 * i; ev_[i] = (e < 522) ? d_EDGE_V[e] : 0; ec_[i] = (e < 522) ? d_EDGE_C[e] : 0; }
+    // membership masks of this lane's two checks (c0 = lane, c1 = 64 + lane) over the 174 variables
     const int c0 = lane, c1 = lane + 64;
-    const int n0 = d_CHK_N[c0], e00 = d_CHK_E0[c0];
-    const int n1 = (c1 < 83) ? d_CHK_N[c1] : 0, e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
-    // membership masks of this lane's two checks over the 174 variables (3 x 64 bits each)
-    // (built with selects, not a runtime array index, so the six words stay in registers)
-    uint64_t cm00 = 0, cm01 = 0, cm02 = 0, cm10 = 0, cm11 = 0, cm12 = 0;
-#pragma unroll
-    for (int j = 0; j < 7; j++) {
-        if (j < n0) { const int v = d_CHK_V[c0][j]; const uint64_t bit = 1ull << (v & 63); const int w = v >> 6;
-                      cm00 |= (w == 0) ? bit : 0; cm01 |= (w == 1) ? bit : 0; cm02 |= (w == 2) ? bit : 0; }
-        if (j < n1) { const int v = d_CHK_V[c1][j]; const uint64_t bit = 1ull << (v & 63); const int w = v >> 6;
-                      cm10 |= (w == 0) ? bit : 0; cm11 |= (w == 1) ? bit : 0; cm12 |= (w == 2) ? bit : 0; }
-    }
+    const uint64_t cm00 = d_CHK_MASK[c0][0], cm01 = d_CHK_MASK[c0][1], cm02 = d_CHK_MASK[c0][2];
+    const uint64_t cm10 = d_CHK_MASK[c1][0], cm11 = d_CHK_MASK[c1][1], cm12 = d_CHK_MASK[c1][2];
+    // the edge tables are only needed once BP really iterates: most ipass-0 attempts stop at the initial
+    // unsatisfied-check test (decoders.py:159), so they are loaded lazily below
+    int ev_[9], ec_[9];
+    int n0 = 0, e00 = 0, n1 = 0, e01 = 0;
+    bool tables = false;
     float mc[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) mc[i] = 0.0f;
@@ -492,6 +485,13 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
             }
             if (r == 2) { res.ok = 1; res.lo = lo; res.hi = hi; res.n_its = (int16_t)it; res.has_out = 0; }
             break;      // success, or frozen state: the reference changes nothing from here on (decoders.py:161-164)
+        }
+        if (!tables) {                 // wave-uniform: first real iteration
+            tables = true;
+#pragma unroll
+            for (int i = 0; i < 9; i++) { int e = lane + 64 * i; ev_[i] = (e < 522) ? d_EDGE_V[e] : 0; ec_[i] = (e < 522) ? d_EDGE_C[e] : 0; }
+            n0 = d_CHK_N[c0]; e00 = d_CHK_E0[c0];
+            n1 = (c1 < 83) ? d_CHK_N[c1] : 0; e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
         }
         float tt[9];
 #pragma unroll
@@ -1535,6 +1535,12 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_EDGE_C), FT8_EDGE_C, sizeof(FT8_EDGE_C)) == hipSuccess;
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_VAR_E), FT8_VAR_E, sizeof(FT8_VAR_E)) == hipSuccess;
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_G0), FT8_G0, sizeof(FT8_G0)) == hipSuccess;
+    {   // per-check membership masks (3 x 64 bits), so a lane gets its two checks' masks with 6 coalesced loads
+        static uint64_t cm[128][3];
+        memset(cm, 0, sizeof(cm));
+        for (int c = 0; c < 83; c++) for (int j = 0; j < FT8_CHK_N[c]; j++) { int v = FT8_CHK_V[c][j]; cm[c][v >> 6] |= 1ull << (v & 63); }
+        ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CHK_MASK), cm, sizeof(cm)) == hipSuccess;
+    }
     {   // CRC-14 syndromes of the 77 unit messages (bit-serial definition, decoders.py:123-129)
         uint16_t syn[77];
         for (int pos = 0; pos < 77; pos++) syn[pos] = (uint16_t)ft8_crc14_serial_host(pos < 64 ? (1ull << pos) : 0ull, pos >= 64 ? (1ull << (pos - 64)) : 0ull);
