@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collect the evidence kept under profiles/ on a GPU box (run from the repo root through gpurun):
+#   tools/collect_profiles.sh <tag>        e.g. r01 -> gpurun_out/<tag>_*
+# rocprofv3 passes are separate runs (kernel trace + stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE), each with the
+# program itself after `--`.  Everything is bounded by `timeout`.
+set -u
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1"
+
+timeout 900 python3 bench.py --steps 10 --warmup 3 > "$OUT/${TAG}_bench_b256_s4.json" 2> "$OUT/${TAG}_bench_b256_s4.err"
+timeout 600 python3 bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b256_s1.json" 2>> "$OUT/${TAG}_bench_b256_s4.err"
+
+rm -rf "$OUT/${TAG}_stats" "$OUT/${TAG}_pmcF" "$OUT/${TAG}_pmcW"
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -o s -- $BENCH > "$OUT/${TAG}_stats.log" 2>&1
+DB=$(find "$OUT/${TAG}_stats" -name '*.db' | head -1)
+[ -n "$DB" ] && python3 tools/rocprof_summary.py "$DB" "$OUT/${TAG}_kernel_stats_b256.txt" > /dev/null
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_pmcF" -o f -- $BENCH > "$OUT/${TAG}_pmcF.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_pmcW" -o w -- $BENCH > "$OUT/${TAG}_pmcW.log" 2>&1
+F=$(find "$OUT/${TAG}_pmcF" -name '*counter_collection.csv' | head -1)
+W=$(find "$OUT/${TAG}_pmcW" -name '*counter_collection.csv' | head -1)
+[ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_pmc.json" "$OUT/${TAG}_pmc_b256.txt" > /dev/null
+
+# other BASELINE configurations (single GPU): config 2 (B = 4096; reference knobs and extension knobs), the config-3 shard
+# size (8192 frames per GPU) and config 4 (low SNR, few signals, truth-based decode probability)
+timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b4096_ref_knobs.json" 2> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline --bp-iters 30 --osd 40 4 > "$OUT/${TAG}_bench_b4096_ext_knobs.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py --frames 8192 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b8192.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline --signals 8 --snr -24 -14 > "$OUT/${TAG}_bench_b4096_lowsnr.json" 2>> "$OUT/${TAG}_big.err"
+timeout 1200 python3 tools/sensitivity.py 4096 > "$OUT/${TAG}_sensitivity_gpu.txt" 2>> "$OUT/${TAG}_big.err"
+ls -la "$OUT" | grep "${TAG}_" | head -40
