@@ -138,6 +138,7 @@ class Receiver:
         self.search_start_hop = self.search_h0_range[1] + 43 * 4
         self.device = device
         self._h = None
+        self._sub = None                              # handle for search() over a sub-range of f0 indices
         self._handle(max_frames)                      # fail loudly now if there is no GPU / library
         self.audio_in = AudioIn(search_freq_range, self)
 
@@ -152,21 +153,44 @@ class Receiver:
         self.band = band
 
     def search(self, cyclestart_string, odd_even, search_f_idxs=None):
-        """Costas sync search over the currently loaded frame (audio_in.load_frame)."""
-        if odd_even != 0:
-            raise _lib.Ft8rxError("frame-complete build: frames are decoded as cycle 0 of the grid (odd_even=0)")
-        rng = self.audio_in.search_f0_idx_range
-        if search_f_idxs is not None and (search_f_idxs[0], search_f_idxs[-1] + 1) != (rng[0], rng[1]):
-            raise _lib.Ft8rxError("search_f_idxs must equal the configured search_freq_range")
+        """Costas sync search over one cycle of audio_in.search_grid (reference receiver.py:338-367).
+
+        odd_even selects the half of the 750-row grid (rows odd_even*375 + 1 ... + 375); hops before the cycle's
+        first row read 1.0 (frame-complete semantics, DESIGN.md section 1 -- the live reference would see the
+        tail of the previous cycle there).  search_f_idxs must be a contiguous ascending range (the reference
+        only ever passes `range(a, b)`); a range other than the configured one runs on its own small handle."""
+        if odd_even not in (0, 1):
+            raise _lib.Ft8rxError("odd_even must be 0 or 1")
+        rng = list(self.audio_in.search_f0_idx_range)
+        if search_f_idxs is not None and len(search_f_idxs) > 0:
+            idx = [int(i) for i in search_f_idxs]
+            if idx != list(range(idx[0], idx[-1] + 1)):
+                raise _lib.Ft8rxError("search_f_idxs must be a contiguous ascending range")
+            rng = [idx[0], idx[-1] + 1]
+        elif search_f_idxs is not None:
+            self.candidates = []
+            return []
+        if rng == list(self.audio_in.search_f0_idx_range):
+            h = self._handle(1)
+        else:
+            if self._sub is None or (self._sub.cfg.f0_lo, self._sub.cfg.f0_hi) != tuple(rng):
+                if self._sub is not None:
+                    self._sub.close()
+                cfg = _lib.Config.from_buffer_copy(bytes(self.cfg))
+                cfg.f0_lo, cfg.f0_hi = rng
+                self._sub = _lib.Handle(cfg, device=self.device, max_frames=1)
+            h = self._sub
+        r0 = odd_even * self.audio_in.search_hops_per_cycle
         grid = np.ones((1, _lib.GRID_ROWS, _lib.GRID_COLS), np.float32)
-        grid[0, 1:376] = self.audio_in.search_grid[1:376]
-        f0, h0, sc, cnt = self._handle(1).sync_search(grid)
+        grid[0, 1:376] = self.audio_in.search_grid[r0 + 1:r0 + 376] if odd_even == 0 else \
+            np.concatenate([self.audio_in.search_grid[r0 + 1:], self.audio_in.search_grid[:1]])
+        f0, h0, sc, cnt = h.sync_search(grid)
         cands = []
         for i in range(int(cnt[0])):
             origin = {"h0_idx": int(h0[0, i]), "f0_idx": int(f0[0, i]), "tsec": int(h0[0, i]) / 25.0,
                       "fHz": 3.125 * int(f0[0, i]), "score": float(sc[0, i]),
                       "cyclestart_string": cyclestart_string, "band": self.band, "odd_even": odd_even}
-            cands.append(Candidate(origin, [int(h0[0, i]) + 4, int(h0[0, i]) + 4 * 71]))
+            cands.append(Candidate(origin, [r0 + int(h0[0, i]) + 4, r0 + int(h0[0, i]) + 4 * 71]))
         self.candidates = cands
         return cands
 

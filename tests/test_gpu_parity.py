@@ -298,6 +298,40 @@ def test_receiver_surface_matches_reference_listing():
     assert decoders.unpack(int('00000000000000000100011011110000010010000000000111000001100011111000010010001', 2)) == ("CQ DX", "G1OJS", "IO90")
 
 
+def test_search_sub_range_and_second_cycle():
+    """Receiver.search(cyclestart_string, odd_even, search_f_idxs) (reference receiver.py:338-367): a contiguous sub-range of
+    f0 indices equals the oracle's search with that range; the second half of the 750-row grid (odd_even=1) gives the
+    same candidates as the first, with the grid bounds moved by 375 hops."""
+    from pyft8_amd import _lib
+    from pyft8_amd.receiver import Receiver
+    rx = Receiver("x", None)
+    audio, gold, js = load_golden("test_08")
+    rx.audio_in.load_frame(audio)
+    full = rx.search("700101_000015", 0, range(32, 960))
+    assert [c.origin["f0_idx"] for c in full] == list(gold["f0_idx"])
+    sub = rx.search("700101_000015", 0, range(300, 340))
+    ocfg = O.default_config(**_lib.fft_plans(), f0_lo=300, f0_hi=340)
+    grid = O.spectrogram(audio, ocfg)
+    oc = O.sync_search(grid, ocfg)
+    assert len(oc) > 5
+    assert [(c.origin["f0_idx"], c.origin["h0_idx"]) for c in sub] == [(int(c.f0_idx), int(c.h0_idx)) for c in oc]
+    assert np.array_equal(np.float32([c.origin["score"] for c in sub]), np.float32([c.score for c in oc]))
+    assert rx.search("700101_000015", 0, []) == []
+    with pytest.raises(_lib.Ft8rxError):
+        rx.search("700101_000015", 0, [300, 302, 304])
+    # the same hops stored as the grid's second cycle (rows 376..749 and the wrap row 0)
+    g = rx.audio_in.search_grid
+    rows = g[1:376].copy()
+    g[:] = 1.0
+    g[376:] = rows[:374]
+    g[0] = rows[374]
+    odd = rx.search("700101_000030", 1, range(32, 960))
+    assert [(c.origin["f0_idx"], c.origin["h0_idx"], c.origin["score"]) for c in odd] == \
+           [(c.origin["f0_idx"], c.origin["h0_idx"], c.origin["score"]) for c in full]
+    assert [c.search_grid_bounds for c in odd] == [[b[0] + 375, b[1] + 375] for b in (c.search_grid_bounds for c in full)]
+    assert odd[0].origin["odd_even"] == 1
+
+
 def _decode_with(cfg_kw, audio):
     from pyft8_amd import _lib
     cfg = _lib.default_config(**cfg_kw)
