@@ -189,6 +189,14 @@ def main():
         prev = h.fetch(B)
     msgs_, mc_ = _lib.package_batch(*prev)
     e2e = 6 * B / (time.perf_counter() - t1)
+    # informational: the host-pointer entry (ft8rx_decode_batch: pageable host audio -> H2D -> kernels -> D2H), PCIe inclusive
+    host_audio = d_audio.cpu().numpy()
+    h.decode_batch(host_audio)
+    t2 = time.perf_counter()
+    for _ in range(3):
+        h.decode_batch(host_audio)
+    pcie = 3 * B / (time.perf_counter() - t2)
+    del host_audio
     n_dec = int(sum((rec[f][:cnt[f]]["status"] == 1).sum() for f in range(B)))
     n_msgs = sum(len(messages.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]))) for f in range(min(B, 16)))
 
@@ -214,7 +222,8 @@ def main():
                                    f"{'Receiver defaults' if reference_knobs else 'extension knobs'} ({knobs})",
                        "frames_per_gpu": B, "decoded_candidates_per_frame": n_dec / B,
                        "unique_messages_first16": n_msgs, "messages_per_frame": float(mc_.mean()),
-                       "end_to_end_frames_per_s_incl_d2h_and_host_message_layer": e2e, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+                       "end_to_end_frames_per_s_incl_d2h_and_host_message_layer": e2e,
+                       "host_pointer_entry_frames_per_s_incl_h2d_d2h": pcie, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
                          "kernel_ms": dom_ms, "alg_bytes_per_launch": ALG_BYTES[dom] * B,

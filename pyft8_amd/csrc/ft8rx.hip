@@ -1670,9 +1670,33 @@ int ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_recor
     if (!h || !audio) return -1;
     if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_decode_batch: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
-    int rc = ft8rx_enqueue_batch(h, h->d_audio, B);
-    if (rc) return rc;
+    // Host audio: the batch is cut into chunks (twice the stream count, >= 8 frames each); chunk k's host-to-device copy is
+    // issued on its stream right before its kernel chain, so it overlaps the kernels of the chunks before it.
+    int nc = h->profiling ? 1 : 2 * h->n_streams;
+    if (nc > B / 8) nc = B / 8;
+    if (nc <= 1) {
+        HIPCHK(h, hipMemcpyAsync(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
+        int rc = ft8rx_enqueue_batch(h, h->d_audio, B);
+        if (rc) return rc;
+        return ft8rx_fetch_results(h, B, records, counts, events, event_counts);
+    }
+    h->pnames.clear();
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    for (int i = 0; i < h->n_streams; i++) HIPCHK(h, hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
+    const int per = (B + nc - 1) / nc;
+    for (int k = 0; k < nc; k++) {
+        const int f0 = k * per, n = (f0 + per <= B) ? per : B - f0;
+        if (n <= 0) break;
+        hipStream_t s = h->sub[k % h->n_streams];
+        HIPCHK(h, hipMemcpyAsync(h->d_audio + (size_t)f0 * FT8RX_NSAMP, audio + (size_t)f0 * FT8RX_NSAMP,
+                                 sizeof(int16_t) * (size_t)n * FT8RX_NSAMP, hipMemcpyHostToDevice, s));
+        enqueue_chain(h, h->d_audio, f0, n, s, false);
+    }
+    for (int i = 0; i < h->n_streams; i++) {
+        HIPCHK(h, hipEventRecord(h->ev_join[i], h->sub[i]));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+    }
+    HIPCHK(h, hipGetLastError());
     return ft8rx_fetch_results(h, B, records, counts, events, event_counts);
 }
 
