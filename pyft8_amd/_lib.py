@@ -44,8 +44,9 @@ class Ft8rxError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = [SRC, os.path.join(HERE, "csrc", "ft8_dev.h"), os.path.join(HERE, "csrc", "ft8_tables.h"),
-            os.path.join(os.path.dirname(HERE), "include", "ft8rx.h")]
+    deps = [os.path.join(os.path.dirname(HERE), "include", "ft8rx.h")]
+    for d, _, files in os.walk(os.path.join(HERE, "csrc")):            # ft8rx.hip + ft8_dev.h, ft8_tables.h, kernels/*.hpp, host_messages.hpp
+        deps += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".hpp"))]
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(d) for d in deps):
         cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC]
         if verbose:

@@ -1,0 +1,191 @@
+// bp.hpp -- LDPC(174,91) belief propagation and the ladder select kernels (decoders.py:140-171, receiver.py:68-107)
+// Part of libft8rx.so; included by ft8rx.hip (single translation unit: the kernels share __constant__/__device__ tables).
+#ifndef FT8RX_BP_HPP
+#define FT8RX_BP_HPP
+
+// ------------------------------------------------------------------------------------ LDPC belief propagation
+// One wavefront per (candidate, AP) -- or per test vector.  Edge-parallel tanh / message update
+// (lane l owns edges l, l+64, ...), check-parallel products, variable-parallel accumulation in the
+// reference's np.add.at order; everything exchanged through LDS; parity via __ballot.
+// mode 0: pipeline ipass 0 (GOOD91 then BP(nc0_a, iters_a)), mode 1: pipeline fine stage
+// (GOOD91 for ap<2, BP(nc0_b, iters_b), save output llr), mode 2: raw vectors (tests).
+__global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ llr_in, ft8rx_record* __restrict__ rec,
+                                           const int32_t* __restrict__ ncand, Att* __restrict__ attG, Att* __restrict__ attB,
+                                           float* __restrict__ saved, ft8rx_event* ev, int32_t* evcount, ft8rx_config cfg,
+                                           int max_nc0, int max_iters) {
+    __shared__ float llr[176];
+    __shared__ float tl[528];
+    __shared__ float dl[528];
+    __shared__ float P[84];
+    const int lane = threadIdx.x;
+    int frame = 0, ci = 0, ap = 0; size_t vec;
+    if (mode == 2) vec = blockIdx.x;
+    else {
+        ap = blockIdx.x % 5; int c = blockIdx.x / 5; frame = c / MAXC; ci = c % MAXC;
+        if (ci >= ncand[frame]) return;
+        if (rec[(size_t)frame * MAXC + ci].status != FT8RX_ST_ACTIVE) return;
+        vec = (size_t)c;
+    }
+    for (int i = lane; i < 174; i += 64) llr[i] = ap_value(ap, i, llr_in[vec * 174 + i]);
+    __syncthreads();
+    Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
+    Att resG; memset(&resG, 0, sizeof(resG)); resG.n_its = -1;
+    const int ipG = (mode == 0) ? 0 : 2;
+    // ---- GOOD91: CRC on the hard decisions of llr[:91] (receiver.py:119-122)
+    bool doneG = false;
+    if (mode == 0 || (mode == 1 && ap < 2)) {
+        uint64_t b0 = __ballot(llr[lane] > 0.0f);
+        uint64_t b1 = __ballot(lane < 27 && llr[64 + (lane < 27 ? lane : 0)] > 0.0f);
+        uint64_t lo, hi;
+        int r = ft8_crc_check(b0, b1, &lo, &hi);
+        if (r) { if (lane == 0) log_event(ev, evcount, frame, ci, ipG, ap, 0, lo, hi, r == 2); }
+        if (r == 2) { resG.ok = 1; resG.lo = lo; resG.hi = hi; resG.n_its = 0; resG.method = FT8RX_M_GOOD91; doneG = true; }
+    }
+    // membership masks of this lane's two checks (c0 = lane, c1 = 64 + lane) over the 174 variables
+    const int c0 = lane, c1 = lane + 64;
+    const uint64_t cm00 = d_CHK_MASK[c0][0], cm01 = d_CHK_MASK[c0][1], cm02 = d_CHK_MASK[c0][2];
+    const uint64_t cm10 = d_CHK_MASK[c1][0], cm11 = d_CHK_MASK[c1][1], cm12 = d_CHK_MASK[c1][2];
+    // the edge tables are only needed once BP really iterates: most ipass-0 attempts stop at the initial
+    // unsatisfied-check test (decoders.py:159), so they are loaded lazily below
+    int ev_[9], ec_[9];
+    int n0 = 0, e00 = 0, n1 = 0, e01 = 0;
+    bool tables = false;
+    float mc[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) mc[i] = 0.0f;
+    bool run_bp = !(mode == 0 && doneG);       // ipass 0: the BP of this AP is only reached if GOOD91 failed
+    res.has_out = 1;
+    if (run_bp) for (int it = 0; it < max_iters; it++) {
+        // parity of every check from the hard decisions
+        const uint64_t h0 = __ballot(llr[lane] > 0.0f), h1 = __ballot(llr[64 + lane] > 0.0f),
+                       h2 = __ballot(lane < 46 && llr[128 + (lane < 46 ? lane : 0)] > 0.0f);
+        const int par0 = (__popcll(h0 & cm00) + __popcll(h1 & cm01) + __popcll(h2 & cm02)) & 1;
+        const int par1 = (__popcll(h0 & cm10) + __popcll(h1 & cm11) + __popcll(h2 & cm12)) & 1;
+        int ncheck = __popcll(__ballot(par0)) + __popcll(__ballot(par1));
+        if (it == 0) { res.nc0 = (uint8_t)ncheck; if (ncheck > max_nc0) { res.has_out = 0; break; } }
+        if (ncheck == 0) {
+            uint64_t b0 = h0;
+            uint64_t b1 = h1 & ((1ull << 27) - 1);
+            uint64_t lo, hi;
+            int r = ft8_crc_check(b0, b1, &lo, &hi);
+            if (r) {
+                int ipass = (mode == 0) ? 0 : ((ap < 2 && res.nc0 <= cfg.bp_nc0_a && it < cfg.bp_iters_a) ? 3 : 4);
+                if (lane == 0) log_event(ev, evcount, frame, ci, ipass, ap, it + 1, lo, hi, r == 2);
+            }
+            if (r == 2) { res.ok = 1; res.lo = lo; res.hi = hi; res.n_its = (int16_t)it; res.has_out = 0; }
+            break;      // success, or frozen state: the reference changes nothing from here on (decoders.py:161-164)
+        }
+        if (!tables) {                 // wave-uniform: first real iteration
+            tables = true;
+#pragma unroll
+            for (int i = 0; i < 9; i++) { int e = lane + 64 * i; ev_[i] = (e < 522) ? d_EDGE_V[e] : 0; ec_[i] = (e < 522) ? d_EDGE_C[e] : 0; }
+            n0 = d_CHK_N[c0]; e00 = d_CHK_E0[c0];
+            n1 = (c1 < 83) ? d_CHK_N[c1] : 0; e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
+        }
+        float tt[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int e = lane + 64 * i;
+            if (e < 522) { float v2c = llr[ev_[i]] - mc[i]; tt[i] = ft8_tanhf(-v2c); tl[e] = tt[i]; }
+        }
+        __syncthreads();
+        {
+            float Pp = tl[e00];
+#pragma unroll
+            for (int j = 1; j < 6; j++) Pp = Pp * tl[e00 + j];
+            if (n0 == 7) Pp = Pp * tl[e00 + 6];
+            P[c0] = Pp;
+            if (c1 < 83) {
+                float Q = tl[e01];
+#pragma unroll
+                for (int j = 1; j < 6; j++) Q = Q * tl[e01 + j];
+                if (n1 == 7) Q = Q * tl[e01 + 6];
+                P[c1] = Q;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int e = lane + 64 * i;
+            if (e < 522) {
+                const float Pc = P[ec_[i]], u = 1.18f * tt[i];
+                float nm = (Pc * tt[i]) / ((Pc - u) * (u + Pc));     // = e/((e-1.18)(1.18+e)), e = P/t, in one division
+                dl[e] = nm - mc[i];
+                mc[i] = nm;
+            }
+        }
+        __syncthreads();
+        for (int v = lane; v < 174; v += 64) {
+            float col = 0.0f;
+            col += dl[d_VAR_E[v][0]]; col += dl[d_VAR_E[v][1]]; col += dl[d_VAR_E[v][2]];
+            llr[v] += col;
+        }
+        __syncthreads();
+    }
+    else res.has_out = 0;
+    if (res.ok) res.method = (mode == 0) ? FT8RX_M_LDPC_A : FT8RX_M_LDPC_B;
+    if (mode == 2) {
+        if (lane == 0) attB[vec] = res;
+        if (res.has_out) for (int i = lane; i < 174; i += 64) saved[vec * 174 + i] = llr[i];
+        return;
+    }
+    if (mode == 0) { if (lane == 0) attB[vec * 5 + ap] = doneG ? resG : res; return; }
+    if (lane == 0) { attB[vec * 5 + ap] = res; if (ap < 2) attG[vec * 2 + ap] = resG; }
+    if (res.has_out) for (int i = lane; i < 174; i += 64) saved[(vec * 5 + ap) * 174 + i] = llr[i];
+}
+
+// first success in ladder order after ipass 0 (receiver.py:72-78)
+__global__ void k_select0(ft8rx_record* rec, const int32_t* ncand, const Att* att0, int B) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B * MAXC) return;
+    int frame = c / MAXC, ci = c % MAXC;
+    if (ci >= ncand[frame]) return;
+    ft8rx_record& r = rec[c];
+    if (r.status != FT8RX_ST_ACTIVE) return;
+    for (int ap = 0; ap < 5; ap++) {
+        const Att& a = att0[(size_t)c * 5 + ap];
+        if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 0; r.ap = (uint8_t)ap; r.method = a.method; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+}
+
+// first success among ipass 2 (GOOD91 ap0,1), 3 (BP_A ap0,1 derived from the BP_B run), 4 (BP_B ap0..4)
+__global__ void k_select1(ft8rx_record* rec, const int32_t* ncand, const Att* attG, const Att* attB, int B, ft8rx_config cfg) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B * MAXC) return;
+    int frame = c / MAXC, ci = c % MAXC;
+    if (ci >= ncand[frame]) return;
+    ft8rx_record& r = rec[c];
+    if (r.status != FT8RX_ST_ACTIVE) return;
+    for (int ap = 0; ap < 2; ap++) {
+        const Att& a = attG[(size_t)c * 2 + ap];
+        if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 2; r.ap = (uint8_t)ap; r.method = FT8RX_M_GOOD91; r.n_its = 0; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+    for (int ap = 0; ap < 2; ap++) {
+        const Att& a = attB[(size_t)c * 5 + ap];
+        if (a.ok && a.nc0 <= cfg.bp_nc0_a && a.n_its < cfg.bp_iters_a) {
+            r.status = FT8RX_ST_DECODED; r.ipass = 3; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_A; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+    for (int ap = 0; ap < 5; ap++) {
+        const Att& a = attB[(size_t)c * 5 + ap];
+        if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 4; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_B; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+}
+
+// ipass 5 (OSD on llr0+AP, slots 0..4) then ipass 6 (OSD on the saved BP outputs, slots 5..9)
+__global__ void k_select2(ft8rx_record* rec, const int32_t* ncand, const Att* attO, int B) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B * MAXC) return;
+    int frame = c / MAXC, ci = c % MAXC;
+    if (ci >= ncand[frame]) return;
+    ft8rx_record& r = rec[c];
+    if (r.status != FT8RX_ST_ACTIVE) return;
+    for (int s = 0; s < 10; s++) {
+        const Att& a = attO[(size_t)c * 10 + s];
+        if (a.ok) {
+            r.status = FT8RX_ST_DECODED; r.ipass = (s < 5) ? 5 : 6; r.ap = (uint8_t)(s % 5);
+            r.method = (s < 5) ? FT8RX_M_OSD : FT8RX_M_LDPC_B_OSD; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    }
+    r.status = FT8RX_ST_EXHAUSTED;
+}
+
+#endif

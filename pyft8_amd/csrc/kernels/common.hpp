@@ -1,0 +1,68 @@
+// common.hpp -- device tables, attempt records, event log shared by all kernels
+// Part of libft8rx.so; included by ft8rx.hip (single translation unit: the kernels share __constant__/__device__ tables).
+#ifndef FT8RX_COMMON_HPP
+#define FT8RX_COMMON_HPP
+
+// ------------------------------------------------------------------------------------ device tables
+struct Tables {
+    const float* win;        // [3840] Hann (np.hanning) as f32
+    const cpx* W1920;        // twiddles
+    const cpx* WR3840;       // [976] real-split twiddles e^{-2 pi i k/3840}
+    const cpx* W3200;
+    const cpx* W96000;
+    const cpx* W300;
+    const cpx* W320;
+    const cpx* WR192k;       // [49152]
+    const cpx* W32;
+    const double* taper;     // [100]
+};
+
+__device__ __constant__ int d_COSTAS[7] = {3, 1, 4, 0, 6, 5, 2};
+__device__ __constant__ uint8_t d_PAYSYM[58] = {7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,
+    43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71};
+// AP masks (reference receiver.py:21-27), copied verbatim as data
+__device__ __constant__ int8_t d_AP_CQ[29]   = {0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,1,0,0};
+__device__ __constant__ int8_t d_AP_END[3][19] = {{0,1, 1,1,1,1,1, 0,0,1,1,1, 0,1,0,1,0, 0,1},
+                                                  {0,1, 1,1,1,1,1, 0,1,0,0,1, 0,1,0,0,0, 0,1},
+                                                  {0,1, 1,1,1,1,1, 0,1,0,0,1, 0,0,1,0,0, 0,1}};
+// LDPC tables in device memory (copies of ft8_tables.h)
+__device__ uint8_t  d_CHK_N[83];
+__device__ int16_t  d_CHK_V[83][7];
+__device__ uint16_t d_CHK_E0[83];
+__device__ uint8_t  d_EDGE_V[522];
+__device__ uint8_t  d_EDGE_C[522];
+__device__ uint16_t d_VAR_E[174][3];
+__device__ uint64_t d_G0[91][3];
+__device__ uint64_t d_CHK_MASK[128][3];   // membership mask of check c over the 174 variables (rows >= 83 are zero)
+
+struct Att {               // one decode attempt's outcome
+    uint64_t lo, hi;
+    int16_t n_its;
+    uint8_t ok;            // 1 = accepted
+    uint8_t method;        // FT8RX_M_*
+    uint8_t nc0;           // initial unsatisfied-check count (BP)
+    uint8_t has_out;       // BP left a 174-vector behind (the reference's third return value)
+    uint8_t pad[2];
+};
+
+#define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */
+
+// grid row accessor with the reference's modulo-750 wrap (receiver.py:240,347,360)
+FT8_DEV float grid_at(const float* __restrict__ g, int row, int col) {
+    row %= 750; if (row < 0) row += 750;
+    if (row >= 1 && row <= 375) return g[row * FT8RX_GRID_COLS + col];
+    return 1.0f;
+}
+
+FT8_DEV void log_event(ft8rx_event* ev, int32_t* evcount, int frame, int cand, int ipass, int slot, int seq,
+                       uint64_t lo, uint64_t hi, int valid) {
+    if (!ev) return;
+    int idx = atomicAdd(&evcount[frame], 1);
+    if (idx < FT8RX_EVENT_CAP) {
+        ft8rx_event e; e.msg_lo = lo; e.msg_hi = hi; e.cand = (uint16_t)cand; e.ipass = (uint8_t)ipass;
+        e.slot = (uint8_t)slot; e.seq = (uint16_t)seq; e.valid = (uint16_t)valid;
+        ev[(size_t)frame * FT8RX_EVENT_CAP + idx] = e;
+    }
+}
+
+#endif

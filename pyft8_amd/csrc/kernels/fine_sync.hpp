@@ -1,0 +1,302 @@
+// fine_sync.hpp -- fine time/frequency sync (receiver.py:140-206)
+// Part of libft8rx.so; included by ft8rx.hip (single translation unit: the kernels share __constant__/__device__ tables).
+#ifndef FT8RX_FINE_SYNC_HPP
+#define FT8RX_FINE_SYNC_HPP
+
+// ------------------------------------------------------------------------------------ fine time/frequency sync (receiver.py:140-206)
+// One 128-thread block per candidate.  The 3200-point inverse FFT (conj o forward o conj) runs in place in
+// one LDS buffer as three register-fused stages [8] | [4,4] | [5,5]; stage 1 reads the tapered spectrum
+// slice straight from global memory and knows that only 1000 of the 3200 bins are non-zero.  The 1/3200
+// scale and the output conjugation are applied where the series is consumed.
+#ifndef FINE_NT
+#define FINE_NT 128
+#endif
+#ifndef FINE_WV
+#define FINE_WV 2
+#endif
+#define FINE_INV 0.0003125f
+
+// conj(taper * spec) for bin k of the rolled 3200-bin slice (receiver.py:180-185); k < 850 or k >= 3050.
+// `sl` is the candidate's spectrum window staged in LDS: sl[i] = spec[fb0 - 182 + i], i < 1064 (covers every ftweak);
+// off = ftweak + 182.
+#define FINE_SLICE 1064
+FT8_DEV cpx fine_input(const cpx* sl, int off, int k, const double* __restrict__ taper) {
+    cpx v; int ti;
+    if (k < 850) { v = sl[off + k]; ti = (k >= 750) ? k - 750 : -1; }
+    else { const int j = k - 3050; v = sl[off - 150 + j]; ti = (j < 100) ? j : -1; }
+    if (ti >= 0) { const double t = taper[ti]; v.x = (float)((double)v.x * t); v.y = (float)((double)v.y * t); }
+    v.y = -v.y;
+    return v;
+}
+
+// forward FFT of the conjugated slice into z (unscaled, unconjugated), natural Stockham layout, in place.
+// (Measured alternatives, profiles/r01_notes.md: 256-thread blocks 7.96 ms, bank-conflict-free padded/transposed
+// inter-stage layouts 6.92 ms, this version 6.36 ms per 256 frames: the kernel is latency/barrier bound.)
+
+// The stages are written for any FINE_NT in {64, 128}: a thread owns ceil(groups / FINE_NT) groups of each stage,
+// loads all of them, passes the barrier, then computes and stores them (in place).  With FINE_NT = 64 the block is a
+// single wavefront, the "barriers" are free and every lane carries 3-4 independent groups (ILP instead of TLP).
+FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W,
+                         const double* __restrict__ taper, int tid) {
+    // pass [8]: n = 3200, s = 1, m = 400: butterfly p reads bins p + 400 j; only j = 0, 1, (2 if p < 50), (7 if p >= 250)
+    // are non-zero.  All global loads of the thread are issued before the first butterfly.
+    constexpr int R = (400 + FINE_NT - 1) / FINE_NT;
+    const cpx zero = make_float2(0.0f, 0.0f);
+    cpx in0[R], in1[R], in7[R], in2;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int p = tid + FINE_NT * i;
+        const bool on = p < 400;
+        in0[i] = on ? fine_input(S, fb, p, taper) : zero;
+        in1[i] = on ? fine_input(S, fb, p + 400, taper) : zero;
+        in7[i] = (on && p >= 250) ? fine_input(S, fb, p + 2800, taper) : zero;
+    }
+    in2 = (tid < 50) ? fine_input(S, fb, tid + 800, taper) : zero;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int p = tid + FINE_NT * i;
+        if (p < 400) {
+            cpx a[8];
+            a[0] = in0[i]; a[1] = in1[i]; a[2] = (i == 0) ? in2 : zero;
+            a[3] = zero; a[4] = zero; a[5] = zero; a[6] = zero; a[7] = in7[i];
+            dft<8>(a);
+            z[8 * p] = a[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) { cpx v = a[j]; if (p != 0) v = cmul(v, W[j * p]); z[8 * p + j] = v; }
+        }
+    }
+    __syncthreads();
+}
+FT8_DEV void fine_stage2(cpx* z, const cpx* w400, int tid) {
+    typedef Fused2<3200, 400, 8, 4, 4> F;                         // passes [4,4]: n = 400, s = 8; 200 groups
+    constexpr int R = (F::groups + FINE_NT - 1) / FINE_NT;
+    cpx a[R][4][4];
+    // group g = (pp = g / 8, q = g % 8): in  q + 8(pp + 25 j' + 100 j),  out  q + 8 j + 32 (4 pp + j')
+#pragma unroll
+    for (int r = 0; r < R; r++) { const int g = tid + FINE_NT * r; if (g < F::groups) F::load_affine<200, 800>(z, g, a[r]); }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int g = tid + FINE_NT * r;
+        if (g < F::groups) {
+            // same arithmetic as F::compute_pp; every twiddle index of this stage is a multiple of 8, so the factors come
+            // from the 400-entry LDS copy w400[t] = W3200[8 t]:  pass A  W3200[j p 8] = w400[j p],  pass B  W3200[j' pp 32] = w400[4 j' pp]
+            const int pp = g >> 3;
+#pragma unroll
+            for (int jp = 0; jp < 4; jp++) {
+                dft<4>(a[r][jp]);
+                const int pq = pp + 25 * jp;
+                if (pq != 0) {
+#pragma unroll
+                    for (int j = 1; j < 4; j++) a[r][jp][j] = cmul(a[r][jp][j], w400[j * pq]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cpx b[4];
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) b[jp] = a[r][jp][j];
+                dft<4>(b);
+                if (pp != 0) {
+#pragma unroll
+                    for (int jp = 1; jp < 4; jp++) b[jp] = cmul(b[jp], w400[4 * jp * pp]);
+                }
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) a[r][jp][j] = b[jp];
+            }
+            F::store_affine<32, 8>(z, (g & 7) + 128 * (g >> 3), a[r]);
+        }
+    }
+    __syncthreads();
+}
+// Only output samples in [lo, hi) are needed (the scoring IFFTs read one Costas block = ~230 samples): a final
+// radix-5 butterfly (q, j) produces samples q + 128 j + 640 j', at most one of which can fall in a window
+// shorter than 640, so butterflies with no sample in the window are skipped.  Needed outputs are bit-identical.
+FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int hi) {
+    typedef Fused2<3200, 25, 128, 5, 5> F;                        // passes [5,5]: n = 25, s = 128; 128 groups
+    constexpr int R = F::groups / FINE_NT;
+    cpx a[R][5][5];
+    // group q: in  q + 128 (j' + 5 j),  out  q + 128 j + 640 j'
+#pragma unroll
+    for (int r = 0; r < R; r++) F::load_affine<128, 640>(z, tid + FINE_NT * r, a[r]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int q = tid + FINE_NT * r;
+        F::compute_passA(0, a[r], W);
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int rr = q + 128 * j;
+            const int first = (lo <= rr) ? rr : rr + 640 * ((lo - rr + 639) / 640);   // smallest rr + 640 j' >= lo
+            if (first < hi && first < 3200) {
+                cpx b[5];
+#pragma unroll
+                for (int jp = 0; jp < 5; jp++) b[jp] = a[r][jp][j];
+                dft<5>(b);                                         // last pass: no twiddles
+#pragma unroll
+                for (int jp = 0; jp < 5; jp++) z[rr + 640 * jp] = b[jp];
+            }
+        }
+    }
+    __syncthreads();
+}
+FT8_DEV void fine_fft(const cpx* S, int fb, cpx* z, const cpx* w400, const Tables& T, int tid, int lo, int hi) {
+    fine_stage1(S, fb, z, T.W3200, T.taper, tid);
+    fine_stage2(z, w400, tid);
+    fine_stage3(z, T.W3200, tid, lo, hi);
+}
+
+// |32-pt DFT| tones 0..7 of the symbol starting at sample i0, computed by the 4 lanes of a quad
+FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, int lane, const cpx* w32, float* mag) {
+    if (i0 < 0) i0 = 0;
+    if (i0 > 3168) i0 = 3168;
+    cpx x[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) { cpx v = z[i0 + 4 * n1 + n2]; x[n1] = make_float2(v.x * FINE_INV, -(v.y * FINE_INV)); }
+    sym32_quad(x, n2, lane, w32, mag);
+}
+
+__global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
+                                                  const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
+                                                  const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
+                                                  float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
+    __shared__ cpx z[3200];
+    __shared__ cpx slice[FINE_SLICE];  // the candidate's 1064 spectrum bins, read by the first stage of all ten IFFTs
+    __shared__ __attribute__((aligned(8))) float mg[640];   // scoring (on, off) sums as fp64, later the [79][8] grid
+    __shared__ cpx w400[400];          // W3200[8 t]: every twiddle of the [4,4] stage
+    float* p = reinterpret_cast<float*>(slice);      // [464] the slice is dead once the last IFFT has run: reuse it
+    float* llr = p + 464;                            // [176]
+    float* sq = llr + 176;                           // [176]
+    __shared__ float sc[16];
+    __shared__ int ish[4];
+    __shared__ cpx w32[32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    int frame, ci = 0, f0, h0;
+    if (trip) { frame = trip[3 * blockIdx.x]; f0 = trip[3 * blockIdx.x + 1]; h0 = trip[3 * blockIdx.x + 2]; }
+    else {
+        frame = blockIdx.x / MAXC; ci = blockIdx.x % MAXC;
+        if (ci >= ncand[frame]) return;
+        const ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
+        if (r.status != FT8RX_ST_ACTIVE) return;
+        f0 = r.f0_idx; h0 = r.h0_idx;
+    }
+    if (tid < 32) w32[tid] = T.W32[tid];
+    const int fb0 = 50 * f0;                                      // int(0.5 + fHz*16)
+    {
+        const cpx* __restrict__ Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
+        for (int i = tid; i < FINE_SLICE; i += FINE_NT) slice[i] = Sg[i];
+        for (int i = tid; i < 400; i += FINE_NT) w400[i] = T.W3200[8 * i];
+        __syncthreads();
+    }
+    const cpx* S = slice;
+    const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
+    // Score of one Costas block (contract): per symbol a the quad leader forms on_a = |tone costas[a]| and off_a = sum of
+    // the other six tones (b ascending) in fp64 from its registers; after ONE barrier every thread combines
+    // S1 = sum_a on_a, S2 = sum_a off_a (a ascending) and score = (float)(S1 + w6 S2) -- no serial chain, no broadcast.
+    double* dsum = reinterpret_cast<double*>(mg);              // [8][7][2] (on, off); mg is free until the final grid
+    // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
+    fine_fft(S, 182, z, w400, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43);   // the 8 time tweaks of the middle Costas block
+#pragma unroll 1
+    for (int r = 0; r < (224 + FINE_NT - 1) / FINE_NT; r++) {
+        const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
+        const bool valid = qd < 56;
+        const int ti = valid ? qd / 7 : 0, a = valid ? qd - 7 * ti : 0;
+        float mag[8];
+        fine_sym_quad(z, tb0 - 8 + 2 * ti + 32 * (36 + a), n2, lane, w32, mag);
+        if (valid && n2 == 0) {
+            const int c = d_COSTAS[a];
+            double off = 0.0, on = 0.0;
+#pragma unroll
+            for (int b = 0; b < 7; b++) { if (b == c) on = (double)mag[b]; else off += (double)mag[b]; }
+            dsum[(ti * 7 + a) * 2] = on; dsum[(ti * 7 + a) * 2 + 1] = off;
+        }
+    }
+    __syncthreads();
+    int tt = -8; float score_f0 = 0.0f;
+    for (int ti = 0; ti < 8; ti++) {                           // every thread: same values, same result
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 7; a++) { s1 += dsum[(ti * 7 + a) * 2]; s2 += dsum[(ti * 7 + a) * 2 + 1]; }
+        const float sct = (float)(s1 + W6 * s2);
+        if (ti == 0 || sct > score_f0) { score_f0 = sct; tt = -8 + 2 * ti; }     // first maximum (np.argmax)
+    }
+    // --- frequency tweaks: range(-32,33,8)
+    float best = 0.0f; int ft = 0;
+#pragma unroll 1
+    for (int i = 0; i < 9; i++) {
+        const int fcur = -32 + 8 * i;
+        float s;
+        if (fcur == 0) s = score_f0;             // same series, same offset: identical value
+        else {
+            fine_fft(S, 182 + fcur, z, w400, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43);
+            if (tid < 64) {                       // 7 symbols x 4 lanes on wavefront 0
+                const int qd = tid >> 2, n2 = tid & 3;
+                const bool valid = qd < 7;
+                float mag[8];
+                fine_sym_quad(z, tb0 + tt + 32 * (36 + (valid ? qd : 0)), n2, lane, w32, mag);
+                if (valid && n2 == 0) {
+                    const int c = d_COSTAS[qd];
+                    double off = 0.0, on = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 7; b++) { if (b == c) on = (double)mag[b]; else off += (double)mag[b]; }
+                    dsum[qd * 2] = on; dsum[qd * 2 + 1] = off;
+                }
+            }
+            __syncthreads();
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 7; a++) { s1 += dsum[a * 2]; s2 += dsum[a * 2 + 1]; }
+            s = (float)(s1 + W6 * s2);
+        }
+        if (i == 0 || s > best) { best = s; ft = fcur; }
+    }
+    fine_fft(S, 182 + ft, z, w400, T, tid, 0, 3200);   // full series for the 79 x 8 grid
+#pragma unroll 1
+    for (int r = 0; r < (316 + FINE_NT - 1) / FINE_NT; r++) {                 // full 79 x 8 grid
+        const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;
+        const bool valid = sy < 79;
+        float mag[8];
+        fine_sym_quad(z, tb0 + tt + 32 * (valid ? sy : 0), n2, lane, w32, mag);
+        if (valid && n2 == 0) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) mg[sy * 8 + b] = mag[b];
+        }
+    }
+    __syncthreads();
+    // --- Costas gate (receiver.py:164-167)
+    bool match = false;
+    if (tid < 21) {
+        int blk = tid / 7, a = tid - blk * 7;
+        const float* q = mg + 8 * (36 * blk + a);
+        int am = 0; for (int t = 1; t < 8; t++) if (q[t] > q[am]) am = t;
+        match = (am == d_COSTAS[a]);
+    }
+    if (tid < 64) { int nm = __popcll(__ballot(match)); if (tid == 0) ish[1] = nm; }
+    __syncthreads();
+    const int nsync = ish[1];
+    if (trip && t_sgrid) for (int i = tid; i < 632; i += FINE_NT) t_sgrid[(size_t)blockIdx.x * 632 + i] = mg[i];
+    int ret = 1; float sd = 0.0f; int snr = 0;
+    if (nsync <= 6) ret = 0;           // block-uniform
+    else {
+        for (int i = tid; i < 464; i += FINE_NT) p[i] = 20.0f * ft8_log10f(mg[8 * (int)d_PAYSYM[i >> 3] + (i & 7)]);   // receiver.py:170
+        __syncthreads();
+        llr_from_p(p, llr, sq, tid, tid < 64, &sd, &snr);
+        if (tid == 0) { sc[10] = sd; ish[2] = snr; }
+        __syncthreads();
+        sd = sc[10]; snr = ish[2];
+        if (sd <= cfg.llr_sd_min) ret = -1;
+        float* out = llr0 + (size_t)blockIdx.x * 174;
+        for (int i = tid; i < 174; i += FINE_NT) out[i] = llr[i];
+    }
+    if (tid == 0) {
+        if (trip) { int32_t* o = t_out + 5 * (size_t)blockIdx.x; o[0] = ret; o[1] = tt; o[2] = ft; o[3] = nsync; o[4] = snr; t_sd[blockIdx.x] = sd; }
+        else {
+            ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
+            r.ttweak = (int8_t)tt; r.ftweak = (int8_t)ft; r.nsync = (uint8_t)nsync;
+            if (ret == 0) r.status = FT8RX_ST_STOP_COSTAS;
+            else { r.fine_sd = sd; r.snr_fine = (int8_t)snr; if (ret < 0) r.status = FT8RX_ST_STOP_FINE_SD; }
+        }
+    }
+}
+
+#endif

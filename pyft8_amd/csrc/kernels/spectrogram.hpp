@@ -1,0 +1,126 @@
+// spectrogram.hpp -- K1: 375-hop dB spectrogram (receiver.py:288-306)
+// Part of libft8rx.so; included by ft8rx.hip (single translation unit: the kernels share __constant__/__device__ tables).
+#ifndef FT8RX_SPECTROGRAM_HPP
+#define FT8RX_SPECTROGRAM_HPP
+
+// ------------------------------------------------------------------------------------ K1 spectrogram
+// one hop: window samples a[base .. base+3840) (zeros before the frame start) -> 976 dB values.
+// 128 threads; 1920-point complex FFT (plan [8,4,4,5,3]) in place in one LDS image as three register-fused stages:
+//   [8]    240 butterflies straight from global memory (int16 -> f32, Hann window fused in),
+//   [4,4]  120 groups of 16 (one per thread), twiddles from the LDS table w240[t] = W1920[8 t],
+//   [5,3]  128 groups of 15 (one per thread), compile-time twiddles,
+// then the real-FFT split and 20 log10|.|.
+#define SPEC_NT 128
+FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __restrict__ out, const Tables& T,
+                             cpx* z, cpx* w240, int tid) {
+    const cpx* __restrict__ W = T.W1920;
+    for (int i = tid; i < 240; i += SPEC_NT) w240[i] = W[8 * i];
+    {   // pass [8]: n = 1920, s = 1, m = 240: butterfly p reads samples m = p + 240 j
+        cpx v[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int p = tid + SPEC_NT * i;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int m = p + 240 * j, i0 = base + 2 * m;
+                float x0 = 0.0f, x1 = 0.0f;
+                if (p < 240 && i0 >= 0) {
+                    const short2 sm = *reinterpret_cast<const short2*>(a + i0);
+                    const float2 w = *reinterpret_cast<const float2*>(T.win + 2 * m);
+                    x0 = (float)sm.x * w.x; x1 = (float)sm.y * w.y;
+                }
+                v[i][j] = make_float2(x0, x1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int p = tid + SPEC_NT * i;
+            if (p < 240) {
+                dft<8>(v[i]);
+                z[8 * p] = v[i][0];
+#pragma unroll
+                for (int j = 1; j < 8; j++) { cpx t = v[i][j]; if (p != 0) t = cmul(t, W[j * p]); z[8 * p + j] = t; }
+            }
+        }
+    }
+    __syncthreads();
+    {   // passes [4,4]: n = 240, s = 8; group g = (pp = g / 8, q = g % 8): in q + 8(pp + 15 j' + 60 j), out q + 8 j + 32(4 pp + j')
+        typedef Fused2<1920, 240, 8, 4, 4> F;
+        cpx v[4][4];
+        const bool on = tid < F::groups;
+        if (on) F::load_affine<120, 480>(z, tid, v);
+        __syncthreads();
+        if (on) {
+            const int pp = tid >> 3;
+#pragma unroll
+            for (int jp = 0; jp < 4; jp++) {
+                dft<4>(v[jp]);
+                const int pq = pp + 15 * jp;
+                if (pq != 0) {
+#pragma unroll
+                    for (int j = 1; j < 4; j++) v[jp][j] = cmul(v[jp][j], w240[j * pq]);          // W1920[j p 8]
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cpx u[4];
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) u[jp] = v[jp][j];
+                dft<4>(u);
+                if (pp != 0) {
+#pragma unroll
+                    for (int jp = 1; jp < 4; jp++) u[jp] = cmul(u[jp], w240[4 * jp * pp]);        // W1920[j' pp 32]
+                }
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) v[jp][j] = u[jp];
+            }
+            F::store_affine<32, 8>(z, (tid & 7) + 128 * (tid >> 3), v);
+        }
+        __syncthreads();
+    }
+    {   // passes [5,3]: n = 15, s = 128; group q: in q + 128 (j' + 3 j), out q + 128 j + 640 j'
+        typedef Fused2<1920, 15, 128, 5, 3> F;
+        cpx v[3][5];
+        F::load_affine<128, 384>(z, tid, v);
+        __syncthreads();
+        F::compute_pp(0, v, W);
+        F::store_affine<640, 128>(z, tid, v);
+        __syncthreads();
+    }
+    for (int k = tid; k < FT8RX_GRID_COLS; k += SPEC_NT) {
+        cpx p = z[k], q = z[(1920 - k) % 1920];
+        float er = 0.5f * (p.x + q.x), ei = 0.5f * (p.y - q.y);
+        float orr = 0.5f * (p.y + q.y), oi = 0.5f * (q.x - p.x);
+        cpx w = T.WR3840[k];
+        float xr = er + (w.x * orr - w.y * oi);
+        float xi = ei + (w.x * oi + w.y * orr);
+        float mag = sqrtf(xr * xr + xi * xi);
+        out[k] = 20.0f * ft8_log10f(mag + 1e-12f);
+    }
+}
+
+__global__ __launch_bounds__(SPEC_NT) void k_spectrogram(const int16_t* __restrict__ audio, float* __restrict__ grid, Tables T) {
+    __shared__ cpx z[1920];
+    __shared__ cpx w240[240];
+    // XCD-aware hop mapping: workgroup id -> XCD is id % 8 and gridDim.x = 376 = 8 * 47, so the 47 workgroups of a
+    // frame that land on one XCD take 47 consecutive hops: each XCD's L2 then sees one eighth of the frame's audio
+    // (8x overlapping windows) instead of all of it.
+    const int hop = (blockIdx.x & 7) * 47 + (blockIdx.x >> 3) + 1, f = blockIdx.y, tid = threadIdx.x;
+    if (hop > 375) return;
+    spectrogram_hop(audio + (size_t)f * FT8RX_NSAMP, 480 * hop - 3840,
+                    grid + ((size_t)f * FT8RX_GRID_ROWS + hop) * FT8RX_GRID_COLS, T, z, w240, tid);
+}
+
+// streaming mode: one hop of the live receiver (AudioIn.get_hop_spectrum, receiver.py:288-293)
+__global__ __launch_bounds__(SPEC_NT) void k_hop_spectrum(const int16_t* __restrict__ win3840, float* __restrict__ row, Tables T) {
+    __shared__ cpx z[1920];
+    __shared__ cpx w240[240];
+    spectrogram_hop(win3840, 0, row, T, z, w240, threadIdx.x);
+}
+
+__global__ void k_fill_row0(float* grid, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * FT8RX_GRID_COLS) grid[(size_t)(i / FT8RX_GRID_COLS) * FT8RX_GRID_ROWS * FT8RX_GRID_COLS + (i % FT8RX_GRID_COLS)] = 1.0f;
+}
+
+#endif
