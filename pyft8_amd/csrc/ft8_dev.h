@@ -37,8 +37,7 @@ FT8_DEV float ft8_log10f(float x) {
 
 // single-branch clamped rational (no divergence inside a wavefront): x P(x^2) / Q(x^2), one IEEE division
 FT8_DEV float ft8_tanhf(float x) {
-    if (x != x) return x;
-    float xc = x;
+    float xc = x;                    // NaN fails both clamps and propagates through P / Q (the oracle returns x itself: same NaN-ness)
     if (xc > 7.90531111f) xc = 7.90531111f;
     if (xc < -7.90531111f) xc = -7.90531111f;
     const float x2 = xc * xc;

@@ -14,8 +14,8 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
                                            float* __restrict__ saved, ft8rx_event* ev, int32_t* evcount, ft8rx_config cfg,
                                            int max_nc0, int max_iters) {
     __shared__ float llr[176];
-    __shared__ float tl[528];
-    __shared__ float dl[528];
+    __shared__ float tl[576];        // 9 x 64 edge slots: slots >= 522 are dummy edges (variable 174, check 83) so that the
+    __shared__ float dl[576];        // per-edge code below is straight-line for all nine slots of a lane
     __shared__ float P[84];
     const int lane = threadIdx.x;
     int frame = 0, ci = 0, ap = 0; size_t vec;
@@ -27,6 +27,8 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
         vec = (size_t)c;
     }
     for (int i = lane; i < 174; i += 64) llr[i] = ap_value(ap, i, llr_in[vec * 174 + i]);
+    if (lane < 2) llr[174 + lane] = 0.0f;
+    if (lane == 0) P[83] = 1.0f;
     __syncthreads();
     Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
     Att resG; memset(&resG, 0, sizeof(resG)); resG.n_its = -1;
@@ -78,15 +80,17 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
         if (!tables) {                 // wave-uniform: first real iteration
             tables = true;
 #pragma unroll
-            for (int i = 0; i < 9; i++) { int e = lane + 64 * i; ev_[i] = (e < 522) ? d_EDGE_V[e] : 0; ec_[i] = (e < 522) ? d_EDGE_C[e] : 0; }
+            for (int i = 0; i < 9; i++) { int e = lane + 64 * i; ev_[i] = (e < 522) ? d_EDGE_V[e] : 174; ec_[i] = (e < 522) ? d_EDGE_C[e] : 83; }
             n0 = d_CHK_N[c0]; e00 = d_CHK_E0[c0];
             n1 = (c1 < 83) ? d_CHK_N[c1] : 0; e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
         }
         float tt[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) {
-            int e = lane + 64 * i;
-            if (e < 522) { float v2c = llr[ev_[i]] - mc[i]; tt[i] = ft8_tanhf(-v2c); tl[e] = tt[i]; }
+            const int e = lane + 64 * i;
+            const float v2c = llr[ev_[i]] - mc[i];
+            tt[i] = ft8_tanhf(-v2c);
+            tl[e] = tt[i];
         }
         __syncthreads();
         {
@@ -106,13 +110,11 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 9; i++) {
-            int e = lane + 64 * i;
-            if (e < 522) {
-                const float Pc = P[ec_[i]], u = 1.18f * tt[i];
-                float nm = (Pc * tt[i]) / ((Pc - u) * (u + Pc));     // = e/((e-1.18)(1.18+e)), e = P/t, in one division
-                dl[e] = nm - mc[i];
-                mc[i] = nm;
-            }
+            const int e = lane + 64 * i;
+            const float Pc = P[ec_[i]], u = 1.18f * tt[i];
+            const float nm = (Pc * tt[i]) / ((Pc - u) * (u + Pc));     // = e/((e-1.18)(1.18+e)), e = P/t, in one division
+            dl[e] = nm - mc[i];
+            mc[i] = nm;
         }
         __syncthreads();
         for (int v = lane; v < 174; v += 64) {
