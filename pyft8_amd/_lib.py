@@ -126,7 +126,10 @@ class Handle:
         if audio.ndim == 1:
             audio = audio[None]
         B = audio.shape[0]
-        assert audio.shape[1] == NSAMP
+        if audio.ndim != 2 or audio.shape[1] != NSAMP:
+            raise Ft8rxError(f"audio must be int16 [n_frames, {NSAMP}] (15 s at 12 kHz); got shape {audio.shape} -- see receiver.frames_from_ragged")
+        if B < 1:
+            raise Ft8rxError("empty batch")
         return self._run(audio, B)
 
     def _alloc_out(self, B):
@@ -178,7 +181,8 @@ class Handle:
 
     def hop_spectrum(self, window3840):
         w = np.ascontiguousarray(window3840, np.int16)
-        assert w.shape == (3840,)
+        if w.shape != (3840,):
+            raise Ft8rxError(f"hop_spectrum needs the last 3840 samples, got shape {w.shape}")
         row = np.empty(GRID_COLS, np.float32)
         self._chk(lib().ft8rx_hop_spectrum(self._h, _ptr(w, C.c_int16), _ptr(row, C.c_float)), "ft8rx_hop_spectrum")
         return row
@@ -301,7 +305,8 @@ def package_batch(rec, cnt, ev, evc, max_msgs=128, n_threads=None):
     cnt = np.ascontiguousarray(cnt, np.int32)
     evc = np.ascontiguousarray(evc, np.int32)
     B, mc = rec.shape
-    assert ev.shape == (B, EVENT_CAP) and rec.dtype == RECORD_DTYPE and ev.dtype == EVENT_DTYPE
+    if ev.shape != (B, EVENT_CAP) or rec.dtype != RECORD_DTYPE or ev.dtype != EVENT_DTYPE:
+        raise Ft8rxError("package_batch: records/events are not the arrays returned by decode_batch/fetch")
     out = np.zeros((B, max_msgs), MESSAGE_DTYPE)
     oc = np.zeros(B, np.int32)
     if n_threads is None:

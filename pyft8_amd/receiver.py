@@ -36,6 +36,29 @@ def config_from_kwargs(sync_score_min=85, max_cands=200, search_freq_range=(100,
     return cfg
 
 
+def frames_from_ragged(frames):
+    """Ragged input -> int16 [B, 180000].  `frames` is an array [B, n] / [n] or a list of 1-D arrays, each at most 15 s long;
+    shorter frames are padded with digital silence at the end (the reference's ring buffer is zero before the first hop,
+    receiver.py:248; in frame-complete semantics the frame starts at cycle time 0, so the missing tail is what is silent).
+    Longer input is an error: cut a recording into cycles yourself -- the cycle boundary is yours to choose."""
+    if isinstance(frames, np.ndarray) and frames.ndim == 1:
+        frames = [frames]
+    out = np.zeros((len(frames), _lib.NSAMP), np.int16)
+    for i, f in enumerate(frames):
+        f = np.asarray(f)
+        if f.ndim != 1:
+            raise _lib.Ft8rxError(f"frame {i}: expected a 1-D array of int16 samples, got shape {f.shape}")
+        if f.dtype != np.int16:
+            if not np.issubdtype(f.dtype, np.integer):
+                raise _lib.Ft8rxError(f"frame {i}: samples must be integers in int16 range (got {f.dtype})")
+            if len(f) and (f.min() < -32768 or f.max() > 32767):
+                raise _lib.Ft8rxError(f"frame {i}: samples outside the int16 range")
+        if len(f) > _lib.NSAMP:
+            raise _lib.Ft8rxError(f"frame {i}: {len(f)} samples > {_lib.NSAMP} (15 s at 12 kHz)")
+        out[i, :len(f)] = f
+    return out
+
+
 class Candidate:
     """Read-only view of one sync candidate (reference receiver.py:29-50 `Candidate.origin`)."""
 
@@ -44,6 +67,15 @@ class Candidate:
         self.search_grid_bounds = search_grid_bounds
         self.record = record
         self.decode_result = None
+
+
+def _as_frames(audio_i16):
+    """[B, 180000] int16 as is; lists / short frames through frames_from_ragged."""
+    if isinstance(audio_i16, np.ndarray) and audio_i16.dtype == np.int16 and audio_i16.ndim == 2 and audio_i16.shape[1] == _lib.NSAMP:
+        return np.ascontiguousarray(audio_i16)
+    if isinstance(audio_i16, np.ndarray) and audio_i16.ndim == 2:
+        return frames_from_ragged(list(audio_i16))
+    return frames_from_ragged(audio_i16)
 
 
 class AudioIn:
@@ -196,10 +228,10 @@ class Receiver:
 
     def decode_frames(self, audio_i16, cyclestart_strings=None, return_records=False):
         """Decode B independent 15-s frames.  -> list (per frame) of message dicts in emit order."""
-        audio = np.ascontiguousarray(audio_i16, np.int16)
-        if audio.ndim == 1:
-            audio = audio[None]
+        audio = _as_frames(audio_i16)
         B = audio.shape[0]
+        if B == 0:
+            return ([], np.zeros((0, self.cfg.max_cands), _lib.RECORD_DTYPE), np.zeros(0, np.int32)) if return_records else []
         rec, cnt, ev, evc = self._handle(B).decode_batch(audio)
         # host message layer: native, multithreaded (ft8rx_package_batch); messages.package_frame is its Python twin
         msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc)
@@ -212,9 +244,9 @@ class Receiver:
     def decode_frames_arrays(self, audio_i16, n_threads=None):
         """High-throughput variant of decode_frames: no Python dicts.  -> (messages[B, 128] of _lib.MESSAGE_DTYPE,
         counts[B], records[B, max_cands], record_counts[B]); rows are in the reference's emit order."""
-        audio = np.ascontiguousarray(audio_i16, np.int16)
-        if audio.ndim == 1:
-            audio = audio[None]
+        audio = _as_frames(audio_i16)
+        if audio.shape[0] == 0:
+            raise _lib.Ft8rxError("empty batch")
         rec, cnt, ev, evc = self._handle(audio.shape[0]).decode_batch(audio)
         msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=n_threads)
         return msgs, mcnt, rec, cnt
@@ -240,7 +272,6 @@ class Receiver:
 
 def decode_frames(audio_i16, on_message=None, **receiver_kwargs):
     """decode_frames(audio_i16[B,180000], **receiver_kwargs) -> list[list[message dict]]  (SURVEY.md 8b)."""
-    audio = np.asarray(audio_i16)
-    n = 1 if audio.ndim == 1 else audio.shape[0]
-    rx = Receiver("", on_message, max_frames=n, **receiver_kwargs)
+    audio = _as_frames(audio_i16)
+    rx = Receiver("", on_message, max_frames=max(1, audio.shape[0]), **receiver_kwargs)
     return rx.decode_frames(audio)

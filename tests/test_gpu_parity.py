@@ -332,6 +332,28 @@ def test_search_sub_range_and_second_cycle():
     assert odd[0].origin["odd_even"] == 1
 
 
+def test_ragged_and_empty_batches(ocfg):
+    """A frame shorter than 15 s decodes like the same frame padded with silence (oracle on the padded frame); an empty
+    batch is an empty result; wrong shapes raise."""
+    from pyft8_amd import _lib
+    from pyft8_amd.receiver import Receiver, frames_from_ragged
+    got = []
+    rx = Receiver("x", got.append, max_frames=2)
+    audio, gold, js = load_golden("synth_000000")
+    short = audio[:150000]                               # 12.5 s: signals starting late lose their tail
+    out = rx.decode_frames([short, audio])
+    assert [m["all_txt_format"] for m in out[1]] == [m["all_txt_format"] for m in js["messages"]]
+    padded = frames_from_ragged([short])[0]
+    want = O.decode_frame(padded, ocfg)
+    assert [" ".join(m["msg_tuple"]) for m in out[0]] == [" ".join(m["msg_tuple"]) for m in want["msgs"]]
+    assert 0 < len(out[0]) <= len(out[1])
+    assert rx.decode_frames(np.zeros((0, _lib.NSAMP), np.int16)) == []
+    with pytest.raises(_lib.Ft8rxError):
+        rx.decode_frames(np.zeros((1, _lib.NSAMP + 5), np.int16))
+    with pytest.raises(_lib.Ft8rxError):
+        _lib.default_handle().decode_batch(np.zeros((1, 1000), np.int16))
+
+
 def _decode_with(cfg_kw, audio):
     from pyft8_amd import _lib
     cfg = _lib.default_config(**cfg_kw)

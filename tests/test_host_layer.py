@@ -161,3 +161,19 @@ def test_native_packager_throughput():
     dt = time.perf_counter() - t0
     assert (mc == len(js["messages"])).all()
     assert B / dt > 3000, f"native packager only {B / dt:.0f} frames/s on one thread"
+
+
+def test_ragged_and_invalid_frames():
+    """Host-side input handling: short frames are padded with silence, bad input raises Ft8rxError (no asserts, no UB)."""
+    from pyft8_amd import _lib
+    from pyft8_amd.receiver import frames_from_ragged, _as_frames
+    a = frames_from_ragged([np.ones(10, np.int16), np.arange(5), np.zeros(0, np.int16)])
+    assert a.shape == (3, _lib.NSAMP) and a.dtype == np.int16
+    assert a[0, :10].tolist() == [1] * 10 and not a[0, 10:].any() and a[1, :5].tolist() == [0, 1, 2, 3, 4] and not a[2].any()
+    full = np.arange(2 * _lib.NSAMP, dtype=np.int64).reshape(2, -1).astype(np.int16)
+    assert _as_frames(full) is not None and np.array_equal(_as_frames(full), full)
+    assert _as_frames(full[0]).shape == (1, _lib.NSAMP)
+    assert _as_frames(np.zeros((0, _lib.NSAMP), np.int16)).shape == (0, _lib.NSAMP)
+    for bad in ([np.zeros(_lib.NSAMP + 1, np.int16)], [np.zeros((2, 3), np.int16)], [np.array([1.5])], [np.array([40000])]):
+        with pytest.raises(_lib.Ft8rxError):
+            frames_from_ragged(bad)
