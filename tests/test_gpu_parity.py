@@ -354,6 +354,29 @@ def test_ragged_and_empty_batches(ocfg):
         _lib.default_handle().decode_batch(np.zeros((1, 1000), np.int16))
 
 
+def test_device_validity_and_crc_on_reference_message_golden(H):
+    """Device-side unpack validity (ft8rx_valid77) and CRC-14 (ft8rx_crc_valid) on the reference-generated message golden:
+    valid  <=>  the reference's unpack() returned a tuple; CRC of the reference transmitter's codewords passes."""
+    from pyft8_amd import synth
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "messages.json")))
+    words = [int(u["bits77"], 16) for u in d["unpack"]]
+    got = H.valid77(words)
+    want = np.array([u["result"] is not None for u in d["unpack"]])
+    assert np.array_equal(got != 0, want)
+    cws, bits = [], []
+    for p in d["pack"]:
+        b = int(p["bits77"], 16)
+        w91 = (b << 14) | p["crc14"]
+        cws.append([1.0 if (w91 >> (90 - i)) & 1 else -1.0 for i in range(91)])
+        bits.append(b)
+    res, lo, hi = H.crc_valid(np.float32(cws))
+    assert np.all(res != 0)                                   # CRC passes on every reference-made codeword
+    assert [int(l) | (int(h) << 64) for l, h in zip(lo, hi)] == bits
+    bad = np.float32(cws)
+    bad[:, 5] *= -1                                           # one flipped message bit: CRC must fail
+    assert not H.crc_valid(bad)[0].any()
+
+
 def _decode_with(cfg_kw, audio):
     from pyft8_amd import _lib
     cfg = _lib.default_config(**cfg_kw)

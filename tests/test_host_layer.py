@@ -177,3 +177,17 @@ def test_ragged_and_invalid_frames():
     for bad in ([np.zeros(_lib.NSAMP + 1, np.int16)], [np.zeros((2, 3), np.int16)], [np.array([1.5])], [np.array([40000])]):
         with pytest.raises(_lib.Ft8rxError):
             frames_from_ragged(bad)
+
+
+def test_messages_py_unpack_matches_reference_golden():
+    """pyft8_amd.messages.unpack + CallHashes against the reference's own unpack() run in sequence (tests/golden/messages.json)."""
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "messages.json")))
+    from pyft8_amd import messages as M, decoders
+    tab = M.CallHashes()
+    for u in d["unpack"]:
+        m = M.unpack(int(u["bits77"], 16), tab)
+        assert (None if m is None else " ".join(m)) == u["result"], u
+    decoders.call_hashes.clear()                  # module-level surface of the reference (decoders.unpack + databases.call_hashes)
+    for u in d["unpack"][:500]:
+        m = decoders.unpack(int(u["bits77"], 16))
+        assert (None if m is None else " ".join(m)) == u["result"], u
