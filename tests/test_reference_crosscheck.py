@@ -1,0 +1,89 @@
+"""Live cross-check of the CPU oracle against the REAL reference on fresh frames (build container only).
+
+The committed goldens (tests/golden/) pin the oracle on 5 frames; this test widens the evidence without growing the
+repository: it decodes N never-seen synthetic frames (varied signal counts, SNR ranges and Receiver kwargs) with the
+reference (oracle/ref_harness.py, ~3 s per frame) and with the oracle and requires identical candidate lists, message
+lists in emit order, SNR/dt/frequency strings, decode notes and the complete unpack() call sequence.
+
+It needs /root/reference and costs minutes, so it only runs on request:
+    PYFT8_REF_CROSSCHECK=24 python -m pytest tests/test_reference_crosscheck.py -q -m ref
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+N = int(os.environ.get("PYFT8_REF_CROSSCHECK", "0"))
+HAVE_REF = os.path.isdir(os.environ.get("PYFT8_REFERENCE", "/root/reference"))
+pytestmark = [pytest.mark.ref, pytest.mark.skipif(not (N and HAVE_REF), reason="set PYFT8_REF_CROSSCHECK=<n frames>; needs /root/reference")]
+
+RECIPES = [dict(n_signals=50, snr_range=(-10.0, 10.0)), dict(n_signals=30, snr_range=(-20.0, 0.0)), dict(n_signals=8, snr_range=(-24.0, -12.0)),
+           dict(n_signals=70, snr_range=(-5.0, 15.0)), dict(n_signals=1, snr_range=(0.0, 5.0)), dict(n_signals=0)]
+KWARGS = [dict(), dict(), dict(), dict(sync_score_min=100, max_cands=150), dict(search_freq_range=[300, 2500], search_time_range=[-1.0, 2.0])]
+
+
+@pytest.mark.parametrize("k", range(N))
+def test_oracle_equals_reference_on_fresh_frame(k):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from ref_harness import run_frame
+    from pyft8_amd import synth
+    from pyft8_amd.receiver import config_from_kwargs
+    recipe, kw = RECIPES[k % len(RECIPES)], KWARGS[k % len(KWARGS)]
+    audio = synth.make_frame(7000000 + k, **recipe)
+    cands, tr, rx = run_frame(audio, **kw)
+    cfg = config_from_kwargs(**kw)
+    ocfg = O.default_config(sync_score_min=cfg.sync_score_min, max_cands=cfg.max_cands, f0_lo=cfg.f0_lo, f0_hi=cfg.f0_hi,
+                            h0_lo=cfg.h0_lo, h0_hi=cfg.h0_hi)
+    r = O.decode_frame(audio, ocfg)
+    # candidate list: same (f0, h0) set, same order -- except that two candidates whose sync scores agree to < 1e-6 relative may
+    # swap places (the reference's score is a BLAS float32 sdot whose summation order is not reproducible; the contract sums in
+    # fp64)
+    ok, rk = [(c.f0_idx, c.h0_idx) for c in r["cands"]], [(f["f0_idx"], f["h0_idx"]) for f in tr.final]
+    assert sorted(ok) == sorted(rk)
+    osc, rsc = {kk: c.score for kk, c in zip(ok, r["cands"])}, {kk: f["score"] for kk, f in zip(rk, tr.final)}
+    for kk in ok:
+        assert abs(osc[kk] - rsc[kk]) <= 1e-4 * abs(rsc[kk])
+    for a, b in zip(ok, rk):
+        if a != b:
+            print(f"frame {k}: candidates {a} / {b} swapped (scores {rsc[a]!r} / {rsc[b]!r})")
+            assert abs(rsc[a] - rsc[b]) <= 1e-6 * abs(rsc[a])
+    # messages: identical texts in identical emit order.  The only tolerated difference is an OSD decode (ipass 5/6) present on one
+    # side only, or the same text reported from a different duplicate candidate: the reference orders |llr| with numpy's UNSTABLE
+    # argsort and tied magnitudes are common (the three bits of a symbol often share one max-log difference), so which tied column
+    # enters the information set is numpy-build specific; the build fixes "ties by index" (DESIGN.md section 2).
+    o_txt = [" ".join(m["msg_tuple"]) for m in r["msgs"]]
+    r_txt = [" ".join(m["msg_tuple"]) for m in tr.messages]
+    common = set(o_txt) & set(r_txt)
+    assert [t for t in o_txt if t in common] == [t for t in r_txt if t in common]
+    for m in r["msgs"]:
+        if " ".join(m["msg_tuple"]) not in common:
+            print(f"frame {k}: only the oracle decodes '{' '.join(m['msg_tuple'])}' ({O.notes_of(m)})")
+            assert "OSD" in O.notes_of(m)
+    for ref in tr.messages:
+        if " ".join(ref["msg_tuple"]) not in common:
+            print(f"frame {k}: only the reference decodes '{' '.join(ref['msg_tuple'])}' ({ref['decode_notes']})")
+            assert "OSD" in ref["decode_notes"]
+    assert len(set(o_txt) ^ set(r_txt)) <= 1
+    by_txt = {" ".join(ref["msg_tuple"]): ref for ref in tr.messages}
+    for m in r["msgs"]:
+        ref = by_txt.get(" ".join(m["msg_tuple"]))
+        if ref is None:
+            continue
+        same = (f"{m['snr']:+03d}" == ref["their_snr"] and abs(m["tsec"] - ref["tsec"]) < 1e-9 and abs(m["fHz"] - ref["fHz"]) < 1e-9
+                and O.notes_of(m) == ref["decode_notes"])
+        if not same:
+            print(f"frame {k}: '{' '.join(m['msg_tuple'])}' reported by another candidate: oracle {O.notes_of(m)} {m['snr']:+03d}, "
+                  f"reference {ref['decode_notes']} {ref['their_snr']}")
+            assert "OSD" in ref["decode_notes"] or "OSD" in O.notes_of(m)
+    # unpack() call sequence: exact up to ipass 4; in the OSD steps the two sides may differ by the few trial words the tie order
+    # decides (counted and reported)
+    got = [(O.msg_int(e.msg_lo, e.msg_hi), ok[e.cand], e.ipass, bool(e.valid)) for e in r["events"]]
+    ref = [(int(bits), rk[cand], ipass, res is not None) for bits, res, cand, ipass in tr.unpack_calls]
+    assert [g for g in got if g[2] < 5] == [x for x in ref if x[2] < 5]
+    diff = sorted(set(g for g in got if g[2] >= 5) ^ set(x for x in ref if x[2] >= 5))
+    if diff:
+        print(f"frame {k}: {len(diff)} OSD-step unpack call(s) differ (argsort tie order): {diff}")
+    assert len(diff) <= 4
