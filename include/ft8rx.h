@@ -152,6 +152,10 @@ int  ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, con
 /* the handle's own device audio buffer ([max_frames][180000] int16) and a D2H copy helper (tests, tools) */
 int16_t* ft8rx_staging_audio(ft8rx_handle* h);
 int  ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes);
+/* Page-locked host memory for audio handed to ft8rx_decode_batch: copies from it are true asynchronous DMA that overlaps the
+ * kernels of earlier chunks (pageable memory works too, at a lower PCIe-inclusive rate).  Free with ft8rx_free_host. */
+void* ft8rx_alloc_host(ft8rx_handle* h, uint64_t bytes);
+int  ft8rx_free_host(ft8rx_handle* h, void* p);               /* h may be NULL */
 /* arithmetic-contract probes: which 0 = log10f, 1 = tanhf; 2 = forward FFT of length n (x = interleaved complex) */
 int  ft8rx_math_probe(ft8rx_handle* h, int which, const float* x, int n, float* y);
 

@@ -3,6 +3,7 @@ missing or no MI355X is visible, the product raises."""
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -265,6 +266,22 @@ class Handle:
         out = np.zeros(len(lo), np.int32)
         self._chk(lib().ft8rx_valid77(self._h, _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), len(lo), _ptr(out, C.c_int32)), "ft8rx_valid77")
         return out
+
+    def pinned_audio(self, n_frames):
+        """int16 [n_frames, 180000] array in page-locked host memory (ft8rx_alloc_host): fill it and pass it to decode_batch for
+        overlapped DMA.  The memory is released when the array (and every view of it) is garbage collected."""
+        L = lib()
+        L.ft8rx_alloc_host.restype = C.c_void_p
+        L.ft8rx_alloc_host.argtypes = [C.c_void_p, C.c_uint64]
+        L.ft8rx_free_host.argtypes = [C.c_void_p, C.c_void_p]
+        nbytes = int(n_frames) * NSAMP * 2
+        p = L.ft8rx_alloc_host(self._h, nbytes)
+        if not p:
+            raise Ft8rxError(f"ft8rx_alloc_host failed: {L.ft8rx_last_error(self._h).decode()}")
+        buf = (C.c_int16 * (int(n_frames) * NSAMP)).from_address(p)
+        arr = np.frombuffer(buf, dtype=np.int16).reshape(int(n_frames), NSAMP)
+        weakref.finalize(buf, L.ft8rx_free_host, None, C.c_void_p(p))
+        return arr
 
     def staging_ptr(self):
         return int(lib().ft8rx_staging_audio(self._h))

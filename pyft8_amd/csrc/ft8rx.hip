@@ -54,6 +54,8 @@ struct ft8rx_handle {
     int n_streams;                       // chunks of a batch run their kernel chains on separate streams
     hipStream_t sub[8];
     hipEvent_t ev_fork, ev_join[8];
+    hipStream_t copy_s;              // host-to-device chunk copies of ft8rx_decode_batch, in order, never queued behind kernels
+    hipEvent_t ev_chunk[16];
     Tables T;
     std::vector<void*> allocs;
     int16_t* d_audio;            // staging for host-pointer entry points
@@ -134,6 +136,8 @@ void ft8rx_destroy(ft8rx_handle* h) {
     for (void* p : h->allocs) hipFree(p);
     for (auto e : h->pev) hipEventDestroy(e);
     for (int i = 0; i < 8; i++) { if (h->sub[i]) hipStreamDestroy(h->sub[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
+    if (h->copy_s) hipStreamDestroy(h->copy_s);
+    for (int i = 0; i < 16; i++) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -152,6 +156,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     ft8rx_handle* h = new ft8rx_handle();
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
     h->n_streams = 4; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
+    h->copy_s = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
     int rc = 0;
@@ -219,6 +224,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: init kernel failed"); ft8rx_destroy(h); return -2; }
     for (int i = 0; i < 24; i++) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); }
     for (int i = 0; i < 8; i++) { hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking); hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming); }
+    hipStreamCreateWithFlags(&h->copy_s, hipStreamNonBlocking);
+    for (int i = 0; i < 16; i++) hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     *out = h;
     return 0;
@@ -334,8 +341,9 @@ int ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_recor
     if (!h || !audio) return -1;
     if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_decode_batch: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
     HIPCHK(h, hipSetDevice(h->device));
-    // Host audio: the batch is cut into chunks (twice the stream count, >= 8 frames each); chunk k's host-to-device copy is
-    // issued on its stream right before its kernel chain, so it overlaps the kernels of the chunks before it.
+    // Host audio: the batch is cut into chunks (twice the stream count, >= 8 frames each).  The chunk copies run in order on a
+    // dedicated copy stream (never queued behind kernels, so a pageable-memory copy blocks the host only for its own duration);
+    // chunk k's kernel chain waits for its copy's event, so copies overlap the kernels of the chunks before them.
     int nc = h->profiling ? 1 : 2 * h->n_streams;
     if (nc > B / 8) nc = B / 8;
     if (nc <= 1) {
@@ -346,6 +354,7 @@ int ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_recor
     }
     h->pnames.clear();
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_fork, 0));
     for (int i = 0; i < h->n_streams; i++) HIPCHK(h, hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
     const int per = (B + nc - 1) / nc;
     for (int k = 0; k < nc; k++) {
@@ -353,7 +362,9 @@ int ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_recor
         if (n <= 0) break;
         hipStream_t s = h->sub[k % h->n_streams];
         HIPCHK(h, hipMemcpyAsync(h->d_audio + (size_t)f0 * FT8RX_NSAMP, audio + (size_t)f0 * FT8RX_NSAMP,
-                                 sizeof(int16_t) * (size_t)n * FT8RX_NSAMP, hipMemcpyHostToDevice, s));
+                                 sizeof(int16_t) * (size_t)n * FT8RX_NSAMP, hipMemcpyHostToDevice, h->copy_s));
+        HIPCHK(h, hipEventRecord(h->ev_chunk[k], h->copy_s));
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev_chunk[k], 0));
         enqueue_chain(h, h->d_audio, f0, n, s, false);
     }
     for (int i = 0; i < h->n_streams; i++) {
@@ -535,6 +546,23 @@ int ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t b
     if (!h || !dst || !d_src) return -1;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+void* ft8rx_alloc_host(ft8rx_handle* h, uint64_t bytes) {
+    if (!h || bytes == 0) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(h->device) != hipSuccess || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        set_err(h, "ft8rx_alloc_host: hipHostMalloc(%llu) failed", (unsigned long long)bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+int ft8rx_free_host(ft8rx_handle* h, void* p) {          // h may be NULL (buffers can outlive the handle that allocated them)
+    if (!p) return -1;
+    const hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) { if (h) set_err(h, "hipHostFree failed: %s", hipGetErrorString(e)); return -2; }
     return 0;
 }
 

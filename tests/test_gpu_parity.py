@@ -348,6 +348,14 @@ def test_ragged_and_empty_batches(ocfg):
     assert [" ".join(m["msg_tuple"]) for m in out[0]] == [" ".join(m["msg_tuple"]) for m in want["msgs"]]
     assert 0 < len(out[0]) <= len(out[1])
     assert rx.decode_frames(np.zeros((0, _lib.NSAMP), np.int16)) == []
+    # page-locked host audio (ft8rx_alloc_host): same results as the pageable path
+    h = _lib.default_handle(2)
+    pin = h.pinned_audio(2)
+    pin[:] = np.stack([padded, audio])
+    ra, ca, ea, eca = h.decode_batch(pin)
+    rb, cb, eb, ecb = h.decode_batch(np.stack([padded, audio]))
+    assert np.array_equal(ca, cb) and ra.tobytes() == rb.tobytes() and np.array_equal(eca, ecb)
+    del pin
     with pytest.raises(_lib.Ft8rxError):
         rx.decode_frames(np.zeros((1, _lib.NSAMP + 5), np.int16))
     with pytest.raises(_lib.Ft8rxError):
