@@ -254,7 +254,8 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(frames)
+            # the CPU oracle timed on this box's host cores: rank 0 at N = 1 only (the contract); null in multi-GPU runs
+            line["cpu_baseline"] = cpu_baseline(frames) if world == 1 else None
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
