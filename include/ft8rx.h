@@ -96,8 +96,11 @@ int  ft8rx_get_fft_plans(int32_t* p1920, int32_t* p3200, int32_t* p300, int32_t*
  *   events  : [n_frames][FT8RX_EVENT_CAP] event_counts : [n_frames] (may exceed the cap => truncated) */
 int  ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int n_frames,
                         ft8rx_record* records, int32_t* counts, ft8rx_event* events, int32_t* event_counts);
-/* Same, split for throughput measurement: audio already resident in HBM (device pointer),
- * enqueue is asynchronous on the handle's stream, fetch copies results to the host. */
+/* Same, split for pipelining: audio already resident in HBM (device pointer); enqueue is asynchronous.  Results are double
+ * buffered: when a batch's kernels finish, a copy stream moves its records/events into page-locked host buffers while the next
+ * enqueued batch computes.  ft8rx_fetch_results waits for and returns the OLDEST unfetched batch (or the latest batch again if
+ * all have been fetched); at most two batches are retained -- a third enqueue drops the oldest.  Steady state:
+ *   enqueue(0); for k = 1..: enqueue(k); fetch(k-1); <host message layer of k-1>   -- the GPU never waits for the host. */
 int  ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int n_frames);
 int  ft8rx_sync(ft8rx_handle* h);
 int  ft8rx_fetch_results(ft8rx_handle* h, int n_frames, ft8rx_record* records, int32_t* counts,

@@ -66,6 +66,13 @@ struct ft8rx_handle {
     Att *d_att0, *d_attG, *d_attB, *d_attO;
     cpx *d_A, *d_Z, *d_spec;
     ft8rx_event* d_ev; int32_t* d_evcount;
+    // Result slots.  A batch writes its records/events into slot k % 2 (slot 0 = d_rec/d_ncand/d_ev/d_evcount above) and, when its
+    // kernels are done, the copy stream moves them into page-locked host buffers while the next batch computes into the other
+    // slot; ft8rx_fetch_results hands out the oldest unfetched batch.  At most two batches' results are retained.
+    ft8rx_record* s_rec[2]; int32_t* s_ncand[2]; ft8rx_event* s_ev[2]; int32_t* s_evcount[2];
+    ft8rx_record* h_rec[2]; int32_t* h_cnt[2]; ft8rx_event* h_ev[2]; int32_t* h_evc[2];
+    hipEvent_t ev_comp[2], ev_done[2];
+    int slot_enq, slot_fetch, inflight, last_slot, slot_B[2];
     std::string err;
     bool profiling;
     std::vector<hipEvent_t> pev;
@@ -139,6 +146,14 @@ void ft8rx_destroy(ft8rx_handle* h) {
     if (h->copy_s) hipStreamDestroy(h->copy_s);
     for (int i = 0; i < 16; i++) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (int k = 0; k < 2; k++) {
+        if (h->ev_comp[k]) hipEventDestroy(h->ev_comp[k]);
+        if (h->ev_done[k]) hipEventDestroy(h->ev_done[k]);
+        if (h->h_rec[k]) hipHostFree(h->h_rec[k]);
+        if (h->h_cnt[k]) hipHostFree(h->h_cnt[k]);
+        if (h->h_ev[k]) hipHostFree(h->h_ev[k]);
+        if (h->h_evc[k]) hipHostFree(h->h_evc[k]);
+    }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -157,6 +172,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
     h->n_streams = 4; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
     h->copy_s = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
+    for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->slot_B[k] = 0; }
+    h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
     int rc = 0;
@@ -177,6 +194,18 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     rc |= dalloc(h, &h->d_spec, B * FT8RX_SPEC_BINS);
     rc |= dalloc(h, &h->d_ev, B * FT8RX_EVENT_CAP);
     rc |= dalloc(h, &h->d_evcount, B);
+    h->s_rec[0] = h->d_rec; h->s_ncand[0] = h->d_ncand; h->s_ev[0] = h->d_ev; h->s_evcount[0] = h->d_evcount;
+    rc |= dalloc(h, &h->s_rec[1], B * MAXC);
+    rc |= dalloc(h, &h->s_ncand[1], B);
+    rc |= dalloc(h, &h->s_ev[1], B * FT8RX_EVENT_CAP);
+    rc |= dalloc(h, &h->s_evcount[1], B);
+    for (int k = 0; k < 2 && !rc; k++) {
+        bool okh = hipHostMalloc((void**)&h->h_rec[k], sizeof(ft8rx_record) * B * cfg->max_cands, hipHostMallocDefault) == hipSuccess;
+        okh = okh && hipHostMalloc((void**)&h->h_cnt[k], sizeof(int32_t) * B, hipHostMallocDefault) == hipSuccess;
+        okh = okh && hipHostMalloc((void**)&h->h_ev[k], sizeof(ft8rx_event) * B * FT8RX_EVENT_CAP, hipHostMallocDefault) == hipSuccess;
+        okh = okh && hipHostMalloc((void**)&h->h_evc[k], sizeof(int32_t) * B, hipHostMallocDefault) == hipSuccess;
+        if (!okh) { set_err(h, "ft8rx_create: page-locked result buffers (%zu frames) could not be allocated", B); rc = -2; }
+    }
     if (rc) { g_create_err = h->err; ft8rx_destroy(h); return -2; }
     // ---- tables (double precision on the host, rounded once)
     std::vector<float> win(3840);
@@ -227,6 +256,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     hipStreamCreateWithFlags(&h->copy_s, hipStreamNonBlocking);
     for (int i = 0; i < 16; i++) hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    for (int k = 0; k < 2; k++) { hipEventCreateWithFlags(&h->ev_comp[k], hipEventDisableTiming); hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming); }
     *out = h;
     return 0;
 }
@@ -242,17 +272,17 @@ int ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms
 
 
 // the kernel chain for frames [f0, f0+B) on stream s (all buffers are frame-major, so a chunk is a pointer offset)
-static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B, hipStream_t s, bool prof) {
+static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B, hipStream_t s, bool prof, int slot) {
     const ft8rx_config& c = h->cfg;
     const size_t F = (size_t)f0;
     const int16_t* audio = d_audio + F * FT8RX_NSAMP;
     float* grid = h->d_grid + F * FT8RX_GRID_ROWS * FT8RX_GRID_COLS;
     float* bs = h->d_best_score + F * NF0MAX; int32_t* bh = h->d_best_h0 + F * NF0MAX;
-    ft8rx_record* rec = h->d_rec + F * MAXC; int32_t* ncand = h->d_ncand + F;
+    ft8rx_record* rec = h->s_rec[slot] + F * MAXC; int32_t* ncand = h->s_ncand[slot] + F;
     float* llr0 = h->d_llr0 + F * MAXC * 174; float* saved = h->d_saved + F * MAXC * 5 * 174;
     Att* att0 = h->d_att0 + F * MAXC * 5; Att* attG = h->d_attG + F * MAXC * 2; Att* attB = h->d_attB + F * MAXC * 5; Att* attO = h->d_attO + F * MAXC * 10;
     cpx* A = h->d_A + F * 96000; cpx* Z = h->d_Z + F * 96000; cpx* spec = h->d_spec + F * FT8RX_SPEC_BINS;
-    ft8rx_event* ev = h->d_ev + F * FT8RX_EVENT_CAP; int32_t* evc = h->d_evcount + F;
+    ft8rx_event* ev = h->s_ev[slot] + F * FT8RX_EVENT_CAP; int32_t* evc = h->s_evcount[slot] + F;
 #define STAGE(name) do { if (prof) { hipEventRecord(h->pev[h->pnames.size()], s); h->pnames.push_back(name); } } while (0)
     hipMemsetAsync(evc, 0, sizeof(int32_t) * B, s);
     STAGE("spectrogram");
@@ -286,29 +316,65 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
 #undef STAGE
 }
 
+// Launch one batch: audio either resident on the device (host_audio == nullptr) or copied from the host in chunks.
+//   profiling mode / small batches: one chain on the main stream (per-stage events bracket whole-batch launches);
+//   otherwise the batch is cut into chunks whose chains overlap on the sub-streams -- the ladder kernels (BP, OSD, fine sync)
+//   are latency bound, so chunks fill each other's stalls.  Host audio uses twice as many chunks; their copies run in order on
+//   the dedicated copy stream (never queued behind kernels, so a pageable-memory copy blocks the host only for its own
+//   duration) and each chunk's chain waits for its copy's event.
+// When the kernels are done the copy stream moves the slot's results into the page-locked host buffers.
+static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* host_audio, int B) {
+    HIPCHK(h, hipSetDevice(h->device));
+    h->pnames.clear();
+    if (h->inflight == 2) { h->slot_fetch ^= 1; h->inflight = 1; }          // the oldest unfetched batch is dropped
+    const int slot = h->slot_enq;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));          // the slot's previous results have left the device
+    int nc = h->profiling ? 1 : (host_audio ? 2 * h->n_streams : h->n_streams);
+    if (nc > B / 8) nc = B / 8;
+    if (nc <= 1) {
+        if (host_audio) HIPCHK(h, hipMemcpyAsync(h->d_audio, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
+        enqueue_chain(h, d_audio, 0, B, h->stream, h->profiling, slot);
+    } else {
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        if (host_audio) HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_fork, 0));
+        for (int i = 0; i < h->n_streams; i++) HIPCHK(h, hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
+        const int per = (B + nc - 1) / nc;
+        for (int k = 0; k < nc; k++) {
+            const int f0 = k * per, n = (f0 + per <= B) ? per : B - f0;
+            if (n <= 0) break;
+            hipStream_t s = h->sub[k % h->n_streams];
+            if (host_audio) {
+                HIPCHK(h, hipMemcpyAsync(h->d_audio + (size_t)f0 * FT8RX_NSAMP, host_audio + (size_t)f0 * FT8RX_NSAMP,
+                                         sizeof(int16_t) * (size_t)n * FT8RX_NSAMP, hipMemcpyHostToDevice, h->copy_s));
+                HIPCHK(h, hipEventRecord(h->ev_chunk[k], h->copy_s));
+                HIPCHK(h, hipStreamWaitEvent(s, h->ev_chunk[k], 0));
+            }
+            enqueue_chain(h, d_audio, f0, n, s, false, slot);
+        }
+        for (int i = 0; i < h->n_streams; i++) {
+            HIPCHK(h, hipEventRecord(h->ev_join[i], h->sub[i]));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    // results -> page-locked host buffers on the copy stream (overlaps the next batch, which computes into the other slot)
+    const int mc = h->cfg.max_cands;
+    HIPCHK(h, hipEventRecord(h->ev_comp[slot], h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_comp[slot], 0));
+    HIPCHK(h, hipMemcpyAsync(h->h_cnt[slot], h->s_ncand[slot], sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->copy_s));
+    HIPCHK(h, hipMemcpy2DAsync(h->h_rec[slot], sizeof(ft8rx_record) * mc, h->s_rec[slot], sizeof(ft8rx_record) * MAXC,
+                               sizeof(ft8rx_record) * mc, B, hipMemcpyDeviceToHost, h->copy_s));
+    HIPCHK(h, hipMemcpyAsync(h->h_evc[slot], h->s_evcount[slot], sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->copy_s));
+    HIPCHK(h, hipMemcpyAsync(h->h_ev[slot], h->s_ev[slot], sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP, hipMemcpyDeviceToHost, h->copy_s));
+    HIPCHK(h, hipEventRecord(h->ev_done[slot], h->copy_s));
+    h->slot_B[slot] = B; h->last_slot = slot; h->slot_enq ^= 1; h->inflight++;
+    return 0;
+}
+
 int ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int B) {
     if (!h || !d_audio) return -1;
     if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_enqueue_batch: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
-    HIPCHK(h, hipSetDevice(h->device));
-    h->pnames.clear();
-    // profiling mode: one chain on the main stream so that per-stage events bracket whole-batch launches.
-    // normal mode: the batch is cut into n_streams chunks whose chains overlap on separate streams -- the ladder
-    // kernels (BP, OSD, fine sync) are latency bound, so chunks fill each other's stalls.
-    int ns = h->profiling ? 1 : h->n_streams;
-    if (ns > B / 8) ns = B / 8;
-    if (ns <= 1) { enqueue_chain(h, d_audio, 0, B, h->stream, h->profiling); HIPCHK(h, hipGetLastError()); return 0; }
-    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-    const int per = (B + ns - 1) / ns;
-    for (int i = 0; i < ns; i++) {
-        const int f0 = i * per, n = (f0 + per <= B) ? per : B - f0;
-        if (n <= 0) break;
-        HIPCHK(h, hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
-        enqueue_chain(h, d_audio, f0, n, h->sub[i], false);
-        HIPCHK(h, hipEventRecord(h->ev_join[i], h->sub[i]));
-        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
-    }
-    HIPCHK(h, hipGetLastError());
-    return 0;
+    return launch_batch(h, d_audio, nullptr, B);
 }
 
 int ft8rx_set_streams(ft8rx_handle* h, int n) { if (!h || n < 1 || n > 8) return -1; h->n_streams = n; return 0; }
@@ -317,6 +383,7 @@ int ft8rx_sync(ft8rx_handle* h) {
     if (!h) return -1;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->copy_s));
     if (h->profiling && !h->pnames.empty()) {
         h->n_stage = (int)h->pnames.size();
         for (int i = 0; i < h->n_stage; i++) hipEventElapsedTime(&h->stage_ms[i], h->pev[i], h->pev[i + 1]);
@@ -326,13 +393,17 @@ int ft8rx_sync(ft8rx_handle* h) {
 
 int ft8rx_fetch_results(ft8rx_handle* h, int B, ft8rx_record* records, int32_t* counts, ft8rx_event* events, int32_t* event_counts) {
     if (!h || B < 1 || B > h->max_frames) return -1;
+    if (h->last_slot < 0) { set_err(h, "ft8rx_fetch_results: nothing has been enqueued"); return -1; }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const int mc = h->cfg.max_cands;
-    if (counts) HIPCHK(h, hipMemcpy(counts, h->d_ncand, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
-    if (records) HIPCHK(h, hipMemcpy2D(records, sizeof(ft8rx_record) * mc, h->d_rec, sizeof(ft8rx_record) * MAXC, sizeof(ft8rx_record) * mc, B, hipMemcpyDeviceToHost));
-    if (event_counts) HIPCHK(h, hipMemcpy(event_counts, h->d_evcount, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
-    if (events) HIPCHK(h, hipMemcpy(events, h->d_ev, sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP, hipMemcpyDeviceToHost));
+    const int slot = h->inflight ? h->slot_fetch : h->last_slot;      // oldest unfetched batch, else the latest one again
+    if (B > h->slot_B[slot]) { set_err(h, "ft8rx_fetch_results: %d frames requested, the batch had %d", B, h->slot_B[slot]); return -1; }
+    HIPCHK(h, hipEventSynchronize(h->ev_done[slot]));
+    const size_t mc = (size_t)h->cfg.max_cands;
+    if (counts) memcpy(counts, h->h_cnt[slot], sizeof(int32_t) * B);
+    if (records) memcpy(records, h->h_rec[slot], sizeof(ft8rx_record) * mc * B);
+    if (event_counts) memcpy(event_counts, h->h_evc[slot], sizeof(int32_t) * B);
+    if (events) memcpy(events, h->h_ev[slot], sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP);
+    if (h->inflight) { h->slot_fetch ^= 1; h->inflight--; }
     return 0;
 }
 
@@ -340,38 +411,9 @@ int ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_recor
                        ft8rx_event* events, int32_t* event_counts) {
     if (!h || !audio) return -1;
     if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_decode_batch: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
-    HIPCHK(h, hipSetDevice(h->device));
-    // Host audio: the batch is cut into chunks (twice the stream count, >= 8 frames each).  The chunk copies run in order on a
-    // dedicated copy stream (never queued behind kernels, so a pageable-memory copy blocks the host only for its own duration);
-    // chunk k's kernel chain waits for its copy's event, so copies overlap the kernels of the chunks before them.
-    int nc = h->profiling ? 1 : 2 * h->n_streams;
-    if (nc > B / 8) nc = B / 8;
-    if (nc <= 1) {
-        HIPCHK(h, hipMemcpyAsync(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
-        int rc = ft8rx_enqueue_batch(h, h->d_audio, B);
-        if (rc) return rc;
-        return ft8rx_fetch_results(h, B, records, counts, events, event_counts);
-    }
-    h->pnames.clear();
-    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_fork, 0));
-    for (int i = 0; i < h->n_streams; i++) HIPCHK(h, hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
-    const int per = (B + nc - 1) / nc;
-    for (int k = 0; k < nc; k++) {
-        const int f0 = k * per, n = (f0 + per <= B) ? per : B - f0;
-        if (n <= 0) break;
-        hipStream_t s = h->sub[k % h->n_streams];
-        HIPCHK(h, hipMemcpyAsync(h->d_audio + (size_t)f0 * FT8RX_NSAMP, audio + (size_t)f0 * FT8RX_NSAMP,
-                                 sizeof(int16_t) * (size_t)n * FT8RX_NSAMP, hipMemcpyHostToDevice, h->copy_s));
-        HIPCHK(h, hipEventRecord(h->ev_chunk[k], h->copy_s));
-        HIPCHK(h, hipStreamWaitEvent(s, h->ev_chunk[k], 0));
-        enqueue_chain(h, h->d_audio, f0, n, s, false);
-    }
-    for (int i = 0; i < h->n_streams; i++) {
-        HIPCHK(h, hipEventRecord(h->ev_join[i], h->sub[i]));
-        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
-    }
-    HIPCHK(h, hipGetLastError());
+    h->inflight = 0; h->slot_fetch = h->slot_enq;                     // synchronous entry: nothing older is kept
+    int rc = launch_batch(h, h->d_audio, audio, B);
+    if (rc) return rc;
     return ft8rx_fetch_results(h, B, records, counts, events, event_counts);
 }
 
