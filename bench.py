@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--unique", type=int, default=64, help="(host generator only) distinct frames generated per rank, tiled to --frames")
     ap.add_argument("--host-synth", action="store_true", help="generate frames with the numpy generator instead of the device kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-entry", action="store_true", help="skip the informational host-pointer (PCIe-inclusive) passes, whose "
+                    "chunked launches would mix part-batch kernels into a rocprofv3 per-kernel average")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for flow tests on one GPU)")
     ap.add_argument("--signals", type=int, default=50, help="signals per synthetic frame (config 1/2: 50, config 4: <= 10)")
     ap.add_argument("--snr", type=float, nargs=2, default=(-10.0, 10.0), metavar=("LO", "HI"), help="SNR range in dB / 2500 Hz")
@@ -200,20 +202,22 @@ def main():
     h.set_profiling(False)
     rec, cnt, ev, evc = h.fetch(B)
     # informational: the host-pointer entry (ft8rx_decode_batch: pageable host audio -> H2D -> kernels -> D2H), PCIe inclusive
-    host_audio = d_audio.cpu().numpy()
-    h.decode_batch(host_audio)
-    t2 = time.perf_counter()
-    for _ in range(3):
+    pcie = pcie_pinned = None
+    if not args.no_host_entry:
+        host_audio = d_audio.cpu().numpy()
         h.decode_batch(host_audio)
-    pcie = 3 * B / (time.perf_counter() - t2)
-    pinned = h.pinned_audio(B)                    # same, from page-locked host memory (ft8rx_alloc_host)
-    pinned[:] = host_audio
-    h.decode_batch(pinned)
-    t2 = time.perf_counter()
-    for _ in range(3):
+        t2 = time.perf_counter()
+        for _ in range(3):
+            h.decode_batch(host_audio)
+        pcie = 3 * B / (time.perf_counter() - t2)
+        pinned = h.pinned_audio(B)                    # same, from page-locked host memory (ft8rx_alloc_host)
+        pinned[:] = host_audio
         h.decode_batch(pinned)
-    pcie_pinned = 3 * B / (time.perf_counter() - t2)
-    del host_audio, pinned
+        t2 = time.perf_counter()
+        for _ in range(3):
+            h.decode_batch(pinned)
+        pcie_pinned = 3 * B / (time.perf_counter() - t2)
+        del host_audio, pinned
     n_dec = int(sum((rec[f][:cnt[f]]["status"] == 1).sum() for f in range(B)))
     n_msgs = sum(len(messages.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]))) for f in range(min(B, 16)))
 
