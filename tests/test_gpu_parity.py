@@ -385,6 +385,45 @@ def test_device_validity_and_crc_on_reference_message_golden(H):
     assert not H.crc_valid(bad)[0].any()
 
 
+def test_result_slots_pipeline_order():
+    """Double-buffered results (include/ft8rx.h): fetch returns the OLDEST unfetched batch, a third enqueue drops the oldest,
+    fetching again without a new enqueue returns the latest batch, and pipelined results equal synchronous ones."""
+    from pyft8_amd import _lib
+    store = _lib.Handle(max_frames=3)                  # its staging buffer holds three device-resident frames
+    base = store.staging_ptr()
+    store.synth_frames(base, 91000, 3, n_signals=20, snr_range=(-12.0, 5.0))
+    frames = store.download_audio(base, 3)
+    h = _lib.Handle(max_frames=1)
+    want = [h.decode_batch(frames[i:i + 1]) for i in range(3)]
+
+    class _D:                                          # device pointer of frame i
+        def __init__(self, i):
+            self.p = base + i * _lib.NSAMP * 2
+
+        def data_ptr(self):
+            return self.p
+    d = [_D(i) for i in range(3)]
+
+    def same(a, b):                                    # valid parts only: entries past the counts are stale slot contents
+        (ra, ca, ea, na), (rb, cb, eb, nb) = a, b
+        return (np.array_equal(ca, cb) and np.array_equal(na, nb) and ra[0, :ca[0]].tobytes() == rb[0, :cb[0]].tobytes()
+                and sorted(ea[0, :na[0]].tolist()) == sorted(eb[0, :nb[0]].tolist()))
+    h.enqueue(d[0].data_ptr(), 1)
+    h.enqueue(d[1].data_ptr(), 1)
+    assert same(h.fetch(1), want[0])
+    h.enqueue(d[2].data_ptr(), 1)                      # slot of batch 0 is reused while batch 1 is still unfetched
+    assert same(h.fetch(1), want[1])
+    assert same(h.fetch(1), want[2])
+    assert same(h.fetch(1), want[2])                   # nothing new: the latest batch again
+    for i in range(3):                                 # three enqueues, no fetch: batch 0 is dropped
+        h.enqueue(d[i].data_ptr(), 1)
+    assert same(h.fetch(1), want[1]) and same(h.fetch(1), want[2])
+    with pytest.raises(_lib.Ft8rxError):
+        _lib.Handle(max_frames=1).fetch(1)             # nothing enqueued yet
+    h.close()
+    store.close()
+
+
 def _decode_with(cfg_kw, audio):
     from pyft8_amd import _lib
     cfg = _lib.default_config(**cfg_kw)
