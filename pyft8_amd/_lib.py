@@ -62,6 +62,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise Ft8rxError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(pyft8_amd has no CPU fallback)")
+        # PyTorch-ROCm wheels bundle their own HIP runtime; libft8rx.so links the system one (/opt/rocm).  Both can live in one
+        # process, but only if torch's runtime opens the GPU first -- so if torch is already imported, let it initialise now.
+        import sys
+        if "torch" in sys.modules:
+            try:
+                sys.modules["torch"].cuda.is_available()
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         L.ft8rx_last_error.restype = C.c_char_p
         L.ft8rx_last_error.argtypes = [C.c_void_p]
