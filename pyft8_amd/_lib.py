@@ -62,8 +62,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise Ft8rxError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(pyft8_amd has no CPU fallback)")
-        # PyTorch-ROCm wheels bundle their own HIP runtime; libft8rx.so links the system one (/opt/rocm).  Both can live in one
-        # process, but only if torch's runtime opens the GPU first -- so if torch is already imported, let it initialise now.
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; libft8rx.so links the system one (/opt/rocm, same soname).  The
+        # copy loaded first serves both: this library runs on either, torch only on its own -- so if torch is already imported,
+        # let it load and initialise its runtime before ours is pulled in.
         import sys
         if "torch" in sys.modules:
             try:
