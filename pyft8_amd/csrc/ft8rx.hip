@@ -251,12 +251,20 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     int nfill = (int)B * FT8RX_GRID_COLS;
     k_fill_row0<<<(nfill + 255) / 256, 256, 0, h->stream>>>(h->d_grid, (int)B);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: init kernel failed"); ft8rx_destroy(h); return -2; }
-    for (int i = 0; i < 24; i++) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); }
-    for (int i = 0; i < 8; i++) { hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking); hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming); }
-    hipStreamCreateWithFlags(&h->copy_s, hipStreamNonBlocking);
-    for (int i = 0; i < 16; i++) hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming);
-    hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
-    for (int k = 0; k < 2; k++) { hipEventCreateWithFlags(&h->ev_comp[k], hipEventDisableTiming); hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming); }
+    bool okc = true;
+    for (int i = 0; i < 24; i++) { hipEvent_t e = nullptr; okc = okc && hipEventCreate(&e) == hipSuccess; if (e) h->pev.push_back(e); }
+    for (int i = 0; i < 8; i++) {
+        okc = okc && hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking) == hipSuccess;
+        okc = okc && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    }
+    okc = okc && hipStreamCreateWithFlags(&h->copy_s, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 16; i++) okc = okc && hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
+    okc = okc && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 2; k++) {
+        okc = okc && hipEventCreateWithFlags(&h->ev_comp[k], hipEventDisableTiming) == hipSuccess;
+        okc = okc && hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!okc) { set_err(nullptr, "ft8rx_create: cannot create HIP streams/events"); ft8rx_destroy(h); return -2; }
     *out = h;
     return 0;
 }
