@@ -155,6 +155,26 @@ int  ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, con
 /* the handle's own device audio buffer ([max_frames][180000] int16) and a D2H copy helper (tests, tools) */
 int16_t* ft8rx_staging_audio(ft8rx_handle* h);
 int  ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes);
+/* ---- signal subtraction ------------------------------------------------------
+ * One decoded signal to remove: its 79 tones (Costas + Gray-coded codeword), refined frequency and start time.  96 bytes. */
+typedef struct {
+    double  fHz, tsec;               /* candidate origin after fine sync (receiver.py:166) */
+    uint8_t tones[79];
+    uint8_t pad;
+} ft8rx_subsig;
+/* Stands in for Receiver.subtract_signal of the reference's subtraction experiment (tests/pipeline/receiver_sub.py:380-402,
+ * with PyFT8/transmitter.py:41-70 for the GFSK model): for every frame, signals sigs[frame][0 .. counts[frame]) are subtracted in
+ * list order from a float32 working copy of the device-resident int16 audio; the residual is rounded back to int16 in place
+ * (d_audio is a device pointer).  audio_f32_out (host, optional, [n_frames][180000]) receives the float32 residual. */
+int  ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int n_frames, ft8rx_subsig* sigs, const int32_t* counts,
+                    int max_sigs, int refine, float* audio_f32_out);
+/* refine = 0: the given (fHz, tsec) are used as they are (the reference's arithmetic).  refine = 1 (extension): before a signal is
+ * subtracted its origin is re-estimated with the same signal model over all 79 symbols -- start sample within [-150, +20] ms and
+ * frequency within [-1.75, +5.75] Hz of the given values -- and `sigs` is updated with the refined origins.  (The decoder's
+ * tsec/fHz follow the search grid's conventions and sit ~75 ms / ~1.9 Hz off the true start; cancellation needs a few ms.) */
+/* 77-bit words -> the 79 transmitted tones (CRC-14, LDPC(174,91) encode, Gray map, Costas framing; reference
+ * transmitter.py:181-223 `encode_bits77`).  Host function, no GPU.  tones: [n][79]. */
+int  ft8rx_encode_tones(const uint64_t* msg_lo, const uint64_t* msg_hi, int n, uint8_t* tones);
 /* Page-locked host memory for audio handed to ft8rx_decode_batch: copies from it are true asynchronous DMA that overlaps the
  * kernels of earlier chunks (pageable memory works too, at a lower PCIe-inclusive rate).  Free with ft8rx_free_host. */
 void* ft8rx_alloc_host(ft8rx_handle* h, uint64_t bytes);

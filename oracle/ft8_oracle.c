@@ -918,3 +918,89 @@ int ft8o_decode_frame(const int16_t* audio, const ft8o_config* cfg, ft8o_cand* c
     ft8o_hash_free(fc.ht); free(grid); free(spec); free(st); free(seen); free(order);
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Signal subtraction.  Restates Receiver.subtract_signal (reference tests/pipeline/receiver_sub.py:380-402):
+ *   sig   = symbols_to_complex_audio(symbols, f_base = fHz - 0.5)              (PyFT8/transmitter.py:52-70, pulse :41-50)
+ *   s0    = int(12000 * tsec); only if s0 > 0 and the 151680 samples fit
+ *   y     = audio[s0 : s0+L] * conj(sig)                     (stored as complex64 in a 192000-sample zero-padded array)
+ *   A     = fft(y)[0:20]; everything else zeroed; the cos^2 "window" of :393-395 is the single value 1.0
+ *   a     = ifft(A)                                           (complex64)
+ *   audio[s0 : s0+L] = audio - 2 * real(a[:L] * sig)          (stored as float32)
+ * The two 192000-point FFTs are replaced by the 20 DFT bins they keep, evaluated directly in double precision (the
+ * reference's complex64 FFT differs from this by its own rounding, ~1e-6 of the signal amplitude).
+ * symbols_to_complex_audio: phase = running sum of dphi (= 2 pi / 1920 * sum_sym tone * pulse, pulse = 3-symbol erf shape, BT = 2)
+ * + 2 pi f n / 12000 over 81 symbol slots, plus the author's edge terms that add the half pulses of the first / last tone to
+ * the PHASE (not to dphi); the first and last slot are cut off; 240-sample raised-cosine ramps with cos(pi i / 239). */
+#define SUB_SPS 1920
+#define SUB_L (79 * SUB_SPS)
+static double g_sub_pulse[3 * SUB_SPS], g_sub_pc[3 * SUB_SPS];
+static int g_sub_init = 0;
+static void sub_init(void) {
+    if (g_sub_init) return;
+    const double c = M_PI * sqrt(2.0 / log(2.0)), bt = 2.0;
+    double acc = 0.0;
+    for (int i = 0; i < 3 * SUB_SPS; i++) {
+        const double tt = ((double)i - 1.5 * SUB_SPS) / SUB_SPS;
+        g_sub_pulse[i] = 0.5 * (erf(c * bt * (tt + 0.5)) - erf(c * bt * (tt - 0.5)));
+        acc += g_sub_pulse[i];
+        g_sub_pc[i] = acc;                                   /* inclusive running sum, as np.add.accumulate */
+    }
+    g_sub_init = 1;
+}
+/* phase (radians) of output sample m (0 <= m < 151680) of symbols_to_complex_audio */
+static double sub_phase(const uint8_t* tones, const double* cum /*[80]: sum of the tones before symbol i*/, double f_base, int m) {
+    const int n = m + SUB_SPS;                               /* index in the 81-slot array */
+    const double dphi_peak = 2.0 * M_PI / SUB_SPS;
+    int ih = n / SUB_SPS; if (ih > 78) ih = 78;
+    int il = ih - 2; if (il < 0) il = 0;
+    double acc = cum[il] * g_sub_pc[3 * SUB_SPS - 1];        /* symbols whose pulse is fully behind n */
+    for (int i = il; i <= ih; i++) {
+        int j = n - SUB_SPS * i; if (j > 3 * SUB_SPS - 1) j = 3 * SUB_SPS - 1;
+        acc += (double)tones[i] * g_sub_pc[j];
+    }
+    double phi = dphi_peak * acc + 2.0 * M_PI * f_base * (double)n / 12000.0;
+    if (n < 2 * SUB_SPS) phi += dphi_peak * g_sub_pulse[SUB_SPS + n] * (double)tones[0];
+    if (n >= 79 * SUB_SPS) phi += dphi_peak * g_sub_pulse[n - 79 * SUB_SPS] * (double)tones[78];
+    return phi;
+}
+int ft8o_subtract(float* audio, const uint8_t* tones, double fHz, double tsec) {
+    sub_init();
+    const int s0 = (int)(12000.0 * tsec);
+    if (!(s0 > 0 && s0 + SUB_L <= FT8O_NSAMP)) return 0;
+    const double f_base = fHz - 0.5;
+    double cum[80]; cum[0] = 0.0;
+    for (int i = 0; i < 79; i++) cum[i + 1] = cum[i] + (double)tones[i];
+    double* sr = (double*)malloc(sizeof(double) * SUB_L * 2);
+    double* si = sr + SUB_L;
+    double Ar[20], Ai[20];
+    for (int k = 0; k < 20; k++) { Ar[k] = 0.0; Ai[k] = 0.0; }
+    for (int m = 0; m < SUB_L; m++) {
+        const double phi = fmod(sub_phase(tones, cum, f_base, m), 2.0 * M_PI);
+        double amp = 1.0;
+        if (m < 240) amp = (1.0 - cos(M_PI * (double)m / 239.0)) / 2.0;
+        else if (m >= SUB_L - 240) amp = (1.0 + cos(M_PI * (double)(m - (SUB_L - 240)) / 239.0)) / 2.0;
+        sr[m] = amp * cos(phi); si[m] = amp * sin(phi);
+        /* y = x * conj(sig), rounded to complex64 as the reference stores it */
+        const double x = (double)audio[s0 + m];
+        const double yr = (double)(float)(x * sr[m]), yi = (double)(float)(-x * si[m]);
+        for (int k = 0; k < 20; k++) {
+            const double ang = -2.0 * M_PI * (double)(((long long)k * m) % 192000) / 192000.0;
+            const double c = cos(ang), s = sin(ang);
+            Ar[k] += yr * c - yi * s; Ai[k] += yr * s + yi * c;
+        }
+    }
+    for (int m = 0; m < SUB_L; m++) {
+        double ar = 0.0, ai = 0.0;
+        for (int k = 0; k < 20; k++) {
+            const double ang = 2.0 * M_PI * (double)(((long long)k * m) % 192000) / 192000.0;
+            const double c = cos(ang), s = sin(ang);
+            ar += Ar[k] * c - Ai[k] * s; ai += Ar[k] * s + Ai[k] * c;
+        }
+        ar = (double)(float)(ar / 192000.0); ai = (double)(float)(ai / 192000.0);          /* ifft output is complex64 */
+        audio[s0 + m] = (float)((double)audio[s0 + m] - 2.0 * (ar * sr[m] - ai * si[m]));
+    }
+    free(sr);
+    return 1;
+}

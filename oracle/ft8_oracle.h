@@ -94,6 +94,11 @@ int   ft8o_unpack77(void* hash, uint64_t lo, uint64_t hi, char out[3][16]);
 int   ft8o_decode_frame(const int16_t* audio, const ft8o_config* c, ft8o_cand* cands, int32_t* n_cands,
                         ft8o_event* log, int32_t log_cap, int32_t* n_log, ft8o_msg* msgs, int32_t msg_cap, int32_t* n_msgs);
 
+/* signal subtraction: Receiver.subtract_signal, reference tests/pipeline/receiver_sub.py:380-402, with
+ * symbols_to_complex_audio (PyFT8/transmitter.py:41-70).  audio = the receiver's float32 ring (180000 samples), modified in
+ * place; returns 1 if the signal was subtracted, 0 if the reference's guard (sig_s0 > 0, whole signal inside the buffer) fails. */
+int   ft8o_subtract(float* audio /*[180000]*/, const uint8_t* tones79, double fHz, double tsec);
+
 #ifdef __cplusplus
 }
 #endif

@@ -205,6 +205,16 @@ class HashTable:
             pass
 
 
+def subtract(audio_f32, tones79, fHz, tsec):
+    """In-place reference-style subtraction of one signal from a float32 180000-sample buffer; -> True if subtracted."""
+    assert audio_f32.dtype == np.float32 and audio_f32.shape == (NSAMP,) and audio_f32.flags.c_contiguous
+    t = np.ascontiguousarray(tones79, np.uint8)
+    assert t.shape == (79,)
+    f = lib().ft8o_subtract
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+    return bool(f(audio_f32.ctypes.data, t.ctypes.data, float(fHz), float(tsec)))
+
+
 def valid77(bits77):
     return bool(lib().ft8o_valid77(C.c_uint64(bits77 & (2 ** 64 - 1)), C.c_uint64(bits77 >> 64)))
 

@@ -31,6 +31,8 @@ EVENT_DTYPE = np.dtype([("msg_lo", "<u8"), ("msg_hi", "<u8"), ("cand", "<u2"), (
                         ("seq", "<u2"), ("valid", "<u2")])
 MESSAGE_DTYPE = np.dtype([("f", "S16", (3,)), ("cand", "<i2"), ("f0_idx", "<i2"), ("h0_idx", "<i2"), ("snr", "i1"), ("ttweak", "i1"),
                           ("ftweak", "i1"), ("ipass", "u1"), ("ap", "u1"), ("method", "u1"), ("fine", "u1"), ("pad", "u1", (3,))])
+SUBSIG_DTYPE = np.dtype([("fHz", "<f8"), ("tsec", "<f8"), ("tones", "u1", (79,)), ("pad", "u1")])
+assert SUBSIG_DTYPE.itemsize == 96
 assert RECORD_DTYPE.itemsize == 48 and EVENT_DTYPE.itemsize == 24 and MESSAGE_DTYPE.itemsize == 64
 
 ST_ACTIVE, ST_DECODED, ST_STOP_GRID_SD, ST_STOP_COSTAS, ST_STOP_FINE_SD, ST_EXHAUSTED = range(6)
@@ -276,6 +278,27 @@ class Handle:
         self._chk(lib().ft8rx_valid77(self._h, _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), len(lo), _ptr(out, C.c_int32)), "ft8rx_valid77")
         return out
 
+    def subtract(self, d_audio_ptr, n_frames, signals, return_float=False, refine=False, return_origins=False):
+        """Subtract decoded signals from device-resident int16 audio in place (ft8rx_subtract).
+        signals: per frame a list of (tones79, fHz, tsec), subtracted in list order.  -> float32 residual if return_float."""
+        B = int(n_frames)
+        ms = max(1, max((len(s) for s in signals), default=1))
+        arr = np.zeros((B, ms), SUBSIG_DTYPE)
+        cnt = np.zeros(B, np.int32)
+        for f, lst in enumerate(signals):
+            cnt[f] = len(lst)
+            for i, (tones, fHz, tsec) in enumerate(lst):
+                arr[f, i]["tones"] = np.asarray(tones, np.uint8)
+                arr[f, i]["fHz"], arr[f, i]["tsec"] = fHz, tsec
+        out = np.empty((B, NSAMP), np.float32) if return_float else None
+        L = lib()
+        L.ft8rx_subtract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self._chk(L.ft8rx_subtract(self._h, C.c_void_p(d_audio_ptr), B, arr.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32), ms,
+                                   int(bool(refine)), out.ctypes.data_as(C.c_void_p) if return_float else None), "ft8rx_subtract")
+        if return_origins:                 # (fHz, tsec) per signal after refinement
+            return out, [[(float(arr[f, i]["fHz"]), float(arr[f, i]["tsec"])) for i in range(cnt[f])] for f in range(B)]
+        return out
+
     def pinned_audio(self, n_frames):
         """int16 [n_frames, 180000] array in page-locked host memory (ft8rx_alloc_host): fill it and pass it to decode_batch for
         overlapped DMA.  The memory is released when the array (and every view of it) is garbage collected."""
@@ -345,6 +368,18 @@ def package_batch(rec, cnt, ev, evc, max_msgs=128, n_threads=None):
 
 
 _default = {}
+
+
+def encode_tones(msg_lo, msg_hi):
+    """77-bit words (as returned in records) -> uint8 [n, 79] tone sequences (ft8rx_encode_tones, host only)."""
+    lo = np.ascontiguousarray(msg_lo, np.uint64).ravel()
+    hi = np.ascontiguousarray(msg_hi, np.uint64).ravel()
+    out = np.zeros((len(lo), 79), np.uint8)
+    L = lib()
+    L.ft8rx_encode_tones.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    if L.ft8rx_encode_tones(lo.ctypes.data, hi.ctypes.data, len(lo), out.ctypes.data) != 0:
+        raise Ft8rxError("ft8rx_encode_tones failed")
+    return out
 
 
 def default_handle(max_frames=1):

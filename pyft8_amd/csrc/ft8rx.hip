@@ -38,6 +38,7 @@
 #include "kernels/fine_sync.hpp"
 #include "kernels/osd.hpp"
 #include "kernels/synth.hpp"
+#include "kernels/subtract.hpp"
 #include "kernels/probes.hpp"
 #include "host_messages.hpp"
 
@@ -73,6 +74,8 @@ struct ft8rx_handle {
     ft8rx_record* h_rec[2]; int32_t* h_cnt[2]; ft8rx_event* h_ev[2]; int32_t* h_evc[2];
     hipEvent_t ev_comp[2], ev_done[2];
     int slot_enq, slot_fetch, inflight, last_slot, slot_B[2];
+    // signal subtraction (extension, allocated on first use): float32 working copy, per-chunk partial sums, GFSK tables
+    float* d_wf; double2* d_part; double* d_pulse; double* d_pc; ft8rx_subsig* d_sigs; int32_t* d_sigcnt; int sig_cap;
     std::string err;
     bool profiling;
     std::vector<hipEvent_t> pev;
@@ -174,6 +177,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     h->copy_s = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
     for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
+    h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
     int rc = 0;
@@ -596,6 +600,94 @@ int ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t b
     if (!h || !dst || !d_src) return -1;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int B, ft8rx_subsig* sigs, const int32_t* counts, int max_sigs,
+                   int refine, float* audio_f32_out) {
+    if (!h || !d_audio || !sigs || !counts) return -1;
+    if (B < 1 || B > h->max_frames || max_sigs < 1 || max_sigs > 256) { set_err(h, "ft8rx_subtract: bad n_frames / max_sigs"); return -1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!h->d_wf) {              // first use: working buffers for max_frames frames and the GFSK pulse tables (transmitter.py:41-50)
+        const size_t MB = (size_t)h->max_frames;
+        int rc = dalloc(h, &h->d_wf, MB * FT8RX_NSAMP);
+        rc |= dalloc(h, &h->d_part, MB * SUB_NCH * 20);           // also holds the refinement scan: [SUB_MAXSHIFT][SUB_NCH] <= [SUB_NCH][20]
+        rc |= dalloc(h, &h->d_pulse, (size_t)5760);
+        rc |= dalloc(h, &h->d_pc, (size_t)5760);
+        rc |= dalloc(h, &h->d_sigcnt, MB);
+        if (rc) return -2;
+        std::vector<double> pulse(5760), pc(5760);
+        const double c = M_PI * sqrt(2.0 / log(2.0)), bt = 2.0;
+        double acc = 0.0;
+        for (int i = 0; i < 5760; i++) {
+            const double tt = ((double)i - 1.5 * 1920.0) / 1920.0;
+            pulse[i] = 0.5 * (erf(c * bt * (tt + 0.5)) - erf(c * bt * (tt - 0.5)));
+            acc += pulse[i]; pc[i] = acc;
+        }
+        HIPCHK(h, hipMemcpy(h->d_pulse, pulse.data(), sizeof(double) * 5760, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->d_pc, pc.data(), sizeof(double) * 5760, hipMemcpyHostToDevice));
+    }
+    if (h->sig_cap < max_sigs) {
+        ft8rx_subsig* p = nullptr;
+        if (dalloc(h, &p, (size_t)h->max_frames * max_sigs)) return -2;       // the smaller one stays in the handle's allocation list
+        h->d_sigs = p; h->sig_cap = max_sigs;
+    }
+    int nmax = 0;
+    for (int f = 0; f < B; f++) {
+        if (counts[f] < 0 || counts[f] > max_sigs) { set_err(h, "ft8rx_subtract: counts[%d] = %d outside [0, %d]", f, counts[f], max_sigs); return -1; }
+        if (counts[f] > nmax) nmax = counts[f];
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_sigs, sigs, sizeof(ft8rx_subsig) * (size_t)B * max_sigs, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_sigcnt, counts, sizeof(int32_t) * B, hipMemcpyHostToDevice, h->stream));
+    const size_t n = (size_t)B * FT8RX_NSAMP;
+    k_sub_to_f32<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(d_audio, h->d_wf, n);
+    const SubTables T{h->d_pulse, h->d_pc};
+    // refinement scans: coarse (10 ms / 0.25 Hz around the decoder's origin, which by the search-grid conventions sits ~75 ms late and
+    // ~1.9 Hz low), then fine (2.5 ms / 0.0625 Hz)
+    SubShifts coarse, fine;
+    coarse.n = 16; for (int i = 0; i < 16; i++) coarse.shift[i] = -1680 + 120 * i;          // -140 .. +10 ms
+    fine.n = 9;    for (int i = 0; i < 9; i++) fine.shift[i] = -120 + 30 * i;               // -10 .. +10 ms
+    for (int i = 9; i < SUB_MAXSHIFT; i++) fine.shift[i] = 0;
+    for (int s = 0; s < nmax; s++) {
+        if (refine) {
+            k_sub_scan<<<dim3(SUB_NCH, B, coarse.n), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, coarse, h->d_part);
+            k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, coarse, h->d_part, -1.0f, 0.0625f, 113);   // signal - model: -1 .. +6 Hz; the sum is coherent over 12.6 s, so the grid must be as fine as 1/16 Hz
+            k_sub_scan<<<dim3(SUB_NCH, B, fine.n), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, fine, h->d_part);
+            k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, fine, h->d_part, 0.4375f, 0.015625f, 9);   // around the +0.5 Hz the coarse step left
+        }
+        k_sub_accum<<<dim3(SUB_NCH, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);
+        k_sub_apply<<<dim3(SUB_NCH, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);
+    }
+    k_sub_to_i16<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(h->d_wf, d_audio, n);
+    HIPCHK(h, hipGetLastError());
+    if (audio_f32_out) HIPCHK(h, hipMemcpyAsync(audio_f32_out, h->d_wf, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    if (refine) HIPCHK(h, hipMemcpyAsync(sigs, h->d_sigs, sizeof(ft8rx_subsig) * (size_t)B * max_sigs, hipMemcpyDeviceToHost, h->stream));   // the refined origins
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ft8rx_encode_tones(const uint64_t* msg_lo, const uint64_t* msg_hi, int n, uint8_t* tones) {
+    if (!msg_lo || !msg_hi || !tones || n < 0) return -1;
+    static const uint8_t costas[7] = {3, 1, 4, 0, 6, 5, 2}, gray[8] = {0, 1, 3, 2, 5, 6, 4, 7};
+    for (int i = 0; i < n; i++) {
+        const uint64_t lo = msg_lo[i], hi = msg_hi[i] & 0x1FFFull;
+        const unsigned crc = ft8_crc14_serial_host(lo, hi);
+        uint64_t cw[3] = {0, 0, 0};                                    // codeword bit v at word v >> 6, bit v & 63
+        for (int r = 0; r < 91; r++) {                                 // message bit r: 77 message bits (bit 76 first), then the CRC
+            unsigned b;
+            if (r < 77) { const int pos = 76 - r; b = (unsigned)((pos >= 64 ? (hi >> (pos - 64)) : (lo >> pos)) & 1u); }
+            else b = (crc >> (13 - (r - 77))) & 1u;
+            if (b) { cw[0] ^= FT8_G0[r][0]; cw[1] ^= FT8_G0[r][1]; cw[2] ^= FT8_G0[r][2]; }
+        }
+        uint8_t* t = tones + (size_t)i * 79;
+        for (int k = 0; k < 7; k++) { t[k] = costas[k]; t[36 + k] = costas[k]; t[72 + k] = costas[k]; }
+        for (int sidx = 0; sidx < 58; sidx++) {
+            unsigned v = 0;
+            for (int b = 0; b < 3; b++) { const int bit = 3 * sidx + b; v = (v << 1) | (unsigned)((cw[bit >> 6] >> (bit & 63)) & 1ull); }
+            t[(sidx < 29 ? 7 : 14) + sidx] = gray[v];
+        }
+    }
     return 0;
 }
 

@@ -226,20 +226,69 @@ class Receiver:
         self.candidates = cands
         return cands
 
-    def decode_frames(self, audio_i16, cyclestart_strings=None, return_records=False):
-        """Decode B independent 15-s frames.  -> list (per frame) of message dicts in emit order."""
+    def decode_frames(self, audio_i16, cyclestart_strings=None, return_records=False, passes=1, subtract_min_snr=-10):
+        """Decode B independent 15-s frames.  -> list (per frame) of message dicts in emit order.
+
+        passes > 1 (extension): after each pass every newly decoded signal with SNR > subtract_min_snr is
+        re-encoded and subtracted from the frame on the GPU (ft8rx_subtract -- the arithmetic of the reference experiment's
+        Receiver.subtract_signal, tests/pipeline/receiver_sub.py:380-402, threshold :434) and the residual is decoded again;
+        messages found that way are appended with "_SUB" added to decode_notes (as the reference tags them, :131-132).  Unlike
+        the reference experiment -- which subtracts after every single decode, serially -- a pass subtracts all of a frame's
+        new decodes at once, so whole batches stay on the GPU."""
         audio = _as_frames(audio_i16)
         B = audio.shape[0]
         if B == 0:
             return ([], np.zeros((0, self.cfg.max_cands), _lib.RECORD_DTYPE), np.zeros(0, np.int32)) if return_records else []
-        rec, cnt, ev, evc = self._handle(B).decode_batch(audio)
+        h = self._handle(B)
+        rec, cnt, ev, evc = h.decode_batch(audio)
         # host message layer: native, multithreaded (ft8rx_package_batch); messages.package_frame is its Python twin
         msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc)
-        out = []
-        for f in range(B):
-            cs = cyclestart_strings[f] if cyclestart_strings is not None else "700101_000015"
-            out.append(_m.message_dicts(msgs[f], mcnt[f], cyclestart_string=cs, band=self.band, odd_even=0, on_message=self.on_message))
+        cs = [cyclestart_strings[f] if cyclestart_strings is not None else "700101_000015" for f in range(B)]
+        out = [_m.message_dicts(msgs[f], mcnt[f], cyclestart_string=cs[f], band=self.band, odd_even=0, on_message=self.on_message)
+               for f in range(B)]
+        seen = [{" ".join(d["msg_tuple"]) for d in out[f]} for f in range(B)]
+        for _ in range(1, int(passes)):
+            sigs = self._subtraction_list(msgs, mcnt, rec, subtract_min_snr)
+            if not any(sigs):
+                break
+            h.subtract(h.staging_ptr(), B, sigs, refine=True)    # decode_batch left the frames in the handle's device buffer
+            h.enqueue(h.staging_ptr(), B)
+            rec, cnt, ev, evc = h.fetch(B)
+            msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc)
+            keep = np.zeros(mcnt.shape, np.int32)
+            for f in range(B):
+                new = []
+                for i, d in enumerate(_m.message_dicts(msgs[f], mcnt[f], cyclestart_string=cs[f], band=self.band, odd_even=0)):
+                    t = " ".join(d["msg_tuple"])
+                    if t not in seen[f]:
+                        seen[f].add(t)
+                        d["decode_notes"] += "_SUB"
+                        new.append(d)
+                        msgs[f, keep[f]] = msgs[f, i]                # compact: only the new messages are subtracted next
+                        keep[f] += 1
+                        if self.on_message is not None:
+                            self.on_message(d)
+                out[f] += new
+            mcnt = keep
         return (out, rec, cnt) if return_records else out
+
+    @staticmethod
+    def _subtraction_list(msgs, mcnt, rec, min_snr):
+        """Per frame: (tones79, fHz, tsec) of every emitted message with snr > min_snr, in emit order."""
+        sigs = []
+        for f in range(len(mcnt)):
+            m = msgs[f, :mcnt[f]]
+            m = m[m["snr"] > min_snr]
+            if len(m) == 0:
+                sigs.append([])
+                continue
+            r = rec[f, m["cand"]]
+            tones = _lib.encode_tones(r["msg_lo"], r["msg_hi"])
+            fine = m["fine"] != 0
+            fHz = 3.125 * m["f0_idx"] + np.where(fine, m["ftweak"] / 16.0, 0.0)
+            tsec = m["h0_idx"] / 25.0 + np.where(fine, m["ttweak"] / 200.0, 0.0)
+            sigs.append([(tones[i], float(fHz[i]), float(tsec[i])) for i in range(len(m))])
+        return sigs
 
     def decode_frames_arrays(self, audio_i16, n_threads=None):
         """High-throughput variant of decode_frames: no Python dicts.  -> (messages[B, 128] of _lib.MESSAGE_DTYPE,

@@ -424,6 +424,77 @@ def test_result_slots_pipeline_order():
     store.close()
 
 
+def test_subtract_matches_reference_golden_and_oracle():
+    """SURVEY 8f-4 primitive: ft8rx_subtract vs the reference's Receiver.subtract_signal run in isolation
+    (tests/golden/subtract.npz, oracle/gen_golden_subtract.py) and vs the C oracle's restatement.  Floating-point stage:
+    tolerance 1e-4 of the audio's RMS (north star), measured ~1e-6; the int16 residual is the rounded float residual."""
+    from pyft8_amd import _lib, synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "subtract.npz"))
+    pos = g["pos"]
+    ncase = len(g["recipes"])
+    frames, sigs = [], []
+    for ci in range(ncase):
+        idx, ns, lo, hi = g["recipes"][ci]
+        frames.append(synth.make_frame(int(idx), n_signals=int(ns), snr_range=(lo, hi)))
+        sigs.append([(t, float(f), float(ts)) for t, f, ts in zip(g[f"c{ci}_tones"], g[f"c{ci}_fHz"], g[f"c{ci}_tsec"])])
+    frames = np.stack(frames)
+    h = _lib.Handle(max_frames=ncase)
+    h.decode_batch(frames)                                   # leaves the frames in the handle's device staging buffer
+    ptr = h.staging_ptr()
+    res = h.subtract(ptr, ncase, sigs, return_float=True)
+    back = h.download_audio(ptr, ncase)
+    for ci in range(ncase):
+        rms = float(g[f"c{ci}_stats"][0])
+        assert np.abs(res[ci][pos] - g[f"c{ci}_after"]).max() < 1e-4 * rms, ci          # vs the reference
+        want = frames[ci].astype(np.float32)
+        for t, f, ts in sigs[ci]:
+            O.subtract(want, t, f, ts)
+        assert np.abs(res[ci] - want).max() < 1e-4 * rms, ci                              # vs the oracle, every sample
+        assert np.array_equal(back[ci], np.clip(np.rint(res[ci]), -32768, 32767).astype(np.int16))
+    assert np.array_equal(back[3], frames[3])                # case 3: int(12000 tsec) = 0 -> nothing subtracted
+    assert abs(float(res[0].astype(np.float64).std()) - float(g["c0_stats"][1])) < 0.01
+    h.close()
+
+
+def test_multi_pass_decode_with_subtraction():
+    """Extension: decode -> subtract every decoded signal (origin refined on the GPU) -> decode the residual.
+    On device-generated frames with known truth: the refined origins hit the true start within 3 ms / 0.1 Hz, pass 1 is
+    unchanged, and the second pass adds several true decodes per frame without flooding false ones."""
+    from pyft8_amd import _lib, synth
+    from pyft8_amd.receiver import Receiver
+    n = 12
+    got = []
+    rx = Receiver("", got.append, max_frames=n)
+    h = rx._handle(n)
+    truth = h.synth_frames(h.staging_ptr(), 8200000, n, n_signals=50, snr_range=(-10.0, 10.0))
+    audio = h.download_audio(h.staging_ptr(), n)
+    want = [{t["msg"]: t for t in truth[f]} for f in range(n)]
+    one = rx.decode_frames(audio)
+    got.clear()
+    two = rx.decode_frames(audio, passes=2)
+    assert sum(len(x) for x in two) == len(got)                                    # every message went through on_message
+    t1 = t2 = f2 = 0
+    for f in range(n):
+        assert [d["all_txt_format"] for d in two[f][:len(one[f])]] == [d["all_txt_format"] for d in one[f]]     # pass 1 untouched
+        extra = two[f][len(one[f]):]
+        assert all(d["decode_notes"].endswith("_SUB") for d in extra) and not any(d["decode_notes"].endswith("_SUB") for d in one[f])
+        t1 += sum(" ".join(d["msg_tuple"]) in want[f] for d in one[f])
+        t2 += sum(" ".join(d["msg_tuple"]) in want[f] for d in two[f])
+        f2 += sum(" ".join(d["msg_tuple"]) not in want[f] for d in two[f])
+    assert t2 >= t1 + 5 * n and f2 <= 2 * n, (t1, t2, f2)
+    # origin refinement against truth
+    h.decode_batch(audio)
+    sigs, tr = [], []
+    for f in range(n):
+        keep = [d for d in one[f] if " ".join(d["msg_tuple"]) in want[f] and int(d["their_snr"]) > -10]
+        tr.append([want[f][" ".join(d["msg_tuple"])] for d in keep])
+        sigs.append([(synth.tones79(synth.pack77(*d["msg_tuple"])), d["fHz"], d["tsec"]) for d in keep])
+    _, orig = h.subtract(h.staging_ptr(), n, sigs, refine=True, return_origins=True)
+    dt = np.array([o[1] - t["t0"] for f in range(n) for o, t in zip(orig[f], tr[f])])
+    df = np.array([o[0] - t["f0"] for f in range(n) for o, t in zip(orig[f], tr[f])])
+    assert len(dt) > 15 * n and np.abs(dt).max() < 0.003 and np.abs(df).max() < 0.1, (np.abs(dt).max(), np.abs(df).max())
+
+
 def _decode_with(cfg_kw, audio):
     from pyft8_amd import _lib
     cfg = _lib.default_config(**cfg_kw)

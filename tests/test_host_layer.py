@@ -191,3 +191,28 @@ def test_messages_py_unpack_matches_reference_golden():
     for u in d["unpack"][:500]:
         m = decoders.unpack(int(u["bits77"], 16))
         assert (None if m is None else " ".join(m)) == u["result"], u
+
+
+def test_native_tone_encoder_matches_reference_transmitter():
+    """ft8rx_encode_tones (host, no GPU): CRC-14 + LDPC encode + Gray + Costas == the reference transmitter's encode_bits77 on the
+    220 messages of tests/golden/messages.json."""
+    from pyft8_amd import _lib
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "messages.json")))
+    words = [int(p["bits77"], 16) for p in d["pack"]]
+    t = _lib.encode_tones([w & (2 ** 64 - 1) for w in words], [w >> 64 for w in words])
+    assert ["".join(map(str, row)) for row in t] == [p["tones"] for p in d["pack"]]
+
+
+def test_oracle_subtract_matches_reference_golden():
+    """SURVEY 8f-4 primitive on the CPU: the oracle's restatement of Receiver.subtract_signal vs the reference run in isolation
+    (tests/golden/subtract.npz, oracle/gen_golden_subtract.py): < 1e-5 of the audio RMS at 16384 sampled positions per case."""
+    import oracle as O
+    from pyft8_amd import synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "subtract.npz"))
+    for ci in range(len(g["recipes"])):
+        idx, ns, lo, hi = g["recipes"][ci]
+        audio = synth.make_frame(int(idx), n_signals=int(ns), snr_range=(lo, hi)).astype(np.float32)
+        done = [O.subtract(audio, t, f, ts) for t, f, ts in zip(g[f"c{ci}_tones"], g[f"c{ci}_fHz"], g[f"c{ci}_tsec"])]
+        assert all(done) == (ci != 3)
+        assert np.abs(audio[g["pos"]] - g[f"c{ci}_after"]).max() < 1e-5 * g[f"c{ci}_stats"][0]
+        assert abs(audio.astype(np.float64).std() - g[f"c{ci}_stats"][1]) < 1e-3

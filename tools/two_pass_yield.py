@@ -1,0 +1,37 @@
+"""Decode yield of the subtraction extension on device-generated frames with known truth.
+Usage (GPU box): python tools/two_pass_yield.py [n_frames] [n_signals]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyft8_amd import _lib  # noqa: E402
+from pyft8_amd.receiver import Receiver  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    nsig = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    rx = Receiver("", None, max_frames=n)
+    h = rx._handle(n)
+    ptr = h.staging_ptr()
+    truth = h.synth_frames(ptr, 8100000, n, n_signals=nsig, snr_range=(-10.0, 10.0))
+    audio = h.download_audio(ptr, n)
+    want = [{t["msg"] for t in truth[f]} for f in range(n)]
+    print(f"{n} frames x {nsig} signals, -10..+10 dB")
+    print("passes  true decodes/frame  false/frame   s per batch")
+    for passes in (1, 2, 3):
+        rx.decode_frames(audio[:2], passes=passes)
+        t0 = time.perf_counter()
+        out = rx.decode_frames(audio, passes=passes)
+        dt = time.perf_counter() - t0
+        got = [{" ".join(d["msg_tuple"]) for d in out[f]} for f in range(n)]
+        true = sum(len(got[f] & want[f]) for f in range(n)) / n
+        false = sum(len(got[f] - want[f]) for f in range(n)) / n
+        print(f"{passes:6d} {true:19.2f} {false:12.2f} {dt:12.3f}")
+
+
+if __name__ == "__main__":
+    main()
