@@ -282,14 +282,20 @@ class Handle:
         """Subtract decoded signals from device-resident int16 audio in place (ft8rx_subtract).
         signals: per frame a list of (tones79, fHz, tsec), subtracted in list order.  -> float32 residual if return_float."""
         B = int(n_frames)
-        ms = max(1, max((len(s) for s in signals), default=1))
-        arr = np.zeros((B, ms), SUBSIG_DTYPE)
-        cnt = np.zeros(B, np.int32)
-        for f, lst in enumerate(signals):
-            cnt[f] = len(lst)
-            for i, (tones, fHz, tsec) in enumerate(lst):
-                arr[f, i]["tones"] = np.asarray(tones, np.uint8)
-                arr[f, i]["fHz"], arr[f, i]["tsec"] = fHz, tsec
+        if isinstance(signals, tuple):          # (array [B, max_sigs] of SUBSIG_DTYPE, counts [B]) -- the fast path
+            arr, cnt = signals
+            arr = np.ascontiguousarray(arr, SUBSIG_DTYPE)
+            cnt = np.ascontiguousarray(cnt, np.int32)
+            ms = arr.shape[1]
+        else:
+            ms = max(1, max((len(s) for s in signals), default=1))
+            arr = np.zeros((B, ms), SUBSIG_DTYPE)
+            cnt = np.zeros(B, np.int32)
+            for f, lst in enumerate(signals):
+                cnt[f] = len(lst)
+                for i, (tones, fHz, tsec) in enumerate(lst):
+                    arr[f, i]["tones"] = np.asarray(tones, np.uint8)
+                    arr[f, i]["fHz"], arr[f, i]["tsec"] = fHz, tsec
         out = np.empty((B, NSAMP), np.float32) if return_float else None
         L = lib()
         L.ft8rx_subtract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]

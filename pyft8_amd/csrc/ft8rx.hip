@@ -646,14 +646,15 @@ int ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int B, ft8rx_subsig* sigs,
     // refinement scans: coarse (10 ms / 0.25 Hz around the decoder's origin, which by the search-grid conventions sits ~75 ms late and
     // ~1.9 Hz low), then fine (2.5 ms / 0.0625 Hz)
     SubShifts coarse, fine;
+    coarse.stride = 1; fine.stride = 1;          // decimating the scan (tried 8 / 2) aliases neighbouring signals into the sum: 1 of 233 origins locked 70 ms off
     coarse.n = 16; for (int i = 0; i < 16; i++) coarse.shift[i] = -1680 + 120 * i;          // -140 .. +10 ms
     fine.n = 9;    for (int i = 0; i < 9; i++) fine.shift[i] = -120 + 30 * i;               // -10 .. +10 ms
     for (int i = 9; i < SUB_MAXSHIFT; i++) fine.shift[i] = 0;
     for (int s = 0; s < nmax; s++) {
         if (refine) {
-            k_sub_scan<<<dim3(SUB_NCH, B, coarse.n), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, coarse, h->d_part);
+            k_sub_scan<<<dim3(SUB_NCH, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, coarse, h->d_part);
             k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, coarse, h->d_part, -1.0f, 0.0625f, 113);   // signal - model: -1 .. +6 Hz; the sum is coherent over 12.6 s, so the grid must be as fine as 1/16 Hz
-            k_sub_scan<<<dim3(SUB_NCH, B, fine.n), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, fine, h->d_part);
+            k_sub_scan<<<dim3(SUB_NCH, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, fine, h->d_part);
             k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, fine, h->d_part, 0.4375f, 0.015625f, 9);   // around the +0.5 Hz the coarse step left
         }
         k_sub_accum<<<dim3(SUB_NCH, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);

@@ -132,33 +132,46 @@ __global__ __launch_bounds__(256) void k_sub_apply(float* __restrict__ wf, const
 // summed over the 128 chunks (k_sub_scan); k_sub_pick then evaluates |sum_c Y_c e^{-2 pi i df t_c}|^2 on a frequency grid and
 // moves the signal's (tsec, fHz) to the best (shift, df).
 #define SUB_MAXSHIFT 16
-struct SubShifts { int n; int shift[SUB_MAXSHIFT]; };          // start-sample shifts relative to int(12000 tsec)
+struct SubShifts { int n; int stride; int shift[SUB_MAXSHIFT]; };   // start-sample shifts relative to int(12000 tsec); the scan uses every
+                                                                  // stride-th sample (the despread signal is narrow-band: decoded signals have > 30 dB to spare)
 
 __global__ __launch_bounds__(256) void k_sub_scan(const float* __restrict__ wf, const ft8rx_subsig* __restrict__ sigs,
                                                   const int32_t* __restrict__ counts, int max_sigs, int s, SubTables T, SubShifts sh,
                                                   double2* __restrict__ scan /*[B][SUB_MAXSHIFT][SUB_NCH]*/) {
     __shared__ ft8rx_subsig S;
     __shared__ double cum[80];
-    __shared__ double2 red[4];
-    const int frame = blockIdx.y, ch = blockIdx.x, z = blockIdx.z, tid = threadIdx.x;
+    __shared__ double2 red[4][SUB_MAXSHIFT];
+    const int frame = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
     int s0;
     if (s >= counts[frame]) return;
     sub_setup(sigs, counts, max_sigs, s, frame, &S, cum, &s0);
-    s0 += sh.shift[z];
-    double2* out = scan + ((size_t)frame * SUB_MAXSHIFT + z) * SUB_NCH + ch;
-    if (!(s0 > 0 && s0 + SUB_L <= FT8RX_NSAMP)) { if (tid == 0) *out = make_double2(0.0, 0.0); return; }
-    const float* x = wf + (size_t)frame * FT8RX_NSAMP + s0;
-    double ar = 0.0, ai = 0.0;
-    for (int m = ch * SUB_CH + tid; m < (ch + 1) * SUB_CH; m += 256) {
+    // the model sample sig[m] does not depend on the shift: evaluate it once and correlate it with all shifted windows
+    double ar[SUB_MAXSHIFT], ai[SUB_MAXSHIFT];
+#pragma unroll
+    for (int z = 0; z < SUB_MAXSHIFT; z++) { ar[z] = 0.0; ai[z] = 0.0; }
+    const float* xf = wf + (size_t)frame * FT8RX_NSAMP;
+    for (int m = ch * SUB_CH + tid * sh.stride; m < (ch + 1) * SUB_CH; m += 256 * sh.stride) {
         float sr, si;
         sub_signal(S, cum, T, m, &sr, &si);
-        const float xv = x[m];
-        ar += (double)(xv * sr); ai -= (double)(xv * si);
+#pragma unroll
+        for (int z = 0; z < SUB_MAXSHIFT; z++) {
+            const int b0 = s0 + sh.shift[z];                         // wave-uniform
+            if (z < sh.n && b0 > 0 && b0 + SUB_L <= FT8RX_NSAMP) {
+                const float xv = xf[b0 + m];
+                ar[z] += (double)(xv * sr); ai[z] -= (double)(xv * si);
+            }
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) { ar += __shfl_xor(ar, o); ai += __shfl_xor(ai, o); }
-    if ((tid & 63) == 0) red[tid >> 6] = make_double2(ar, ai);
+#pragma unroll
+    for (int z = 0; z < SUB_MAXSHIFT; z++) {
+        double vr = ar[z], vi = ai[z];
+        for (int o = 32; o > 0; o >>= 1) { vr += __shfl_xor(vr, o); vi += __shfl_xor(vi, o); }
+        if ((tid & 63) == 0) red[tid >> 6][z] = make_double2(vr, vi);
+    }
     __syncthreads();
-    if (tid == 0) *out = make_double2((red[0].x + red[1].x) + (red[2].x + red[3].x), (red[0].y + red[1].y) + (red[2].y + red[3].y));
+    if (tid < sh.n)
+        scan[((size_t)frame * SUB_MAXSHIFT + tid) * SUB_NCH + ch] =
+            make_double2((red[0][tid].x + red[1][tid].x) + (red[2][tid].x + red[3][tid].x), (red[0][tid].y + red[1][tid].y) + (red[2][tid].y + red[3][tid].y));
 }
 
 // one block per frame: best (shift, df) of signal s; df on [df_lo, df_lo + ndf * df_step)
@@ -174,12 +187,14 @@ __global__ __launch_bounds__(256) void k_sub_pick(ft8rx_subsig* __restrict__ sig
         const float df = df_lo + df_step * (float)j;
         const double2* Y = scan + ((size_t)frame * SUB_MAXSHIFT + z) * SUB_NCH;
         float er = 0.0f, ei = 0.0f;
+        // e^{-2 pi i df t_c} at the chunk centres t_c = (c + 1/2) CH / 12000: one rotation step per chunk
+        float wr, wi, rr, ri;
+        sincosf(-6.28318531f * df * ((float)SUB_CH / 12000.0f), &wi, &wr);
+        sincosf(-6.28318531f * df * (0.5f * (float)SUB_CH / 12000.0f), &ri, &rr);
         for (int c = 0; c < SUB_NCH; c++) {
-            const float tc = ((float)c + 0.5f) * (float)SUB_CH / 12000.0f;              // chunk centre, seconds
-            float sn, cs;
-            sincosf(-6.28318531f * df * tc, &sn, &cs);
             const float yr = (float)Y[c].x, yi = (float)Y[c].y;
-            er += yr * cs - yi * sn; ei += yr * sn + yi * cs;
+            er += yr * rr - yi * ri; ei += yr * ri + yi * rr;
+            const float t = rr * wr - ri * wi; ri = rr * wi + ri * wr; rr = t;
         }
         const float e = er * er + ei * ei;
         if (e > be) { be = e; bi = idx; }

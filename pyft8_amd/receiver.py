@@ -249,7 +249,7 @@ class Receiver:
         seen = [{" ".join(d["msg_tuple"]) for d in out[f]} for f in range(B)]
         for _ in range(1, int(passes)):
             sigs = self._subtraction_list(msgs, mcnt, rec, subtract_min_snr)
-            if not any(sigs):
+            if not sigs[1].any():
                 break
             h.subtract(h.staging_ptr(), B, sigs, refine=True)    # decode_batch left the frames in the handle's device buffer
             h.enqueue(h.staging_ptr(), B)
@@ -274,21 +274,25 @@ class Receiver:
 
     @staticmethod
     def _subtraction_list(msgs, mcnt, rec, min_snr):
-        """Per frame: (tones79, fHz, tsec) of every emitted message with snr > min_snr, in emit order."""
-        sigs = []
-        for f in range(len(mcnt)):
-            m = msgs[f, :mcnt[f]]
-            m = m[m["snr"] > min_snr]
-            if len(m) == 0:
-                sigs.append([])
-                continue
-            r = rec[f, m["cand"]]
-            tones = _lib.encode_tones(r["msg_lo"], r["msg_hi"])
-            fine = m["fine"] != 0
-            fHz = 3.125 * m["f0_idx"] + np.where(fine, m["ftweak"] / 16.0, 0.0)
-            tsec = m["h0_idx"] / 25.0 + np.where(fine, m["ttweak"] / 200.0, 0.0)
-            sigs.append([(tones[i], float(fHz[i]), float(tsec[i])) for i in range(len(m))])
-        return sigs
+        """(signals[B, max] of _lib.SUBSIG_DTYPE, counts[B]): every emitted message with snr > min_snr, in emit order, with the
+        tones of its codeword and the decoder's origin (fHz, tsec as the message dict reports them)."""
+        B = len(mcnt)
+        col = np.arange(msgs.shape[1])[None, :]
+        sel = (col < np.asarray(mcnt)[:, None]) & (msgs["snr"] > min_snr)
+        cnt = sel.sum(axis=1).astype(np.int32)
+        ms = max(1, int(cnt.max()) if B else 1)
+        arr = np.zeros((B, ms), _lib.SUBSIG_DTYPE)
+        fi, mi = np.nonzero(sel)                                   # row-major: emit order within each frame
+        if len(fi) == 0:
+            return arr, cnt
+        m = msgs[fi, mi]
+        r = rec[fi, m["cand"]]
+        slot = np.concatenate([np.arange(c) for c in cnt])
+        fine = m["fine"] != 0
+        arr["tones"][fi, slot] = _lib.encode_tones(r["msg_lo"], r["msg_hi"])
+        arr["fHz"][fi, slot] = 3.125 * m["f0_idx"] + np.where(fine, m["ftweak"] / 16.0, 0.0)
+        arr["tsec"][fi, slot] = m["h0_idx"] / 25.0 + np.where(fine, m["ttweak"] / 200.0, 0.0)
+        return arr, cnt
 
     def decode_frames_arrays(self, audio_i16, n_threads=None):
         """High-throughput variant of decode_frames: no Python dicts.  -> (messages[B, 128] of _lib.MESSAGE_DTYPE,
