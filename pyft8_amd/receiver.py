@@ -226,7 +226,8 @@ class Receiver:
         self.candidates = cands
         return cands
 
-    def decode_frames(self, audio_i16, cyclestart_strings=None, return_records=False, passes=1, subtract_min_snr=-10):
+    def decode_frames(self, audio_i16, cyclestart_strings=None, return_records=False, passes=1, subtract_min_snr=-10,
+                      sub_pass_osd=True):
         """Decode B independent 15-s frames.  -> list (per frame) of message dicts in emit order.
 
         passes > 1 (extension): after each pass every newly decoded signal with SNR > subtract_min_snr is
@@ -234,7 +235,8 @@ class Receiver:
         Receiver.subtract_signal, tests/pipeline/receiver_sub.py:380-402, threshold :434) and the residual is decoded again;
         messages found that way are appended with "_SUB" added to decode_notes (as the reference tags them, :131-132).  Unlike
         the reference experiment -- which subtracts after every single decode, serially -- a pass subtracts all of a frame's
-        new decodes at once, so whole batches stay on the GPU."""
+        new decodes at once, so whole batches stay on the GPU.  sub_pass_osd=False drops OSD decodes (ipass 5/6: first CRC-valid
+        trial wins, the reference's source of false decodes) found in the later passes -- fewer false decodes, slightly less yield."""
         audio = _as_frames(audio_i16)
         B = audio.shape[0]
         if B == 0:
@@ -260,7 +262,7 @@ class Receiver:
                 new = []
                 for i, d in enumerate(_m.message_dicts(msgs[f], mcnt[f], cyclestart_string=cs[f], band=self.band, odd_even=0)):
                     t = " ".join(d["msg_tuple"])
-                    if t not in seen[f]:
+                    if t not in seen[f] and (sub_pass_osd or "OSD" not in d["decode_notes"]):
                         seen[f].add(t)
                         d["decode_notes"] += "_SUB"
                         new.append(d)

@@ -22,15 +22,15 @@ def main():
     want = [{t["msg"] for t in truth[f]} for f in range(n)]
     print(f"{n} frames x {nsig} signals, -10..+10 dB")
     print("passes  true decodes/frame  false/frame   s per batch")
-    for passes in (1, 2, 3):
+    for passes, osd in ((1, True), (2, True), (3, True), (2, False), (3, False)):
         rx.decode_frames(audio[:2], passes=passes)
         t0 = time.perf_counter()
-        out = rx.decode_frames(audio, passes=passes)
+        out = rx.decode_frames(audio, passes=passes, sub_pass_osd=osd)
         dt = time.perf_counter() - t0
         got = [{" ".join(d["msg_tuple"]) for d in out[f]} for f in range(n)]
         true = sum(len(got[f] & want[f]) for f in range(n)) / n
         false = sum(len(got[f] - want[f]) for f in range(n)) / n
-        print(f"{passes:6d} {true:19.2f} {false:12.2f} {dt:12.3f}")
+        print(f"{passes:6d} {true:19.2f} {false:12.2f} {dt:12.3f}" + ("" if osd else "   (no OSD decodes accepted in passes > 1)"))
 
 
 if __name__ == "__main__":
