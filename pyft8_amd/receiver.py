@@ -325,8 +325,9 @@ class Receiver:
         return out
 
 
-def decode_frames(audio_i16, on_message=None, **receiver_kwargs):
-    """decode_frames(audio_i16[B,180000], **receiver_kwargs) -> list[list[message dict]]  (SURVEY.md 8b)."""
+def decode_frames(audio_i16, on_message=None, passes=1, **receiver_kwargs):
+    """decode_frames(audio_i16[B,180000], **receiver_kwargs) -> list[list[message dict]]  (SURVEY.md 8b); passes > 1 adds the
+    subtraction passes of Receiver.decode_frames."""
     audio = _as_frames(audio_i16)
     rx = Receiver("", on_message, max_frames=max(1, audio.shape[0]), **receiver_kwargs)
-    return rx.decode_frames(audio)
+    return rx.decode_frames(audio, passes=passes)
