@@ -30,6 +30,7 @@ def main():
     t0 = time.time()
     n = 0
     rss0 = None
+    dev = None
     while time.time() - t0 < budget:
         B = int(rng.choice([1, 2, 7, 8, 16, 33, 48]))
         ns = int(rng.choice([1, 2, 4, 8]))
@@ -38,8 +39,21 @@ def main():
             h.close()
             h = _lib.Handle(max_frames=48)
         h.set_streams(ns)
-        got = digest(h.decode_batch(frames[start:start + B]))
-        assert got == ref[start:start + B], (B, ns, start)
+        mode = int(rng.integers(0, 3))
+        if mode == 0:                                   # synchronous host-pointer entry
+            got = digest(h.decode_batch(frames[start:start + B]))
+            assert got == ref[start:start + B], (B, ns, start)
+        else:                                           # device-resident, pipelined: two batches in flight, fetched oldest first
+            if dev is None:
+                dev = _lib.Handle(max_frames=48)        # its staging buffer holds the frames on the device
+                dev.decode_batch(frames)
+            base = dev.staging_ptr()
+            s2 = int(rng.integers(0, 48 - B + 1))
+            h.enqueue(base + start * _lib.NSAMP * 2, B)
+            h.enqueue(base + s2 * _lib.NSAMP * 2, B)
+            assert digest(h.fetch(B)) == ref[start:start + B], ("pipelined", B, ns, start)
+            if mode == 1:
+                assert digest(h.fetch(B)) == ref[s2:s2 + B], ("pipelined 2", B, ns, s2)
         n += 1
         if n == 50:
             rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
