@@ -93,8 +93,8 @@ def cpu_baseline(frames, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 1: 256)")
     ap.add_argument("--unique", type=int, default=64, help="(host generator only) distinct frames generated per rank, tiled to --frames")
     ap.add_argument("--host-synth", action="store_true", help="generate frames with the numpy generator instead of the device kernel")
@@ -166,8 +166,8 @@ def main():
         for i in range(n):
             h.enqueue(d_audio.data_ptr(), B)
             if i > 0:
-                msgs = _lib.package_batch(*h.fetch(B), n_threads=pk_threads)
-        return _lib.package_batch(*h.fetch(B), n_threads=pk_threads)
+                msgs = _lib.package_batch(*h.fetch_view(B), n_threads=pk_threads)
+        return _lib.package_batch(*h.fetch_view(B), n_threads=pk_threads)
 
     if args.warmup:
         run_steps(args.warmup)

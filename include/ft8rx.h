@@ -105,6 +105,11 @@ int  ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int n_frames);
 int  ft8rx_sync(ft8rx_handle* h);
 int  ft8rx_fetch_results(ft8rx_handle* h, int n_frames, ft8rx_record* records, int32_t* counts,
                          ft8rx_event* events, int32_t* event_counts);
+/* Zero-copy variant of ft8rx_fetch_results: waits for the same batch and returns pointers INTO the handle's page-locked result
+ * buffers (records packed [n_frames][cfg.max_cands], events [n_frames][FT8RX_EVENT_CAP]).  They stay valid until two more
+ * batches have been enqueued (the slot is then reused). */
+int  ft8rx_fetch_results_view(ft8rx_handle* h, int n_frames, const ft8rx_record** records, const int32_t** counts,
+                              const ft8rx_event** events, const int32_t** event_counts);
 /* per-kernel HIP-event timing of the most recent enqueue (enable before enqueue). names/ms: up to 16 */
 /* number of HIP streams a batch is cut across (1..8, default 4); profiling mode always uses one */
 int  ft8rx_set_streams(ft8rx_handle* h, int n);

@@ -168,6 +168,21 @@ class Handle:
         self._chk(rc, "ft8rx_fetch_results")
         return rec, cnt, ev, evc
 
+    def fetch_view(self, B):
+        """Like fetch, without the copy: numpy views of the handle's page-locked result buffers (ft8rx_fetch_results_view).
+        Valid until two more batches have been enqueued."""
+        B = int(B)
+        p = [C.c_void_p() for _ in range(4)]
+        L = lib()
+        L.ft8rx_fetch_results_view.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4
+        self._chk(L.ft8rx_fetch_results_view(self._h, B, *[C.byref(x) for x in p]), "ft8rx_fetch_results_view")
+        mc = self.cfg.max_cands
+
+        def view(ptr, nbytes, dtype, shape):
+            return np.frombuffer((C.c_char * nbytes).from_address(ptr.value), dtype=dtype).reshape(shape)
+        return (view(p[0], B * mc * RECORD_DTYPE.itemsize, RECORD_DTYPE, (B, mc)), view(p[1], B * 4, np.int32, (B,)),
+                view(p[2], B * EVENT_CAP * EVENT_DTYPE.itemsize, EVENT_DTYPE, (B, EVENT_CAP)), view(p[3], B * 4, np.int32, (B,)))
+
     def set_streams(self, n):
         self._chk(lib().ft8rx_set_streams(self._h, int(n)), "ft8rx_set_streams")
 

@@ -419,6 +419,22 @@ int ft8rx_fetch_results(ft8rx_handle* h, int B, ft8rx_record* records, int32_t* 
     return 0;
 }
 
+int ft8rx_fetch_results_view(ft8rx_handle* h, int B, const ft8rx_record** records, const int32_t** counts,
+                             const ft8rx_event** events, const int32_t** event_counts) {
+    if (!h || B < 1 || B > h->max_frames) return -1;
+    if (h->last_slot < 0) { set_err(h, "ft8rx_fetch_results_view: nothing has been enqueued"); return -1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int slot = h->inflight ? h->slot_fetch : h->last_slot;
+    if (B > h->slot_B[slot]) { set_err(h, "ft8rx_fetch_results_view: %d frames requested, the batch had %d", B, h->slot_B[slot]); return -1; }
+    HIPCHK(h, hipEventSynchronize(h->ev_done[slot]));
+    if (records) *records = h->h_rec[slot];
+    if (counts) *counts = h->h_cnt[slot];
+    if (events) *events = h->h_ev[slot];
+    if (event_counts) *event_counts = h->h_evc[slot];
+    if (h->inflight) { h->slot_fetch ^= 1; h->inflight--; }
+    return 0;
+}
+
 int ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_record* records, int32_t* counts,
                        ft8rx_event* events, int32_t* event_counts) {
     if (!h || !audio) return -1;
