@@ -10,8 +10,8 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry --streams 1"
 
-timeout 900 python3 bench.py --steps 10 --warmup 3 > "$OUT/${TAG}_bench_b256_s4.json" 2> "$OUT/${TAG}_bench_b256_s4.err"
-timeout 600 python3 bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b256_s1.json" 2>> "$OUT/${TAG}_bench_b256_s4.err"
+timeout 900 python3 bench.py > "$OUT/${TAG}_bench_b256_s4.json" 2> "$OUT/${TAG}_bench_b256_s4.err"
+timeout 600 python3 bench.py --streams 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b256_s1.json" 2>> "$OUT/${TAG}_bench_b256_s4.err"
 
 rm -rf "$OUT/${TAG}_stats" "$OUT/${TAG}_pmcF" "$OUT/${TAG}_pmcW"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -o s -- $BENCH > "$OUT/${TAG}_stats.log" 2>&1
@@ -30,5 +30,6 @@ timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baselin
 timeout 900 python3 bench.py --frames 8192 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b8192.json" 2>> "$OUT/${TAG}_big.err"
 timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline --signals 8 --snr -24 -14 > "$OUT/${TAG}_bench_b4096_lowsnr.json" 2>> "$OUT/${TAG}_big.err"
 timeout 300 python3 tools/latency.py > "$OUT/${TAG}_latency.txt" 2>> "$OUT/${TAG}_big.err"
+timeout 600 python3 tools/two_pass_yield.py 256 50 2>&1 | tail -7 > "$OUT/${TAG}_multi_pass_yield.txt"
 timeout 1200 python3 tools/sensitivity.py 4096 > "$OUT/${TAG}_sensitivity_gpu.txt" 2>> "$OUT/${TAG}_big.err"
 ls -la "$OUT" | grep "${TAG}_" | head -40
