@@ -296,15 +296,49 @@ class Receiver:
         arr["tsec"][fi, slot] = m["h0_idx"] / 25.0 + np.where(fine, m["ttweak"] / 200.0, 0.0)
         return arr, cnt
 
-    def decode_frames_arrays(self, audio_i16, n_threads=None):
+    def decode_frames_arrays(self, audio_i16, n_threads=None, passes=1, subtract_min_snr=-10, sub_pass_osd=True):
         """High-throughput variant of decode_frames: no Python dicts.  -> (messages[B, 128] of _lib.MESSAGE_DTYPE,
-        counts[B], records[B, max_cands], record_counts[B]); rows are in the reference's emit order."""
+        counts[B], records[B, max_cands], record_counts[B]); rows are in the reference's emit order.  With passes > 1 (see
+        decode_frames) the messages of the later passes are appended per frame and carry the pass index (1, 2, ...) in
+        messages["pad"][:, :, 0]; the returned records are those of the first pass."""
         audio = _as_frames(audio_i16)
-        if audio.shape[0] == 0:
+        B = audio.shape[0]
+        if B == 0:
             raise _lib.Ft8rxError("empty batch")
-        rec, cnt, ev, evc = self._handle(audio.shape[0]).decode_batch(audio)
+        h = self._handle(B)
+        rec, cnt, ev, evc = h.decode_batch(audio)
         msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=n_threads)
-        return msgs, mcnt, rec, cnt
+        if passes <= 1:
+            return msgs, mcnt, rec, cnt
+        out, ocnt = msgs.copy(), mcnt.copy()
+        cur_m, cur_c, cur_rec = msgs, mcnt, rec
+        osd_methods = (_lib.M_OSD, _lib.M_LDPC_B_OSD)
+        for p in range(1, int(passes)):
+            sigs = self._subtraction_list(cur_m, cur_c, cur_rec, subtract_min_snr)
+            if not sigs[1].any():
+                break
+            h.subtract(h.staging_ptr(), B, sigs, refine=True)
+            h.enqueue(h.staging_ptr(), B)
+            rec2, cnt2, ev2, evc2 = h.fetch(B)
+            m2, c2 = _lib.package_batch(rec2, cnt2, ev2, evc2, n_threads=n_threads)
+            new_m = np.zeros_like(m2)
+            new_c = np.zeros_like(c2)
+            for f in range(B):
+                seen = set(out[f, :ocnt[f]]["f"].tobytes()[i * 48:(i + 1) * 48] for i in range(ocnt[f]))
+                for i in range(c2[f]):
+                    row = m2[f, i]
+                    key = row["f"].tobytes()
+                    if key in seen or (not sub_pass_osd and row["method"] in osd_methods) or ocnt[f] >= out.shape[1]:
+                        continue
+                    seen.add(key)
+                    row = row.copy()
+                    row["pad"][0] = p
+                    out[f, ocnt[f]] = row
+                    ocnt[f] += 1
+                    new_m[f, new_c[f]] = m2[f, i]
+                    new_c[f] += 1
+            cur_m, cur_c, cur_rec = new_m, new_c, rec2
+        return out, ocnt, rec, cnt
 
     def decode_frame(self, audio_i16, cyclestart_string="700101_000015"):
         return self.decode_frames(np.asarray(audio_i16)[None], [cyclestart_string])[0]
