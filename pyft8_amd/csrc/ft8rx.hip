@@ -668,13 +668,13 @@ int ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int B, ft8rx_subsig* sigs,
     for (int i = 9; i < SUB_MAXSHIFT; i++) fine.shift[i] = 0;
     for (int s = 0; s < nmax; s++) {
         if (refine) {
-            k_sub_scan<<<dim3(SUB_NCH, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, coarse, h->d_part);
+            k_sub_scan<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, coarse, h->d_part);
             k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, coarse, h->d_part, -1.0f, 0.0625f, 113);   // signal - model: -1 .. +6 Hz; the sum is coherent over 12.6 s, so the grid must be as fine as 1/16 Hz
-            k_sub_scan<<<dim3(SUB_NCH, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, fine, h->d_part);
+            k_sub_scan<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, fine, h->d_part);
             k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, fine, h->d_part, 0.4375f, 0.015625f, 9);   // around the +0.5 Hz the coarse step left
         }
-        k_sub_accum<<<dim3(SUB_NCH, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);
-        k_sub_apply<<<dim3(SUB_NCH, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);
+        k_sub_accum<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);
+        k_sub_apply<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);
     }
     k_sub_to_i16<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(h->d_wf, d_audio, n);
     HIPCHK(h, hipGetLastError());

@@ -33,21 +33,26 @@ FT8_DEV void sub_signal(const ft8rx_subsig& S, const double* __restrict__ cum /*
     double phi = dphi_peak * acc + 6.283185307179586 * (S.fHz - 0.5) * (double)n / 12000.0;
     if (n < 3840) phi += dphi_peak * T.pulse[1920 + n] * (double)S.tones[0];
     if (n >= 79 * 1920) phi += dphi_peak * T.pulse[n - 79 * 1920] * (double)S.tones[78];
-    phi -= 6.283185307179586 * floor(phi * (1.0 / 6.283185307179586));
-    float s, c;
-    sincosf((float)phi, &s, &c);
+    const double rev = phi * (1.0 / 6.283185307179586);           // revolutions; the hardware sin / cos take the fraction directly
+    const float fr = (float)(rev - floor(rev));
+    const float s = __builtin_amdgcn_sinf(fr), c = __builtin_amdgcn_cosf(fr);
     float amp = 1.0f;
     if (m < 240) amp = 0.5f * (1.0f - cosf(3.14159265f * (float)m / 239.0f));
     else if (m >= SUB_L - 240) amp = 0.5f * (1.0f + cosf(3.14159265f * (float)(m - (SUB_L - 240)) / 239.0f));
     *sr = amp * c; *si = amp * s;
 }
 
+// Work decomposition of the sample kernels: a block is 4 wavefronts; a wavefront owns SUB_CPW chunks and walks each with its 64
+// lanes (19 samples per lane), so per-chunk sums need only wave shuffles; the per-signal setup is paid once per 16 chunks.
+#define SUB_CPW 4
+#define SUB_GRIDX (SUB_NCH / (4 * SUB_CPW))
+
 FT8_DEV bool sub_setup(const ft8rx_subsig* __restrict__ sigs, const int32_t* __restrict__ counts, int max_sigs, int s, int frame,
                        ft8rx_subsig* S, double* cum, int* s0) {
     if (s >= counts[frame]) return false;
     if (threadIdx.x < 24) reinterpret_cast<uint32_t*>(S)[threadIdx.x] = reinterpret_cast<const uint32_t*>(sigs + (size_t)frame * max_sigs + s)[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x == 0) { double a = 0.0; cum[0] = 0.0; for (int i = 0; i < 79; i++) { a += (double)S->tones[i]; cum[i + 1] = a; } }
+    if (threadIdx.x < 80) { int a = 0; for (int i = 0; i < (int)threadIdx.x; i++) a += S->tones[i]; cum[threadIdx.x] = (double)a; }   // tones before symbol i
     __syncthreads();
     *s0 = (int)(12000.0 * S->tsec);
     return *s0 > 0 && *s0 + SUB_L <= FT8RX_NSAMP;                 // the reference's guard (receiver_sub.py:390) + "fits the buffer"
@@ -58,40 +63,35 @@ __global__ __launch_bounds__(256) void k_sub_accum(const float* __restrict__ wf,
                                                    double2* __restrict__ part /*[B][SUB_NCH][20]*/) {
     __shared__ ft8rx_subsig S;
     __shared__ double cum[80];
-    __shared__ double2 red[4][20];
-    const int frame = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int s0;
     if (!sub_setup(sigs, counts, max_sigs, s, frame, &S, cum, &s0)) return;
     const float* x = wf + (size_t)frame * FT8RX_NSAMP + s0;
-    double ar[20], ai[20];
+    for (int i = 0; i < SUB_CPW; i++) {
+        const int ch = (blockIdx.x * 4 + wave) * SUB_CPW + i;
+        float fr_[20], fi_[20];                                       // 19 terms per lane in fp32, the cross-lane sums in fp64
 #pragma unroll
-    for (int k = 0; k < 20; k++) { ar[k] = 0.0; ai[k] = 0.0; }
-    for (int m = ch * SUB_CH + tid; m < (ch + 1) * SUB_CH; m += 256) {
-        float sr, si;
-        sub_signal(S, cum, T, m, &sr, &si);
-        const float xv = x[m];
-        const float yr = xv * sr, yi = -(xv * si);                  // y = x conj(sig)  (complex64 in the reference)
-        float wr, wi;                                               // e^{-2 pi i m / 192000}
-        { float sn, cs; sincosf(-6.28318531f * (float)m * (1.0f / 192000.0f), &sn, &cs); wr = cs; wi = sn; }
-        float rr = 1.0f, ri = 0.0f;
+        for (int k = 0; k < 20; k++) { fr_[k] = 0.0f; fi_[k] = 0.0f; }
+        for (int m = ch * SUB_CH + lane; m < (ch + 1) * SUB_CH; m += 64) {
+            float sr, si;
+            sub_signal(S, cum, T, m, &sr, &si);
+            const float xv = x[m];
+            const float yr = xv * sr, yi = -(xv * si);              // y = x conj(sig)  (complex64 in the reference)
+            const float rv = (float)m * (1.0f / 192000.0f);        // e^{-2 pi i m / 192000}
+            const float wr = __builtin_amdgcn_cosf(rv), wi = -__builtin_amdgcn_sinf(rv);
+            float rr = 1.0f, ri = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 20; k++) {
-            ar[k] += (double)(yr * rr - yi * ri); ai[k] += (double)(yr * ri + yi * rr);
-            const float t = rr * wr - ri * wi; ri = rr * wi + ri * wr; rr = t;
+            for (int k = 0; k < 20; k++) {
+                fr_[k] += yr * rr - yi * ri; fi_[k] += yr * ri + yi * rr;
+                const float t = rr * wr - ri * wi; ri = rr * wi + ri * wr; rr = t;
+            }
         }
-    }
-    // block reduction in a fixed order: lanes by xor-shuffle, then the four wavefronts
 #pragma unroll
-    for (int k = 0; k < 20; k++) {
-        double vr = ar[k], vi = ai[k];
-        for (int o = 32; o > 0; o >>= 1) { vr += __shfl_xor(vr, o); vi += __shfl_xor(vi, o); }
-        if ((tid & 63) == 0) red[tid >> 6][k] = make_double2(vr, vi);
-    }
-    __syncthreads();
-    if (tid < 20) {
-        double2 v = red[0][tid];
-        for (int w = 1; w < 4; w++) { v.x += red[w][tid].x; v.y += red[w][tid].y; }
-        part[((size_t)frame * SUB_NCH + ch) * 20 + tid] = v;
+        for (int k = 0; k < 20; k++) {                                // fixed-order butterfly over the 64 lanes
+            double vr = (double)fr_[k], vi = (double)fi_[k];
+            for (int o = 32; o > 0; o >>= 1) { vr += __shfl_xor(vr, o); vi += __shfl_xor(vi, o); }
+            if (lane == k) part[((size_t)frame * SUB_NCH + ch) * 20 + k] = make_double2(vr, vi);
+        }
     }
 }
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_sub_apply(float* __restrict__ wf, const
     __shared__ ft8rx_subsig S;
     __shared__ double cum[80];
     __shared__ float Ar[20], Ai[20];
-    const int frame = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int s0;
     if (!sub_setup(sigs, counts, max_sigs, s, frame, &S, cum, &s0)) return;
     if (tid < 20) {
@@ -111,18 +111,21 @@ __global__ __launch_bounds__(256) void k_sub_apply(float* __restrict__ wf, const
     }
     __syncthreads();
     float* x = wf + (size_t)frame * FT8RX_NSAMP + s0;
-    for (int m = ch * SUB_CH + tid; m < (ch + 1) * SUB_CH; m += 256) {
-        float sr, si;
-        sub_signal(S, cum, T, m, &sr, &si);
-        float wr, wi;                                               // e^{+2 pi i m / 192000}
-        { float sn, cs; sincosf(6.28318531f * (float)m * (1.0f / 192000.0f), &sn, &cs); wr = cs; wi = sn; }
-        float rr = 1.0f, ri = 0.0f, er = 0.0f, ei = 0.0f;
+    for (int i = 0; i < SUB_CPW; i++) {
+        const int ch = (blockIdx.x * 4 + wave) * SUB_CPW + i;
+        for (int m = ch * SUB_CH + lane; m < (ch + 1) * SUB_CH; m += 64) {
+            float sr, si;
+            sub_signal(S, cum, T, m, &sr, &si);
+            const float rv = (float)m * (1.0f / 192000.0f);        // e^{+2 pi i m / 192000}
+            const float wr = __builtin_amdgcn_cosf(rv), wi = __builtin_amdgcn_sinf(rv);
+            float rr = 1.0f, ri = 0.0f, er = 0.0f, ei = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 20; k++) {
-            er += Ar[k] * rr - Ai[k] * ri; ei += Ar[k] * ri + Ai[k] * rr;
-            const float t = rr * wr - ri * wi; ri = rr * wi + ri * wr; rr = t;
+            for (int k = 0; k < 20; k++) {
+                er += Ar[k] * rr - Ai[k] * ri; ei += Ar[k] * ri + Ai[k] * rr;
+                const float t = rr * wr - ri * wi; ri = rr * wi + ri * wr; rr = t;
+            }
+            x[m] = x[m] - 2.0f * (er * sr - ei * si);
         }
-        x[m] = x[m] - 2.0f * (er * sr - ei * si);
     }
 }
 
@@ -132,46 +135,52 @@ __global__ __launch_bounds__(256) void k_sub_apply(float* __restrict__ wf, const
 // summed over the 128 chunks (k_sub_scan); k_sub_pick then evaluates |sum_c Y_c e^{-2 pi i df t_c}|^2 on a frequency grid and
 // moves the signal's (tsec, fHz) to the best (shift, df).
 #define SUB_MAXSHIFT 16
-struct SubShifts { int n; int stride; int shift[SUB_MAXSHIFT]; };   // start-sample shifts relative to int(12000 tsec); the scan uses every
-                                                                  // stride-th sample (the despread signal is narrow-band: decoded signals have > 30 dB to spare)
+#define SUB_MAXSPAN 1800
+struct SubShifts { int n; int stride; int shift[SUB_MAXSHIFT]; };   // start-sample shifts relative to int(12000 tsec); stride > 1 would
+                                                                  // decimate the scan (tried: it aliases neighbouring signals into the sums)
 
 __global__ __launch_bounds__(256) void k_sub_scan(const float* __restrict__ wf, const ft8rx_subsig* __restrict__ sigs,
                                                   const int32_t* __restrict__ counts, int max_sigs, int s, SubTables T, SubShifts sh,
                                                   double2* __restrict__ scan /*[B][SUB_MAXSHIFT][SUB_NCH]*/) {
     __shared__ ft8rx_subsig S;
     __shared__ double cum[80];
-    __shared__ double2 red[4][SUB_MAXSHIFT];
-    const int frame = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int s0;
     if (s >= counts[frame]) return;
     sub_setup(sigs, counts, max_sigs, s, frame, &S, cum, &s0);
-    // the model sample sig[m] does not depend on the shift: evaluate it once and correlate it with all shifted windows
-    double ar[SUB_MAXSHIFT], ai[SUB_MAXSHIFT];
-#pragma unroll
-    for (int z = 0; z < SUB_MAXSHIFT; z++) { ar[z] = 0.0; ai[z] = 0.0; }
     const float* xf = wf + (size_t)frame * FT8RX_NSAMP;
-    for (int m = ch * SUB_CH + tid * sh.stride; m < (ch + 1) * SUB_CH; m += 256 * sh.stride) {
-        float sr, si;
-        sub_signal(S, cum, T, m, &sr, &si);
+    __shared__ float xs[4][SUB_CH + SUB_MAXSPAN + 3];                // per wavefront: the audio its chunk sees under every shift
+    const int span = sh.shift[sh.n - 1] - sh.shift[0];               // shifts ascend; span <= SUB_MAXSPAN (host)
+    for (int i = 0; i < SUB_CPW; i++) {
+        const int ch = (blockIdx.x * 4 + wave) * SUB_CPW + i;
+        __syncthreads();                                              // the previous chunk's reads are done
+        const int g0 = s0 + sh.shift[0] + ch * SUB_CH;
+        for (int j = lane; j < SUB_CH + span; j += 64) { const int g = g0 + j; xs[wave][j] = (g >= 0 && g < FT8RX_NSAMP) ? xf[g] : 0.0f; }
+        __syncthreads();
+        // the model sample sig[m] does not depend on the shift: evaluate it once and correlate it with all shifted windows
+        float ar[SUB_MAXSHIFT], ai[SUB_MAXSHIFT];
 #pragma unroll
-        for (int z = 0; z < SUB_MAXSHIFT; z++) {
-            const int b0 = s0 + sh.shift[z];                         // wave-uniform
-            if (z < sh.n && b0 > 0 && b0 + SUB_L <= FT8RX_NSAMP) {
-                const float xv = xf[b0 + m];
-                ar[z] += (double)(xv * sr); ai[z] -= (double)(xv * si);
+        for (int z = 0; z < SUB_MAXSHIFT; z++) { ar[z] = 0.0f; ai[z] = 0.0f; }
+        for (int m = ch * SUB_CH + lane * sh.stride; m < (ch + 1) * SUB_CH; m += 64 * sh.stride) {
+            float sr, si;
+            sub_signal(S, cum, T, m, &sr, &si);
+            const float* xw = xs[wave] + (m - ch * SUB_CH) - sh.shift[0];
+#pragma unroll
+            for (int z = 0; z < SUB_MAXSHIFT; z++) {
+                const int b0 = s0 + sh.shift[z];                     // wave-uniform
+                if (z < sh.n && b0 > 0 && b0 + SUB_L <= FT8RX_NSAMP) {
+                    const float xv = xw[sh.shift[z]];
+                    ar[z] += xv * sr; ai[z] -= xv * si;
+                }
             }
         }
-    }
 #pragma unroll
-    for (int z = 0; z < SUB_MAXSHIFT; z++) {
-        double vr = ar[z], vi = ai[z];
-        for (int o = 32; o > 0; o >>= 1) { vr += __shfl_xor(vr, o); vi += __shfl_xor(vi, o); }
-        if ((tid & 63) == 0) red[tid >> 6][z] = make_double2(vr, vi);
+        for (int z = 0; z < SUB_MAXSHIFT; z++) {
+            double vr = (double)ar[z], vi = (double)ai[z];
+            for (int o = 32; o > 0; o >>= 1) { vr += __shfl_xor(vr, o); vi += __shfl_xor(vi, o); }
+            if (lane == z && z < sh.n) scan[((size_t)frame * SUB_MAXSHIFT + z) * SUB_NCH + ch] = make_double2(vr, vi);
+        }
     }
-    __syncthreads();
-    if (tid < sh.n)
-        scan[((size_t)frame * SUB_MAXSHIFT + tid) * SUB_NCH + ch] =
-            make_double2((red[0][tid].x + red[1][tid].x) + (red[2][tid].x + red[3][tid].x), (red[0][tid].y + red[1][tid].y) + (red[2][tid].y + red[3][tid].y));
 }
 
 // one block per frame: best (shift, df) of signal s; df on [df_lo, df_lo + ndf * df_step)
