@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def H():
     from pyft8_amd import _lib
-    h = _lib.Handle(max_frames=8)
+    h = _lib.Handle(max_frames=16)
     yield h
     h.close()
 
@@ -268,10 +268,17 @@ def test_edge_frames(H, ocfg):
     silence = np.zeros(180000, np.int16)
     noise = np.clip(np.rint(rng.standard_normal(180000) * 1000), -32768, 32767).astype(np.int16)
     loud = np.clip(np.rint(rng.standard_normal(180000) * 30000), -32768, 32767).astype(np.int16)
-    audio = np.stack([silence, noise, loud])
+    t = np.arange(180000)
+    tone = np.rint(12000 * np.sin(2 * np.pi * 1000.0 * t / 12000)).astype(np.int16)            # one bin, exact zeros elsewhere
+    nyq = np.where(t % 2 == 0, 32767, -32768).astype(np.int16)                                  # full-scale Nyquist
+    dc = np.full(180000, 12345, np.int16)
+    impulse = np.zeros(180000, np.int16); impulse[90000] = 32767
+    burst = noise.copy(); burst[60000:60480] = 32767                                            # one clipped hop
+    half = noise.copy(); half[90000:] = 0                                                       # audio stops mid-frame
+    audio = np.stack([silence, noise, loud, tone, nyq, dc, impulse, burst, half])
     rec, cnt, ev, evc = H.decode_batch(audio)
     assert cnt[0] == 0                       # digital silence: grid = -240 dB everywhere, no candidates
-    for i in (1, 2):
+    for i in range(1, len(audio)):           # every degenerate input: same candidates, records, events and messages as the oracle
         _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
 
 

@@ -87,3 +87,29 @@ def test_oracle_equals_reference_on_fresh_frame(k):
     if diff:
         print(f"frame {k}: {len(diff)} OSD-step unpack call(s) differ (argsort tie order): {diff}")
     assert len(diff) <= 4
+
+
+@pytest.mark.parametrize("name", ["silence", "tone", "nyquist", "dc", "impulse", "burst", "half"])
+def test_oracle_equals_reference_on_degenerate_input(name):
+    """Digital silence, a pure tone on a bin centre, full-scale Nyquist, DC, a single impulse, one clipped hop in noise, audio that
+    stops mid-frame: same candidates and (no) messages as the reference, which must not raise either."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from ref_harness import run_frame
+    rng = np.random.default_rng(9)
+    noise = np.clip(np.rint(rng.standard_normal(180000) * 1000), -32768, 32767).astype(np.int16)
+    t = np.arange(180000)
+    a = {"silence": np.zeros(180000, np.int16),
+         "tone": np.rint(12000 * np.sin(2 * np.pi * 1000.0 * t / 12000)).astype(np.int16),
+         "nyquist": np.where(t % 2 == 0, 32767, -32768).astype(np.int16),
+         "dc": np.full(180000, 12345, np.int16)}
+    a["impulse"] = np.zeros(180000, np.int16)
+    a["impulse"][90000] = 32767
+    a["burst"] = noise.copy()
+    a["burst"][60000:60480] = 32767
+    a["half"] = noise.copy()
+    a["half"][90000:] = 0
+    cands, tr, rx = run_frame(a[name])
+    r = O.decode_frame(a[name])
+    assert [(c.f0_idx, c.h0_idx) for c in r["cands"]] == [(f["f0_idx"], f["h0_idx"]) for f in tr.final]
+    assert [" ".join(m["msg_tuple"]) for m in r["msgs"]] == [" ".join(m["msg_tuple"]) for m in tr.messages]
+    assert r["n_events"] == len(tr.unpack_calls)
