@@ -207,6 +207,22 @@ def make_frame(index, n_signals=50, snr_range=(-10.0, 10.0), seed_base=SEED_BASE
     return (y, truth) if return_truth else y
 
 
+def frame_from_words(index, words77, snr_range=(0.0, 8.0), seed_base=SEED_BASE):
+    """A frame carrying the given 77-bit words (any message type the transmitter could send: i3 = 4 non-standard calls, hashed
+    calls, ...) evenly spread over 300..2700 Hz -- for parity tests of the message layer inside the whole pipeline."""
+    rng = np.random.Generator(np.random.Philox(key=seed_base + 77000000 + int(index)))
+    x = rng.standard_normal(NFRAME)
+    n = len(words77)
+    for k, w77 in enumerate(words77):
+        f0 = 300.0 + 2400.0 * (k + 0.5) / n + rng.uniform(-3.0, 3.0)
+        t0 = 0.5 + rng.uniform(-0.3, 0.8)
+        amp = np.sqrt(2.0 * (2500.0 / 6000.0) * 10.0 ** (rng.uniform(*snr_range) / 10.0))
+        w = tones_to_wave(tones79(int(w77)), f0)
+        i0 = int(round(t0 * FS))
+        x[i0:i0 + len(w)] += amp * w
+    return np.clip(np.rint(x * 1000.0), -32768, 32767).astype(np.int16)
+
+
 def make_batch(start, count, **kw):
     return np.stack([make_frame(start + i, **kw) for i in range(count)])
 

@@ -59,3 +59,29 @@ def load_golden(name):
 @pytest.fixture(params=GOLDEN_FRAMES)
 def golden(request):
     return (request.param,) + load_golden(request.param)
+
+
+def special_message_words():
+    """77-bit words of the reference-generated message golden that exercise the message layer beyond standard calls: i3 = 4
+    (non-standard call + hash), hashed calls in standard messages, /P and /R suffixes, CQ nnn / CQ AAAA, RRR/RR73/73, R-reports.
+    Ordered so that a hashed reference follows the message that defines the hash."""
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "messages.json")))
+    acc = [(int(u["bits77"], 16), u["result"]) for u in d["unpack"] if u["result"]]
+    pick, seen = [], set()
+    def take(pred, n):
+        k = 0
+        for w, r in acc:
+            if k >= n:
+                break
+            if w not in seen and pred(w, r):
+                seen.add(w); pick.append(w); k += 1
+    take(lambda w, r: (w & 7) == 4 and r.startswith("CQ "), 3)                       # CQ <nonstandard>
+    take(lambda w, r: (w & 7) == 4 and "<" in r, 4)                                   # <hash12> nonstandard RRR/RR73/73
+    take(lambda w, r: (w & 7) in (1, 2) and "<" in r, 3)                              # hash22 in a standard message
+    take(lambda w, r: "/P" in r, 3)
+    take(lambda w, r: "/R" in r, 3)
+    take(lambda w, r: r.startswith("CQ ") and len(r.split(" ")) > 3, 3)               # CQ nnn / CQ AAAA (directed)
+    take(lambda w, r: r.endswith(" RRR") or r.endswith(" 73"), 3)
+    take(lambda w, r: " R+" in r or " R-" in r, 3)
+    return pick

@@ -502,6 +502,23 @@ def test_multi_pass_decode_with_subtraction():
     assert len(dt) > 15 * n and np.abs(dt).max() < 0.003 and np.abs(df).max() < 0.1, (np.abs(dt).max(), np.abs(df).max())
 
 
+def test_special_message_types_through_the_pipeline(H, ocfg):
+    """Frames carrying i3 = 4 / hashed / suffixed / directed-CQ messages (words from the reference-generated message golden):
+    every record, event and rendered message equals the oracle's, and the special forms do come out."""
+    from conftest import special_message_words
+    from pyft8_amd import synth, messages as M
+    words = special_message_words()
+    assert len(words) >= 20
+    audio = np.stack([synth.frame_from_words(0, words), synth.frame_from_words(1, words[::-1], snr_range=(-8.0, 2.0))])
+    rec, cnt, ev, evc = H.decode_batch(audio)
+    texts = []
+    for i in range(2):
+        _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
+        texts += [" ".join(m["msg_tuple"]) for m in M.package_frame(rec[i], int(cnt[i]), ev[i], int(evc[i]))]
+    assert any("<" in t for t in texts) and any("/P" in t for t in texts) and any("/R" in t for t in texts)
+    assert sum(t.startswith("CQ ") for t in texts) >= 3
+
+
 def _decode_with(cfg_kw, audio):
     from pyft8_amd import _lib
     cfg = _lib.default_config(**cfg_kw)

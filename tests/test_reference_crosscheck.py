@@ -113,3 +113,21 @@ def test_oracle_equals_reference_on_degenerate_input(name):
     assert [(c.f0_idx, c.h0_idx) for c in r["cands"]] == [(f["f0_idx"], f["h0_idx"]) for f in tr.final]
     assert [" ".join(m["msg_tuple"]) for m in r["msgs"]] == [" ".join(m["msg_tuple"]) for m in tr.messages]
     assert r["n_events"] == len(tr.unpack_calls)
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_oracle_equals_reference_on_special_message_types(k):
+    """The frames of test_gpu_parity.test_special_message_types_through_the_pipeline decoded by the real reference: same messages in
+    the same order (hash resolution inside the frame included)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from ref_harness import run_frame
+    from conftest import special_message_words
+    from pyft8_amd import synth
+    words = special_message_words()
+    audio = synth.frame_from_words(0, words) if k == 0 else synth.frame_from_words(1, words[::-1], snr_range=(-8.0, 2.0))
+    cands, tr, rx = run_frame(audio)
+    r = O.decode_frame(audio)
+    assert [(c.f0_idx, c.h0_idx) for c in r["cands"]] == [(f["f0_idx"], f["h0_idx"]) for f in tr.final]
+    o_txt = [" ".join(m["msg_tuple"]) for m in r["msgs"]]
+    assert o_txt == [" ".join(m["msg_tuple"]) for m in tr.messages]
+    assert len(o_txt) >= 15 and any("<" in t for t in o_txt)
