@@ -1,6 +1,6 @@
 // ft8rx.hip -- MI355X (gfx950) FT8 receive hot path: HIP kernels + the C ABI of include/ft8rx.h.
 //
-// Pipeline for a batch of B independent 15-s frames (all stream-ordered on one HIP stream, no host
+// Pipeline for a batch of B independent 15-s frames (stream-ordered, no host
 // round trips; frames are the batch dimension, candidates the second one):
 //   k_spectrogram  (hop, frame)         Hann * 3840-pt real FFT (1920-pt complex Stockham in LDS) -> dB grid
 //   k_sync         (16-f0 tile, frame)  Costas correlation over all time offsets from an LDS tile
@@ -13,6 +13,9 @@
 //   k_bp           (candidate, AP)      GOOD91 + BP(90,20) with saved outputs
 //   k_select1, k_osd (candidate, slot) one wavefront: rank sort, register-resident GF(2) Gauss-Jordan
 //                                       with ballot pivoting, lane-per-trial CRC-14 + validity, k_select2
+// A batch is cut into chunks whose chains run on separate HIP streams; results land in one of two result slots and are copied to
+// page-locked host buffers by a copy stream while the next batch computes (launch_batch / ft8rx_fetch_results).
+// Extension: k_sub_scan / k_sub_pick / k_sub_accum / k_sub_apply subtract decoded signals (ft8rx_subtract).
 // Reference line citations are to PyFT8/receiver.py and PyFT8/decoders.py (see include/ft8rx.h).
 #include <hip/hip_runtime.h>
 #include <math.h>
