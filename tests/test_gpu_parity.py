@@ -500,6 +500,22 @@ def test_multi_pass_decode_with_subtraction():
     dt = np.array([o[1] - t["t0"] for f in range(n) for o, t in zip(orig[f], tr[f])])
     df = np.array([o[0] - t["f0"] for f in range(n) for o, t in zip(orig[f], tr[f])])
     assert len(dt) > 15 * n and np.abs(dt).max() < 0.003 and np.abs(df).max() < 0.1, (np.abs(dt).max(), np.abs(df).max())
+    # edge cases: nothing to subtract, a single frame, more passes than there is anything to find, a real recording, late signals
+    rx1 = Receiver("", None)
+    rng = np.random.default_rng(4)
+    noise = np.clip(np.rint(rng.standard_normal(180000) * 1000), -32768, 32767).astype(np.int16)
+    assert rx1.decode_frames(noise, passes=3) == [[]]
+    wav, gold, js = load_golden("test_09")
+    p1, p5 = rx1.decode_frames(wav), rx1.decode_frames(wav, passes=5)
+    assert [d["all_txt_format"] for d in p5[0][:len(p1[0])]] == [d["all_txt_format"] for d in p1[0]] and len(p5[0]) > len(p1[0])
+    m, c, rec, cnt = rx1.decode_frames_arrays(wav, passes=2)
+    assert c[0] > len(p1[0]) and set(m[0, :c[0]]["pad"][:, 0].tolist()) == {0, 1}
+    late = synth.tones_to_wave(synth.tones79(synth.pack77("CQ", "K1ABC", "FN42")), 1500.0)
+    x = noise.astype(np.float64)
+    x[30000:] += 3000.0 * late[:150000]                                        # starts at 2.5 s and is cut off by the end of the frame
+    lf = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    out = rx1.decode_frames(lf, passes=2)                                      # decodes; the subtraction guard skips it; no crash
+    assert [" ".join(d["msg_tuple"]) for d in out[0]][:1] == ["CQ K1ABC FN42"]
 
 
 def test_special_message_types_through_the_pipeline(H, ocfg):
