@@ -23,6 +23,19 @@ F=$(find "$OUT/${TAG}_pmcF" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/${TAG}_pmcW" -name '*counter_collection.csv' | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_pmc.json" "$OUT/${TAG}_pmc_b256.txt" > /dev/null
 
+# BASELINE config 2 as stated (4096 frames, BP 30 iterations, OSD depth 2 = osd_012(30, 2)): rocprofv3 kernel stats + PMC traffic
+B2="python3 bench.py --frames 4096 --steps 2 --warmup 1 --bp-iters 30 --no-cpu-baseline --no-host-entry --streams 1"
+rm -rf "$OUT/${TAG}_c2_stats" "$OUT/${TAG}_c2_pmcF" "$OUT/${TAG}_c2_pmcW"
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_c2_stats" -o s -- $B2 > "$OUT/${TAG}_c2_stats.log" 2>&1
+DB=$(find "$OUT/${TAG}_c2_stats" -name '*.db' | head -1)
+[ -n "$DB" ] && python3 tools/rocprof_summary.py "$DB" "$OUT/${TAG}_kernel_stats_b4096_config2.txt" > /dev/null
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_c2_pmcF" -o f -- $B2 > "$OUT/${TAG}_c2_pmcF.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_c2_pmcW" -o w -- $B2 > "$OUT/${TAG}_c2_pmcW.log" 2>&1
+F=$(find "$OUT/${TAG}_c2_pmcF" -name '*counter_collection.csv' | head -1)
+W=$(find "$OUT/${TAG}_c2_pmcW" -name '*counter_collection.csv' | head -1)
+[ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_c2_pmc.json" "$OUT/${TAG}_pmc_b4096_config2.txt" > /dev/null
+timeout 900 $B2 > "$OUT/${TAG}_bench_b4096_config2_bp30.json" 2>> "$OUT/${TAG}_big.err"
+
 # other BASELINE configurations (single GPU): config 2 (B = 4096; reference knobs and extension knobs), the config-3 shard
 # size (8192 frames per GPU) and config 4 (low SNR, few signals, truth-based decode probability)
 timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b4096_ref_knobs.json" 2> "$OUT/${TAG}_big.err"
