@@ -46,27 +46,47 @@ def test_oracle_equals_reference_on_fresh_frame(k):
     osc, rsc = {kk: c.score for kk, c in zip(ok, r["cands"])}, {kk: f["score"] for kk, f in zip(rk, tr.final)}
     for kk in ok:
         assert abs(osc[kk] - rsc[kk]) <= 1e-4 * abs(rsc[kk])
+    swapped = False
     for a, b in zip(ok, rk):
         if a != b:
+            swapped = True
             print(f"frame {k}: candidates {a} / {b} swapped (scores {rsc[a]!r} / {rsc[b]!r})")
             assert abs(rsc[a] - rsc[b]) <= 1e-6 * abs(rsc[a])
-    # messages: identical texts in identical emit order.  The only tolerated difference is an OSD decode (ipass 5/6) present on one
-    # side only, or the same text reported from a different duplicate candidate: the reference orders |llr| with numpy's UNSTABLE
-    # argsort and tied magnitudes are common (the three bits of a symbol often share one max-log difference), so which tied column
-    # enters the information set is numpy-build specific; the build fixes "ties by index" (DESIGN.md section 2).
+    # Per-candidate outcomes.  Candidates whose outcome differs are classified; everything else must agree exactly.
+    o_out = {kk: ((c.ipass, " ".join(O.HashTable().unpack(O.msg_int(c.msg_lo, c.msg_hi)) or ())) if c.status == 1 else None)
+             for kk, c in zip(ok, r["cands"])}
+    r_out = {kk: ((f["ipass"], " ".join(f["result"])) if f["result"] else None) for kk, f in zip(rk, tr.final)}
+    differing = [kk for kk in ok if (o_out[kk] is None) != (r_out[kk] is None) or (o_out[kk] and r_out[kk] and o_out[kk][0] != r_out[kk][0])]
+    for kk in differing:
+        stage = max((o_out[kk] or (0,))[0], (r_out[kk] or (0,))[0])
+        if stage >= 5 or (o_out[kk] is None and r_out[kk] is None):
+            # OSD steps: the reference orders |llr| with numpy's UNSTABLE argsort and tied magnitudes are common (the three bits of a
+            # symbol often share one max-log difference), so which tied column enters the information set is numpy-build specific;
+            # the build fixes "ties by index" 
+            print(f"frame {k}: candidate {kk}: OSD outcome differs (argsort tie order): oracle {o_out[kk]}, reference {r_out[kk]}")
+            continue
+        # before OSD: only a last-ulp threshold effect is legitimate -- the soft metrics must agree to 1e-4 and the hard decisions may
+        # differ only where the reference's LLR is itself ~0 (an exact 0.0 LLR = difference of two equal maxima NaN-poisons BP through
+        # the reference's 0/0, decoders.py:143-147, so one ulp of dB decides a decode)
+        i = ok.index(kk)
+        ref_llr = [np.array(c["llr_in"], np.float32) for c in tr.bp_calls if rk[c["cand"]] == kk and c["ipass"] == 0 and c["ap"] == "NoAP"]
+        assert ref_llr, (kk, o_out[kk], r_out[kk])
+        grid = O.spectrogram(audio, ocfg)
+        llr = O.db_to_llr(O.payload(grid, kk[0], kk[1]))[0]
+        assert np.abs(llr - ref_llr[0]).max() <= 1e-4 * np.abs(ref_llr[0]).max()
+        flips = np.nonzero((llr > 0) != (ref_llr[0] > 0))[0]
+        assert len(flips) and np.abs(ref_llr[0][flips]).max() < 1e-4 and np.abs(llr[flips]).max() < 1e-4
+        print(f"frame {k}: candidate {kk} (#{i}): LLR {flips.tolist()} is {llr[flips].tolist()} here and {ref_llr[0][flips].tolist()} in the "
+              f"reference -> outcome {o_out[kk]} vs {r_out[kk]} (last-ulp threshold effect)")
+    assert len(differing) <= 2
     o_txt = [" ".join(m["msg_tuple"]) for m in r["msgs"]]
     r_txt = [" ".join(m["msg_tuple"]) for m in tr.messages]
+    if not differing and not swapped:
+        assert o_txt == r_txt                                            # same messages, same emit order
     common = set(o_txt) & set(r_txt)
-    assert [t for t in o_txt if t in common] == [t for t in r_txt if t in common]
-    for m in r["msgs"]:
-        if " ".join(m["msg_tuple"]) not in common:
-            print(f"frame {k}: only the oracle decodes '{' '.join(m['msg_tuple'])}' ({O.notes_of(m)})")
-            assert "OSD" in O.notes_of(m)
-    for ref in tr.messages:
-        if " ".join(ref["msg_tuple"]) not in common:
-            print(f"frame {k}: only the reference decodes '{' '.join(ref['msg_tuple'])}' ({ref['decode_notes']})")
-            assert "OSD" in ref["decode_notes"]
-    assert len(set(o_txt) ^ set(r_txt)) <= 1
+    assert len(set(o_txt) ^ set(r_txt)) <= len(differing)
+    if not differing:
+        assert sorted(o_txt) == sorted(r_txt)
     by_txt = {" ".join(ref["msg_tuple"]): ref for ref in tr.messages}
     for m in r["msgs"]:
         ref = by_txt.get(" ".join(m["msg_tuple"]))
@@ -77,12 +97,14 @@ def test_oracle_equals_reference_on_fresh_frame(k):
         if not same:
             print(f"frame {k}: '{' '.join(m['msg_tuple'])}' reported by another candidate: oracle {O.notes_of(m)} {m['snr']:+03d}, "
                   f"reference {ref['decode_notes']} {ref['their_snr']}")
-            assert "OSD" in ref["decode_notes"] or "OSD" in O.notes_of(m)
-    # unpack() call sequence: exact up to ipass 4; in the OSD steps the two sides may differ by the few trial words the tie order
-    # decides (counted and reported)
+            assert differing
+    # unpack() call sequence: exact (as a multiset when two equal-score candidates swapped places) up to ipass 4 for the candidates that
+    # did not differ; in the OSD steps the two sides may differ by the few trial words the tie order decides (counted and reported)
     got = [(O.msg_int(e.msg_lo, e.msg_hi), ok[e.cand], e.ipass, bool(e.valid)) for e in r["events"]]
     ref = [(int(bits), rk[cand], ipass, res is not None) for bits, res, cand, ipass in tr.unpack_calls]
-    assert [g for g in got if g[2] < 5] == [x for x in ref if x[2] < 5]
+    g4 = [g for g in got if g[2] < 5 and g[1] not in differing]
+    r4 = [x for x in ref if x[2] < 5 and x[1] not in differing]
+    assert (sorted(g4) == sorted(r4)) if (swapped or differing) else (g4 == r4)
     diff = sorted(set(g for g in got if g[2] >= 5) ^ set(x for x in ref if x[2] >= 5))
     if diff:
         print(f"frame {k}: {len(diff)} OSD-step unpack call(s) differ (argsort tie order): {diff}")
