@@ -97,7 +97,7 @@ def test_oracle_equals_reference_on_fresh_frame(k):
         if not same:
             print(f"frame {k}: '{' '.join(m['msg_tuple'])}' reported by another candidate: oracle {O.notes_of(m)} {m['snr']:+03d}, "
                   f"reference {ref['decode_notes']} {ref['their_snr']}")
-            assert differing
+            assert differing or ("OSD" in ref["decode_notes"] and "OSD" in O.notes_of(m))     # e.g. another AP slot's OSD attempt won
     # unpack() call sequence: exact (as a multiset when two equal-score candidates swapped places) up to ipass 4 for the candidates that
     # did not differ; in the OSD steps the two sides may differ by the few trial words the tie order decides (counted and reported)
     got = [(O.msg_int(e.msg_lo, e.msg_hi), ok[e.cand], e.ipass, bool(e.valid)) for e in r["events"]]
