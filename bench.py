@@ -59,6 +59,21 @@ def pmc_traffic(kernel_stage, B):
     return sum(prof[n]["hbm_bytes"] for n in names)
 
 
+def per_kernel_hbm(acc, B):
+    """Measured HBM GB/s of every stage that has PMC traffic on file (B = 256 only): bytes per launch / HIP-event duration."""
+    if not os.path.exists(PMC_PROFILE) or B != 256:
+        return None
+    prof = json.load(open(PMC_PROFILE))
+    groups = {"spectrogram": ["k_spectrogram"], "sync": ["k_sync"], "grid_llr": ["k_grid_llr"], "cycle_fft": ["k_cyc_a", "k_cyc_b", "k_cyc_c"],
+              "fine": ["k_fine"], "osd": ["k_osd"]}
+    out = {}
+    for stage, names in groups.items():
+        if stage in acc and all(n in prof for n in names):
+            gbs = sum(prof[n]["hbm_bytes"] for n in names) / (acc[stage] * 1e-3) / 1e9
+            out[stage] = {"GB/s": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
 def _gen(args):
     from pyft8_amd import synth
     i, nsig, lo, hi = args
@@ -285,6 +300,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
                          "kernel_ms": dom_ms, "alg_bytes_per_launch": ALG_BYTES[dom] * B,
                          "whole_path_frac": value / world * ALG_BYTES_FRAME / 1e9 / HBM_PEAK_GBS,
+                         # measured HBM rate of each stage (PMC bytes / event time): the memory-bound stages sit near the roofline
+                         "per_stage_measured_hbm": per_kernel_hbm(acc, B),
                          # secondary figure SURVEY.md 8d asks for: the path is VALU/LDS/latency bound, not HBM bound
                          "valu": None if (args.signals, tuple(args.snr)) != (50, (-10.0, 10.0)) else {"unit": "TFLOP/s", "peak": VALU_PEAK_TFLOPS,
                                   "whole_path_achieved": value / world * ALG_FLOP_FRAME / 1e12,
