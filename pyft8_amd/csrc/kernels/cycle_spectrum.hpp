@@ -10,6 +10,7 @@ __global__ __launch_bounds__(256) void k_cyc_a(const int16_t* __restrict__ audio
     __shared__ cpx bufB[8 * 300];
     // XCD-aware tile mapping (workgroup id % 8 = XCD, gridDim.x = 40 = 8 * 5): one XCD takes 5 adjacent column tiles,
     // i.e. 160 contiguous bytes of every audio row, so the 128-B lines are shared inside one L2 instead of four.
+    static_assert(320 / 8 == 8 * 5, "the tile map below assumes 40 column tiles = 8 XCDs x 5");
     const int tile = (blockIdx.x & 7) * 5 + (blockIdx.x >> 3);
     const int f = blockIdx.y, tid = threadIdx.x, n2b = 8 * tile;
     const int16_t* a = audio + (size_t)f * FT8RX_NSAMP;

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(SPEC_NT) void k_spectrogram(const int16_t* __restri
     // XCD-aware hop mapping: workgroup id -> XCD is id % 8 and gridDim.x = 376 = 8 * 47, so the 47 workgroups of a
     // frame that land on one XCD take 47 consecutive hops: each XCD's L2 then sees one eighth of the frame's audio
     // (8x overlapping windows) instead of all of it.
+    static_assert(FT8RX_GRID_ROWS == 8 * 47, "the hop map below assumes gridDim.x = 376 = 8 XCDs x 47");
     const int hop = (blockIdx.x & 7) * 47 + (blockIdx.x >> 3) + 1, f = blockIdx.y, tid = threadIdx.x;
     if (hop > 375) return;
     spectrogram_hop(audio + (size_t)f * FT8RX_NSAMP, 480 * hop - 3840,
