@@ -4,10 +4,7 @@ import os
 import sys
 import time
 
-import numpy as np
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pyft8_amd import _lib  # noqa: E402
 from pyft8_amd.receiver import Receiver  # noqa: E402
 
 
