@@ -203,7 +203,7 @@ def main():
     # and the native host message layer (every message tuple rendered), pipelined: while batch k computes, the host fetches and
     # packages batch k-1.  All K batches are fully decoded to message arrays inside the timed region.
     cores = os.cpu_count() or 8
-    pk_threads = max(2, min(32, cores // (2 * max(1, world))))
+    pk_threads = max(2, min(32, cores // max(1, world)))
 
     def run_steps(n):
         msgs = None
