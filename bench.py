@@ -1,6 +1,10 @@
 """bench.py -- FT8 15-s frames decoded per second on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--frames B]
+    python bench.py --gpus N --steps K --warmup W [--frames B | --config 1|2|3|4]
+
+Launched as one process per GPU (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`); when --gpus N > 1
+is given WITHOUT a torchrun environment, bench.py starts that launcher itself as a child process (before anything touches the GPU)
+and exits with its code, so `python bench.py --gpus 8` is the 8-GPU run and never a mislabelled single-GPU one.
 
 One "step" = one pass of the whole receive hot path (spectrogram -> Costas sync -> LLR -> cycle FFT ->
 fine sync -> LDPC BP -> OSD -> records -> D2H -> host message layer: every message tuple rendered) over one
@@ -43,6 +47,10 @@ HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md
 ALG_FLOP_FRAME = 1.3e9
 ALG_FLOP_FINE = 0.78e9
 VALU_PEAK_TFLOPS = 157.3
+# executed fp32 operations of k_fine per candidate (counted from the kernel's butterflies): a pruned scoring IFFT
+# 150 k (sparse radix-8 pass 39 k + [4,4] stage 54 k + [5,5] stage with the last pass pruned 57 k), the full final IFFT 170 k, a
+# 32-point symbol DFT on a lane quad 0.6 k: 150 k + 56 x 0.6 k + 8 x (150 k + 7 x 0.6 k) + 170 k + 79 x 0.6 k
+EXEC_FLOP_FINE_CAND = 150e3 + 56 * 0.6e3 + 8 * (150e3 + 7 * 0.6e3) + 170e3 + 79 * 0.6e3
 PMC_PROFILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
                                                                   # command (tools/pmc_summary.py), B = 256
 
@@ -151,7 +159,37 @@ def main():
     ap.add_argument("--bp-iters", type=int, default=None, help="extension knob: iterations of the second BP stage (reference 20; config 2: 30)")
     ap.add_argument("--osd", type=int, nargs=2, default=None, metavar=("SINGLE", "DOUBLE"), help="extension knob: osd_012 flip counts (reference 30 2)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams a batch is cut across (1 = one chain of whole-batch launches)")
+    ap.add_argument("--config", type=int, default=None, choices=(1, 2, 3, 4), help="BASELINE.json configuration preset (per GPU): 1 = 256 frames; "
+                    "2 = 4096 frames, BP 30 iterations, OSD depth 2; 3 = 8192 frames per GPU (65 536 over 8 GPUs) + record gather; "
+                    "4 = 2048 frames per GPU (16 384 over 8), <= 10 signals at -24..-20 dB, OSD order 3")
+    ap.add_argument("--osd3", type=int, default=None, help="extension knob: OSD order-3 depth (triple flips over the first N basis positions; 0 = off)")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="after the K timed steps keep stepping (untimed for `value`, reported as "
+                    "extra_steps) until the GPU has been busy this long, so that coarse GPU-activity samplers see the run")
     args = ap.parse_args()
+    explicit = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+    if args.config is not None:
+        preset = {1: dict(frames=256), 2: dict(frames=4096, bp_iters=30, osd=(30, 2)), 3: dict(frames=8192),
+                  4: dict(frames=2048, signals=10, snr=(-24.0, -20.0), osd3=30)}[args.config]
+        for k, v in preset.items():
+            if "--" + k.replace("_", "-") not in explicit:
+                setattr(args, k, v)
+        if args.config >= 2 and "--steps" not in explicit:
+            args.steps, args.warmup = 3, 1
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # not under a launcher: start one as a CHILD process (nothing has touched the GPU yet) and pass its exit code on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if int(world_env or 1) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env or 1}: launch one process per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
     import torch
     import torch.distributed as dist
@@ -175,8 +213,10 @@ def main():
         cfg.bp_iters_b = args.bp_iters
     if args.osd is not None:
         cfg.osd_single, cfg.osd_double = args.osd
-    knobs = f"BP {cfg.bp_iters_a}/{cfg.bp_iters_b} iters, OSD {cfg.osd_single}/{cfg.osd_double}"
-    reference_knobs = (cfg.bp_iters_b, cfg.osd_single, cfg.osd_double) == (20, 30, 2)
+    if args.osd3 is not None:
+        cfg.osd_triple = args.osd3
+    knobs = f"BP {cfg.bp_iters_a}/{cfg.bp_iters_b} iters, OSD {cfg.osd_single}/{cfg.osd_double}" + (f"/order-3 over {cfg.osd_triple}" if cfg.osd_triple else "")
+    reference_knobs = (cfg.bp_iters_b, cfg.osd_single, cfg.osd_double, cfg.osd_triple) == (20, 30, 2, 0)
     h = _lib.Handle(cfg=cfg, device=local, max_frames=B)
     h.set_streams(args.streams)
     if args.host_synth:
@@ -222,6 +262,15 @@ def main():
     h.sync()
     barrier()
     dt = time.perf_counter() - t0
+    # keep the GPU busy for --min-seconds in total (identical steps, not part of `value`): a 0.16-s timed region is invisible to
+    # a GPU-activity sampler with a period of seconds
+    extra_steps, extra_dt = 0, 0.0
+    if args.min_seconds > dt:
+        n_more = max(1, int((args.min_seconds - dt) / (dt / args.steps)))
+        t_e = time.perf_counter()
+        run_steps(n_more)
+        h.sync()
+        extra_steps, extra_dt = n_more, time.perf_counter() - t_e
     # kernel-only rate (no D2H, no host layer), informational
     h.sync()
     t1 = time.perf_counter()
@@ -263,17 +312,26 @@ def main():
         pcie_pinned = 3 * B / (time.perf_counter() - t2)
         del host_audio, pinned
     n_dec = int(sum((rec[f][:cnt[f]]["status"] == 1).sum() for f in range(B)))
+    # candidates that ran the fine-sync kernel: everything not decoded / stopped on the grid LLRs (ipass 0)
+    valid = np.arange(rec.shape[1])[None, :] < cnt[:, None]
+    n_fine = int((valid & ~(((rec["status"] == 1) & (rec["ipass"] < 2)) | (rec["status"] == 2))).sum())
     n_msgs = sum(len(messages.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]))) for f in range(min(B, 16)))
 
     # gather path (RCCL): per-rank fixed-capacity record blocks to rank 0 -- off the timed path
     gather_note = "single rank"
     if world > 1:
-        from pyft8_amd.distributed import gather_results
+        from pyft8_amd.distributed import gather_results, gather_results_device
         try:
             t3 = time.perf_counter()
-            allres = gather_results(rec, cnt, ev, evc, dst=0)
+            if args.backend == "nccl":           # device-resident: D2D into torch buffers, RCCL gather over xGMI, one D2H on rank 0
+                allres = gather_results_device(h, B, dst=0)
+            else:
+                allres = gather_results(rec, cnt, ev, evc, dst=0)
             torch.cuda.synchronize()
-            gather_note = f"records/events of {world} ranks gathered to rank 0 over {args.backend} in {1e3 * (time.perf_counter() - t3):.1f} ms"
+            gather_note = (f"records/events of {world} ranks gathered to rank 0 over {args.backend}"
+                           f"{' (device-resident buffers)' if args.backend == 'nccl' else ''} in {1e3 * (time.perf_counter() - t3):.1f} ms")
+            if rank == 0 and not (np.array_equal(allres[1][:B], cnt) and np.array_equal(allres[0][:B], rec)):
+                gather_note = "gather mismatch: rank 0's own block differs from its local results"
             if rank == 0 and allres[0].shape[0] != world * B:
                 gather_note = f"gather returned {allres[0].shape[0]} frames, expected {world * B}"
         except Exception as e:                    # the gather is validation outside the timed region: report, do not lose the line
@@ -288,6 +346,10 @@ def main():
             "metric": "FT8 15-s frames decoded/sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # SURVEY 8d defines the metric as H2D + kernels + D2H + host unpack: the same batch handed over as HOST audio (page-locked),
+            # this rank only (PCIe inclusive; `value` has the audio resident in HBM as the bench contract asks)
+            "value_incl_h2d": pcie_pinned, "value_incl_h2d_pageable": pcie,
+            "extra_steps": extra_steps, "extra_steps_frames_per_s": (world * B * extra_steps / extra_dt) if extra_steps else None,
             "config": {"workload": f"{'config 1: ' if (B, args.signals, reference_knobs) == (256, 50, True) else ''}batch of {B} synthetic 15-s frames "
                                    f"per GPU ({data_desc}), {args.signals} signals/frame, {args.snr[0]:+.0f}..{args.snr[1]:+.0f} dB SNR, "
                                    f"{'Receiver defaults' if reference_knobs else 'extension knobs'} ({knobs})",
@@ -298,6 +360,8 @@ def main():
                        "host_pointer_entry_pinned_frames_per_s_incl_h2d_d2h": pcie_pinned, "parallelism": f"frames sharded over {world} GPU(s), no collective on the decode path", "gather": gather_note},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
+                         "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of this command at B = 256, "
+                                           "collected by tools/collect_profiles.sh; not measured in this run)" if pmc_traffic(dom, B) is not None else None,
                          "kernel_ms": dom_ms, "alg_bytes_per_launch": ALG_BYTES[dom] * B,
                          "whole_path_frac": value / world * ALG_BYTES_FRAME / 1e9 / HBM_PEAK_GBS,
                          # measured HBM rate of each stage (PMC bytes / event time): the memory-bound stages sit near the roofline
@@ -308,6 +372,12 @@ def main():
                                   "whole_path_frac": value / world * ALG_FLOP_FRAME / 1e12 / VALU_PEAK_TFLOPS,
                                   "fine_achieved": ALG_FLOP_FINE * B / (acc["fine"] * 1e-3) / 1e12,
                                   "fine_frac": ALG_FLOP_FINE * B / (acc["fine"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                                  # what k_fine really executes: EXEC_FLOP_FINE_CAND fp32 mul/add per candidate that reaches it (10 pruned
+                                  # IFFTs + symbol DFTs), no FMA => its ceiling is half the FMA peak
+                                  "fine_executed_flop_per_launch": EXEC_FLOP_FINE_CAND * n_fine,
+                                  "fine_executed_achieved": EXEC_FLOP_FINE_CAND * n_fine / (acc["fine"] * 1e-3) / 1e12,
+                                  "fine_executed_frac_of_nofma_peak": EXEC_FLOP_FINE_CAND * n_fine / (acc["fine"] * 1e-3) / 1e12 / (VALU_PEAK_TFLOPS / 2),
+                                  "fine_candidates_per_launch": n_fine,
                                   "note": "algorithmic fp32 flops of the reference-shaped dataflow (SURVEY 8d: 1.3 GFLOP/frame, "
                                           "fine sync 0.78 G of 18 full IFFTs); the kernels execute fewer (10 pruned IFFTs) and, by the "
                                           "bit-exact arithmetic contract, without FMA contraction"}},

@@ -37,6 +37,12 @@ typedef struct {
     int32_t bp_nc0_b, bp_iters_b;    /* 90, 20 : ldpc_decode(llr, 90, 20) (ipass 4) */
     int32_t osd_single, osd_double;  /* 30, 2  : osd_012(llr, 30, 2) */
     float   llr_sd_min;              /* 5 : Candidate.llr_sd_min */
+    /* Extension knobs with no reference counterpart (BASELINE config 4 "OSD depth-3"); 0 = off = the reference's osd_012. */
+    int32_t osd_triple;              /* 0 : order-3 reprocessing -- after the reference's trials, triple flips (i, j, k), k < j < i < osd_triple
+                                      *     over the least reliable basis positions, i-major; C(osd_triple, 3) extra trials (<= 40) */
+    int32_t osd_max_hd;              /* 0 : acceptance gate -- an OSD trial counts (and calls unpack) only if its 174-bit codeword differs from
+                                      *     the hard decisions in <= osd_max_hd positions.  The reference accepts the first CRC-valid trial
+                                      *     whatever its distance (decoders.py:248-272), which is where its false decodes come from. */
 } ft8rx_config;
 
 enum { FT8RX_ST_ACTIVE = 0, FT8RX_ST_DECODED = 1, FT8RX_ST_STOP_GRID_SD = 2, FT8RX_ST_STOP_COSTAS = 3,
@@ -51,7 +57,8 @@ typedef struct {
     int8_t   ttweak, ftweak, snr_grid, snr_fine;
     uint8_t  status, ipass, ap, method;
     int16_t  n_its;                  /* BP iteration index or OSD trial index of the success */
-    uint8_t  nsync, pad;
+    uint8_t  nsync;
+    uint8_t  osd_hd;                 /* OSD decodes: Hamming distance of the accepted codeword to the 174 hard decisions */
     uint32_t pad2;
 } ft8rx_record;
 
@@ -110,6 +117,11 @@ int  ft8rx_fetch_results(ft8rx_handle* h, int n_frames, ft8rx_record* records, i
  * batches have been enqueued (the slot is then reused). */
 int  ft8rx_fetch_results_view(ft8rx_handle* h, int n_frames, const ft8rx_record** records, const int32_t** counts,
                               const ft8rx_event** events, const int32_t** event_counts);
+/* Multi-GPU gather support: copies the LATEST batch's results, device to device, into caller-owned device buffers laid out like
+ * the host outputs of ft8rx_decode_batch (records packed [n_frames][cfg.max_cands]); waits for the batch first.  The caller hands
+ * these buffers to its collective (RCCL gather over xGMI, pyft8_amd/distributed.py) -- no host round trip.  Any pointer may be NULL. */
+int  ft8rx_results_to_device(ft8rx_handle* h, int n_frames, ft8rx_record* d_records, int32_t* d_counts,
+                             ft8rx_event* d_events, int32_t* d_event_counts);
 /* per-kernel HIP-event timing of the most recent enqueue (enable before enqueue). names/ms: up to 16 */
 /* number of HIP streams a batch is cut across (1..8, default 4); profiling mode always uses one */
 int  ft8rx_set_streams(ft8rx_handle* h, int n);
@@ -141,6 +153,10 @@ int  ft8rx_ldpc(ft8rx_handle* h, const float* llr, int n, int max_ncheck0, int m
 /* osd_012(llr, singleflips, doubleflips) (decoders.py:223-272) on n vectors */
 int  ft8rx_osd(ft8rx_handle* h, const float* llr, int n, int singleflips, int doubleflips,
                int32_t* ok, uint64_t* msg_lo, uint64_t* msg_hi, int32_t* trial);
+/* same with the build's extension knobs: tripleflips = order-3 depth, max_hd = acceptance gate (0 = off); hd[i] (optional) = the
+ * Hamming distance of the accepted codeword to the hard decisions */
+int  ft8rx_osd_ext(ft8rx_handle* h, const float* llr, int n, int singleflips, int doubleflips, int tripleflips, int max_hd,
+                   int32_t* ok, uint64_t* msg_lo, uint64_t* msg_hi, int32_t* trial, int32_t* hd);
 /* crc_unpack91 (decoders.py:117-131) on n x 91 soft/hard values: res 0 = no CRC, 1 = CRC ok but unpack None, 2 = tuple */
 int  ft8rx_crc_valid(ft8rx_handle* h, const float* cw91, int n, int32_t* res, uint64_t* msg_lo, uint64_t* msg_hi);
 /* unpack() validity predicate (decoders.py:16-115) on n 77-bit words */
@@ -153,10 +169,28 @@ int  ft8rx_synth_frames(ft8rx_handle* h, uint64_t seed, int first_index, int n_f
 /* Host message layer (pure host code, no GPU needed): replays each frame's records + events in the reference's emit
  * order -- hash-table side effects of every unpack() call (decoders.py:44,92; databases.py:10-26), duplicate filter
  * (receiver.py:51-66), round/llr_sd ordering of manage_cycle (receiver.py:389-398) -- and renders the message tuples.
- * records [n_frames][max_cands], events [n_frames][FT8RX_EVENT_CAP]; out [n_frames][max_msgs]; frames are spread over
- * n_threads host threads.  out_counts[f] may exceed max_msgs (truncated). */
+ * records [n_frames][max_cands], events [n_frames][FT8RX_EVENT_CAP]; out [n_frames][max_msgs]; out_counts[f] <= max_msgs.
+ *   table == NULL : every frame gets a fresh call-hash table (independent batched frames, the parity semantics of
+ *                   DESIGN.md section 1); frames are spread over n_threads host threads.
+ *   table != NULL : frames are replayed in order on the caller's thread against that persistent table, which they update --
+ *                   the reference's process-global `call_hashes` (databases.py:8): a hashed / non-standard call heard in
+ *                   cycle N resolves `<...>` in cycle N+1.  This is what the streaming receiver uses.
+ * flags (optional, [n_frames]): FT8RX_PKG_* bits per frame. */
+#define FT8RX_PKG_MSG_TRUNCATED    1   /* more than max_msgs messages: the list was cut (size max_msgs >= cfg.max_cands to rule it out) */
+#define FT8RX_PKG_EVENTS_TRUNCATED 2   /* event_counts[f] > FT8RX_EVENT_CAP: unpack() calls were dropped, `<...>` strings may differ */
+typedef struct ft8rx_hashes ft8rx_hashes;
 int  ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, const ft8rx_event* events, const int32_t* event_counts,
-                         int n_frames, int max_cands, ft8rx_message* out, int max_msgs, int32_t* out_counts, int n_threads);
+                         int n_frames, int max_cands, ft8rx_message* out, int max_msgs, int32_t* out_counts, int n_threads,
+                         ft8rx_hashes* table, int32_t* flags);
+/* the persistent call-hash table (databases.py:8-26 `call_hashes` + add_call_hashes) */
+ft8rx_hashes* ft8rx_hashes_create(void);
+void ft8rx_hashes_destroy(ft8rx_hashes* t);
+int  ft8rx_hashes_clear(ft8rx_hashes* t);
+int  ft8rx_hashes_add(ft8rx_hashes* t, const char* call);           /* add_call_hashes(call) */
+int  ft8rx_hashes_size(const ft8rx_hashes* t);                       /* number of (hash, nbits) keys */
+/* Optional reject log: with a path set, every callsign that fails the plausibility test is appended to that file, one per line,
+ * as the reference does unconditionally to ./rejected_callsigns.txt (decoders.py:114-115).  NULL or "" turns it off (default). */
+int  ft8rx_set_reject_log(const char* path);
 /* the handle's own device audio buffer ([max_frames][180000] int16) and a D2H copy helper (tests, tools) */
 int16_t* ft8rx_staging_audio(ft8rx_handle* h);
 int  ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes);

@@ -719,8 +719,22 @@ int ft8o_ldpc(float* llr, int max_nc0, int max_iters, uint64_t* lo, uint64_t* hi
 /* ------------------------------------------------------------------ OSD (decoders.py:223-272) */
 static void cw91_to_bits(const uint64_t* w, uint8_t* b91) { for (int k = 0; k < 91; k++) b91[k] = (uint8_t)((w[k >> 6] >> (k & 63)) & 1ULL); }
 
-static int osd_core(const float* llr, int singles, int doubles, accept_fn acc, void* ctx,
-                    uint64_t* lo, uint64_t* hi, int32_t* trial_out, int32_t* info_cols) {
+/* One OSD trial: codeword words w[3] (174 bits).  The extension gate (osd_max_hd > 0) drops the trial -- no unpack() call -- when the
+ * codeword is further than max_hd bit positions from the hard decisions hard[3]. */
+static int osd_trial(const uint64_t* w, const uint64_t* hard, int max_hd, accept_fn acc, void* ctx, int trial,
+                     uint64_t* lo, uint64_t* hi, int32_t* hd_out) {
+    const uint64_t M1 = (1ULL << 27) - 1, M2 = (1ULL << 46) - 1;
+    int hd = __builtin_popcountll(w[0] ^ hard[0]) + __builtin_popcountll(w[1] ^ hard[1]) + __builtin_popcountll((w[2] ^ hard[2]) & M2);
+    if (max_hd > 0 && hd > max_hd) return 0;
+    uint64_t m[2] = {w[0], w[1] & M1};
+    uint8_t b[91]; cw91_to_bits(m, b);
+    int r = crc_check_bits(b, acc, ctx, trial, lo, hi);
+    if (r == 2 && hd_out) *hd_out = hd;
+    return r;
+}
+
+static int osd_core(const float* llr, int singles, int doubles, int triples, int max_hd, accept_fn acc, void* ctx,
+                    uint64_t* lo, uint64_t* hi, int32_t* trial_out, int32_t* info_cols, int32_t* hd_out) {
     /* reliability order: |llr| descending, ties (and NaNs, last) by index -- the build's fixed tie rule
      * for np.argsort(-abs(llr)) (decoders.py:226, unstable in the reference) */
     int order[174];
@@ -747,32 +761,44 @@ static int osd_core(const float* llr, int singles, int doubles, accept_fn acc, v
         prow[k] = piv; pcol[k] = col; k++;
     }
     if (info_cols) for (int i = 0; i < 91; i++) info_cols[i] = (i < k) ? pcol[i] : -1;
-    uint64_t cw0[2] = {0, 0};
-    for (int i = 0; i < k; i++) if (llr[pcol[i]] > 0.0f) { cw0[0] ^= G[prow[i]][0]; cw0[1] ^= G[prow[i]][1]; }
-    const uint64_t M1 = (1ULL << 27) - 1;
+    uint64_t hard[3] = {0, 0, 0};
+    for (int v = 0; v < 174; v++) if (llr[v] > 0.0f) hard[v >> 6] |= 1ULL << (v & 63);
+    uint64_t cw0[3] = {0, 0, 0};
+    for (int i = 0; i < k; i++) if (llr[pcol[i]] > 0.0f) { cw0[0] ^= G[prow[i]][0]; cw0[1] ^= G[prow[i]][1]; cw0[2] ^= G[prow[i]][2]; }
     int trial = 0;
-    uint8_t b[91];
+#define FLIP(i) G[prow[90 - (i)]]
     /* order-0 */
-    { uint64_t w[2] = {cw0[0], cw0[1] & M1}; cw91_to_bits(w, b);
-      if (crc_check_bits(b, acc, ctx, trial, lo, hi) == 2) { *trial_out = trial; return 1; } }
+    if (osd_trial(cw0, hard, max_hd, acc, ctx, trial, lo, hi, hd_out) == 2) { *trial_out = trial; return 1; }
     trial++;
     for (int i = 0; i < singles; i++, trial++) {
-        const uint64_t* f = G[prow[90 - i]];
-        uint64_t w[2] = {cw0[0] ^ f[0], (cw0[1] ^ f[1]) & M1}; cw91_to_bits(w, b);
-        if (crc_check_bits(b, acc, ctx, trial, lo, hi) == 2) { *trial_out = trial; return 1; }
+        const uint64_t* f = FLIP(i);
+        uint64_t w[3] = {cw0[0] ^ f[0], cw0[1] ^ f[1], cw0[2] ^ f[2]};
+        if (osd_trial(w, hard, max_hd, acc, ctx, trial, lo, hi, hd_out) == 2) { *trial_out = trial; return 1; }
     }
     for (int i = 0; i < singles; i++) for (int j = 0; j < doubles; j++) if (j < i) {
-        const uint64_t* f = G[prow[90 - i]]; const uint64_t* g = G[prow[90 - j]];
-        uint64_t w[2] = {cw0[0] ^ f[0] ^ g[0], (cw0[1] ^ f[1] ^ g[1]) & M1}; cw91_to_bits(w, b);
-        if (crc_check_bits(b, acc, ctx, trial, lo, hi) == 2) { *trial_out = trial; return 1; }
+        const uint64_t* f = FLIP(i); const uint64_t* g = FLIP(j);
+        uint64_t w[3] = {cw0[0] ^ f[0] ^ g[0], cw0[1] ^ f[1] ^ g[1], cw0[2] ^ f[2] ^ g[2]};
+        if (osd_trial(w, hard, max_hd, acc, ctx, trial, lo, hi, hd_out) == 2) { *trial_out = trial; return 1; }
         trial++;
     }
+    /* extension: order-3 reprocessing over the `triples` least reliable basis positions (no reference counterpart) */
+    for (int i = 0; i < triples; i++) for (int j = 0; j < i; j++) for (int q = 0; q < j; q++) {
+        const uint64_t* f = FLIP(i); const uint64_t* g = FLIP(j); const uint64_t* e = FLIP(q);
+        uint64_t w[3] = {cw0[0] ^ f[0] ^ g[0] ^ e[0], cw0[1] ^ f[1] ^ g[1] ^ e[1], cw0[2] ^ f[2] ^ g[2] ^ e[2]};
+        if (osd_trial(w, hard, max_hd, acc, ctx, trial, lo, hi, hd_out) == 2) { *trial_out = trial; return 1; }
+        trial++;
+    }
+#undef FLIP
     *trial_out = -1;
     return 0;
 }
 
 int ft8o_osd(const float* llr, int singles, int doubles, uint64_t* lo, uint64_t* hi, int32_t* trial, int32_t* info_cols) {
-    return osd_core(llr, singles, doubles, accept_pure, NULL, lo, hi, trial, info_cols);
+    return osd_core(llr, singles, doubles, 0, 0, accept_pure, NULL, lo, hi, trial, info_cols, NULL);
+}
+int ft8o_osd_ext(const float* llr, int singles, int doubles, int triples, int max_hd, uint64_t* lo, uint64_t* hi, int32_t* trial,
+                 int32_t* info_cols, int32_t* hd_out) {
+    return osd_core(llr, singles, doubles, triples, max_hd, accept_pure, NULL, lo, hi, trial, info_cols, hd_out);
 }
 
 /* ------------------------------------------------------------------ whole frame (receiver.py:68-107, 338-367, 389-398) */
@@ -879,14 +905,14 @@ int ft8o_decode_frame(const int16_t* audio, const ft8o_config* cfg, ft8o_cand* c
                     fc.slot = ap;
                     ft8o_set_ap(s->llr0, ap, s->llr);
                     int32_t trial;
-                    if (osd_core(s->llr, cfg->osd_single, cfg->osd_double, accept_frame, &fc, &lo, &hi, &trial, NULL)) {
+                    if (osd_core(s->llr, cfg->osd_single, cfg->osd_double, cfg->osd_triple, cfg->osd_max_hd, accept_frame, &fc, &lo, &hi, &trial, NULL, NULL)) {
                         done = 1; c->method = FT8O_M_OSD; c->ap = ap; c->msg_lo = lo; c->msg_hi = hi; c->n_its = trial; }
                 }
             } else if (ip == 6) {
                 for (int k = 0; k < s->n_saved && !done; k++) {
                     fc.slot = 5 + s->saved_ap[k];
                     int32_t trial;
-                    if (osd_core(s->saved[k], cfg->osd_single, cfg->osd_double, accept_frame, &fc, &lo, &hi, &trial, NULL)) {
+                    if (osd_core(s->saved[k], cfg->osd_single, cfg->osd_double, cfg->osd_triple, cfg->osd_max_hd, accept_frame, &fc, &lo, &hi, &trial, NULL, NULL)) {
                         done = 1; c->method = FT8O_M_LDPC_B_OSD; c->ap = s->saved_ap[k]; c->msg_lo = lo; c->msg_hi = hi; c->n_its = trial; }
                 }
             } else {

@@ -25,6 +25,9 @@ typedef struct {
     int32_t bp_nc0_b, bp_iters_b;   /* 90, 20 (ipass 4) */
     int32_t osd_single, osd_double; /* 30, 2 */
     float llr_sd_min;       /* 5 */
+    /* extension knobs with no reference counterpart (BASELINE config 4 "OSD depth-3"); 0 = off = the reference's osd_012 */
+    int32_t osd_triple;     /* order-3 reprocessing: triple flips (i, j, k), k < j < i < osd_triple, i-major, tried after the reference's trials */
+    int32_t osd_max_hd;     /* acceptance gate: an OSD trial counts (and calls unpack) only if its 174-bit codeword differs from the hard decisions in <= this many positions */
     /* FFT radix plans (0-terminated).  The product exports its plans through the C ABI and the
      * parity tests hand them to the oracle, so both sides run the same butterfly sequence. */
     int32_t plan1920[8], plan3200[8], plan300[8], plan320[8];
@@ -84,6 +87,8 @@ int   ft8o_crc_valid91(const float* llr91, uint64_t* lo, uint64_t* hi); /* 0 fai
 int   ft8o_valid77(uint64_t lo, uint64_t hi);
 int   ft8o_ldpc(float* llr /* in/out */, int max_nc0, int max_iters, uint64_t* lo, uint64_t* hi,
                 int32_t* n_its, int32_t* has_out);
+int   ft8o_osd_ext(const float* llr, int singles, int doubles, int triples, int max_hd, uint64_t* lo, uint64_t* hi, int32_t* trial,
+                   int32_t* info_cols, int32_t* hd_out);
 int   ft8o_osd(const float* llr, int singles, int doubles, uint64_t* lo, uint64_t* hi, int32_t* trial,
                int32_t* info_cols /*[91] or NULL*/);
 /* hash table + rendering (reference decoders.py:16-115, databases.py:8-26) */

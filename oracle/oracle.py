@@ -18,6 +18,7 @@ class Config(C.Structure):
                 ("f0_lo", C.c_int32), ("f0_hi", C.c_int32), ("h0_lo", C.c_int32), ("h0_hi", C.c_int32),
                 ("bp_nc0_a", C.c_int32), ("bp_iters_a", C.c_int32), ("bp_nc0_b", C.c_int32), ("bp_iters_b", C.c_int32),
                 ("osd_single", C.c_int32), ("osd_double", C.c_int32), ("llr_sd_min", C.c_float),
+                ("osd_triple", C.c_int32), ("osd_max_hd", C.c_int32),
                 ("plan1920", C.c_int32 * 8), ("plan3200", C.c_int32 * 8), ("plan300", C.c_int32 * 8), ("plan320", C.c_int32 * 8)]
 
 
@@ -173,13 +174,16 @@ def ldpc(llr, max_nc0, max_iters):
     return bool(ok), (msg_int(lo.value, hi.value) if ok else None), (nits.value if ok else -1), (llr if has.value else None)
 
 
-def osd(llr, singles=30, doubles=2):
+def osd(llr, singles=30, doubles=2, triples=0, max_hd=0, want_hd=False):
+    """osd_012 (decoders.py:223-272); triples / max_hd are the build's order-3 and acceptance-gate extensions (0 = reference)."""
     llr = np.ascontiguousarray(llr, np.float32)
     lo, hi = C.c_uint64(), C.c_uint64()
-    trial = C.c_int32()
+    trial, hd = C.c_int32(), C.c_int32(-1)
     cols = np.zeros(91, np.int32)
-    ok = lib().ft8o_osd(_p(llr), int(singles), int(doubles), C.byref(lo), C.byref(hi), C.byref(trial), _p(cols, C.c_int32))
-    return bool(ok), (msg_int(lo.value, hi.value) if ok else None), trial.value, cols
+    ok = lib().ft8o_osd_ext(_p(llr), int(singles), int(doubles), int(triples), int(max_hd), C.byref(lo), C.byref(hi), C.byref(trial),
+                            _p(cols, C.c_int32), C.byref(hd))
+    out = (bool(ok), (msg_int(lo.value, hi.value) if ok else None), trial.value, cols)
+    return out + (hd.value,) if want_hd else out
 
 
 def crc_valid91(llr91):

@@ -10,7 +10,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FT8RX_LIB", os.path.join(HERE, "libft8rx.so"))   # FT8RX_LIB: A/B builds of the same ABI
 SRC = os.path.join(HERE, "csrc", "ft8rx.hip")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result",
+# -fno-slp-vectorize: on gfx950 a v_pk_add/mul_f32 issues at exactly the cost of the two scalar ops it replaces (tools/ubench/valu_rate.hip,
+# profiles/r02_valu_rate.txt) while the packing costs ~1000 extra v_mov in k_fine: scalar code is 7 % faster there, bit-identical.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-result",
                "-Wno-unused-value", "-fPIC", "-shared"]
 
 NSAMP, GRID_ROWS, GRID_COLS, SPEC_BINS, MAX_CANDS, EVENT_CAP = 180000, 376, 976, 49152, 256, 512
@@ -20,13 +22,14 @@ class Config(C.Structure):
     _fields_ = [("sync_score_min", C.c_float), ("max_cands", C.c_int32),
                 ("f0_lo", C.c_int32), ("f0_hi", C.c_int32), ("h0_lo", C.c_int32), ("h0_hi", C.c_int32),
                 ("bp_nc0_a", C.c_int32), ("bp_iters_a", C.c_int32), ("bp_nc0_b", C.c_int32), ("bp_iters_b", C.c_int32),
-                ("osd_single", C.c_int32), ("osd_double", C.c_int32), ("llr_sd_min", C.c_float)]
+                ("osd_single", C.c_int32), ("osd_double", C.c_int32), ("llr_sd_min", C.c_float),
+                ("osd_triple", C.c_int32), ("osd_max_hd", C.c_int32)]
 
 
 RECORD_DTYPE = np.dtype([("msg_lo", "<u8"), ("msg_hi", "<u8"), ("score", "<f4"), ("grid_sd", "<f4"), ("fine_sd", "<f4"),
                          ("f0_idx", "<i2"), ("h0_idx", "<i2"), ("ttweak", "i1"), ("ftweak", "i1"), ("snr_grid", "i1"),
                          ("snr_fine", "i1"), ("status", "u1"), ("ipass", "u1"), ("ap", "u1"), ("method", "u1"),
-                         ("n_its", "<i2"), ("nsync", "u1"), ("pad", "u1"), ("pad2", "<u4")])
+                         ("n_its", "<i2"), ("nsync", "u1"), ("osd_hd", "u1"), ("pad2", "<u4")])
 EVENT_DTYPE = np.dtype([("msg_lo", "<u8"), ("msg_hi", "<u8"), ("cand", "<u2"), ("ipass", "u1"), ("slot", "u1"),
                         ("seq", "<u2"), ("valid", "<u2")])
 MESSAGE_DTYPE = np.dtype([("f", "S16", (3,)), ("cand", "<i2"), ("f0_idx", "<i2"), ("h0_idx", "<i2"), ("snr", "i1"), ("ttweak", "i1"),
@@ -183,6 +186,13 @@ class Handle:
         return (view(p[0], B * mc * RECORD_DTYPE.itemsize, RECORD_DTYPE, (B, mc)), view(p[1], B * 4, np.int32, (B,)),
                 view(p[2], B * EVENT_CAP * EVENT_DTYPE.itemsize, EVENT_DTYPE, (B, EVENT_CAP)), view(p[3], B * 4, np.int32, (B,)))
 
+    def results_to_device(self, B, d_rec, d_cnt, d_ev, d_evc):
+        """Latest batch's results -> caller-owned device buffers (raw device pointers; ft8rx_results_to_device)."""
+        L = lib()
+        L.ft8rx_results_to_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        self._chk(L.ft8rx_results_to_device(self._h, int(B), C.c_void_p(d_rec), C.c_void_p(d_cnt), C.c_void_p(d_ev), C.c_void_p(d_evc)),
+                  "ft8rx_results_to_device")
+
     def set_streams(self, n):
         self._chk(lib().ft8rx_set_streams(self._h, int(n)), "ft8rx_set_streams")
 
@@ -270,14 +280,15 @@ class Handle:
                                    _ptr(out, C.c_float)), "ft8rx_ldpc")
         return ok, lo, hi, nits, has, out
 
-    def osd(self, llr, singleflips=30, doubleflips=2):
+    def osd(self, llr, singleflips=30, doubleflips=2, tripleflips=0, max_hd=0, want_hd=False):
         llr = np.ascontiguousarray(llr, np.float32).reshape(-1, 174)
         n = len(llr)
-        ok, trial = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        ok, trial, hd = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
         lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
-        self._chk(lib().ft8rx_osd(self._h, _ptr(llr, C.c_float), n, int(singleflips), int(doubleflips), _ptr(ok, C.c_int32),
-                                  _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), _ptr(trial, C.c_int32)), "ft8rx_osd")
-        return ok, lo, hi, trial
+        self._chk(lib().ft8rx_osd_ext(self._h, _ptr(llr, C.c_float), n, int(singleflips), int(doubleflips), int(tripleflips), int(max_hd),
+                                      _ptr(ok, C.c_int32), _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), _ptr(trial, C.c_int32),
+                                      _ptr(hd, C.c_int32)), "ft8rx_osd_ext")
+        return (ok, lo, hi, trial, hd) if want_hd else (ok, lo, hi, trial)
 
     def crc_valid(self, cw91):
         cw91 = np.ascontiguousarray(cw91, np.float32).reshape(-1, 91)
@@ -367,9 +378,58 @@ class Handle:
         return y
 
 
-def package_batch(rec, cnt, ev, evc, max_msgs=128, n_threads=None):
+PKG_MSG_TRUNCATED, PKG_EVENTS_TRUNCATED = 1, 2
+
+
+class Ft8rxTruncationWarning(RuntimeWarning):
+    """A frame's event log (FT8RX_EVENT_CAP) or message list overflowed: see include/ft8rx.h FT8RX_PKG_*."""
+
+
+class CallHashTable:
+    """Persistent native call-hash table (ft8rx_hashes_*; reference databases.py:8-26) for package_batch(table=...)."""
+
+    def __init__(self):
+        L = lib()
+        L.ft8rx_hashes_create.restype = C.c_void_p
+        L.ft8rx_hashes_destroy.argtypes = [C.c_void_p]
+        L.ft8rx_hashes_destroy.restype = None
+        L.ft8rx_hashes_clear.argtypes = [C.c_void_p]
+        L.ft8rx_hashes_add.argtypes = [C.c_void_p, C.c_char_p]
+        L.ft8rx_hashes_size.argtypes = [C.c_void_p]
+        self._t = C.c_void_p(L.ft8rx_hashes_create())
+        if not self._t.value:
+            raise Ft8rxError("ft8rx_hashes_create failed")
+
+    def add(self, call):
+        lib().ft8rx_hashes_add(self._t, call.encode())
+
+    def clear(self):
+        lib().ft8rx_hashes_clear(self._t)
+
+    def __len__(self):
+        return int(lib().ft8rx_hashes_size(self._t))
+
+    def __del__(self):
+        try:
+            if self._t.value:
+                lib().ft8rx_hashes_destroy(self._t)
+                self._t = C.c_void_p()
+        except Exception:
+            pass
+
+
+def set_reject_log(path):
+    """Turn the reference's rejected_callsigns.txt side effect (decoders.py:114-115) on (path) or off (None)."""
+    L = lib()
+    L.ft8rx_set_reject_log.argtypes = [C.c_char_p]
+    L.ft8rx_set_reject_log(path.encode() if path else None)
+
+
+def package_batch(rec, cnt, ev, evc, max_msgs=None, n_threads=None, table=None, return_flags=False):
     """Native host message layer (ft8rx_package_batch): records/events of B frames -> (messages[B, max_msgs], counts[B]).
-    Pure host code: works without a GPU."""
+    Pure host code: works without a GPU.  max_msgs defaults to the record capacity (so the list cannot be truncated); table = a
+    CallHashTable shared by the frames in order (streaming) instead of a fresh table per frame.  An overflowed event log or
+    message list raises Ft8rxTruncationWarning (warnings module) and is reported per frame in the flags (return_flags=True)."""
     rec = np.ascontiguousarray(rec)
     ev = np.ascontiguousarray(ev)
     cnt = np.ascontiguousarray(cnt, np.int32)
@@ -377,15 +437,26 @@ def package_batch(rec, cnt, ev, evc, max_msgs=128, n_threads=None):
     B, mc = rec.shape
     if ev.shape != (B, EVENT_CAP) or rec.dtype != RECORD_DTYPE or ev.dtype != EVENT_DTYPE:
         raise Ft8rxError("package_batch: records/events are not the arrays returned by decode_batch/fetch")
+    if max_msgs is None:
+        max_msgs = max(mc, 1)
     out = np.zeros((B, max_msgs), MESSAGE_DTYPE)
     oc = np.zeros(B, np.int32)
+    flags = np.zeros(B, np.int32)
     if n_threads is None:
         n_threads = min(32, os.cpu_count() or 1)
-    rc = lib().ft8rx_package_batch(rec.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32), ev.ctypes.data_as(C.c_void_p), _ptr(evc, C.c_int32),
-                                   int(B), int(mc), out.ctypes.data_as(C.c_void_p), int(max_msgs), _ptr(oc, C.c_int32), int(n_threads))
+    L = lib()
+    L.ft8rx_package_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_void_p]
+    rc = L.ft8rx_package_batch(rec.ctypes.data, cnt.ctypes.data, ev.ctypes.data, evc.ctypes.data, int(B), int(mc), out.ctypes.data,
+                               int(max_msgs), oc.ctypes.data, int(n_threads), table._t if table is not None else None, flags.ctypes.data)
     if rc != 0:
         raise Ft8rxError(f"ft8rx_package_batch failed ({rc})")
-    return out, oc
+    if flags.any():
+        import warnings
+        nev, nmsg = int((flags & PKG_EVENTS_TRUNCATED != 0).sum()), int((flags & PKG_MSG_TRUNCATED != 0).sum())
+        warnings.warn(f"package_batch: event log overflowed in {nev} frame(s) (> {EVENT_CAP} CRC-passing words: `<...>` strings may differ), "
+                      f"message list truncated in {nmsg} frame(s)", Ft8rxTruncationWarning, stacklevel=2)
+    return (out, oc, flags) if return_flags else (out, oc)
 
 
 _default = {}

@@ -251,18 +251,6 @@ FT8_DEV unsigned ft8_crc14(uint64_t lo, uint64_t hi) {
     for (int pos = 0; pos < 13; pos++) r ^= ((hi >> pos) & 1ull) ? (unsigned)d_CRC_SYN[64 + pos] : 0u;
     return r;
 }
-static inline unsigned ft8_crc14_serial_host(uint64_t lo, uint64_t hi) {
-    unsigned r = 0;
-    for (int i = 0; i < 96; i++) {
-        unsigned b = 0;
-        if (i < 77) { int pos = 76 - i; b = (unsigned)((pos >= 64 ? (hi >> (pos - 64)) : (lo >> pos)) & 1u); }
-        unsigned top = (r >> 13) & 1u;
-        r = ((r << 1) & 0x3FFFu) | b;
-        if (top) r ^= 0x2757u;
-    }
-    return r;
-}
-
 // 28-bit standard callsign plausibility (reference decoders.py:95-115); first = first character after strip
 FT8_DEV bool ft8_std_call_ok(uint32_t c28, char* first) {
     int64_t nn = (int64_t)c28 - (2063592 + 4194304);

@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <new>
 #include <string>
 #include <vector>
 #include "../../include/ft8rx.h"
@@ -48,6 +49,22 @@
 // ====================================================================================== host side
 #define HIPCHK(h, x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_err(h, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); return -2; } } while (0)
 
+// OSD trial list in the reference's order (decoders.py:248-272): order 0; single flips i < S; the restricted double flips
+// (i, j), i < S, j < min(i, D), i-major; then the build's order-3 extension (i, j, k), k < j < i < T, i-major.  One packed entry
+// per trial: i | j << 8 | k << 16, OSD_NONE for "no flip".
+static std::vector<uint32_t> osd_trial_table(int S, int D, int T) {
+    std::vector<uint32_t> t;
+    const uint32_t N = OSD_NONE;
+    t.push_back(N | (N << 8) | (N << 16));
+    for (int i = 0; i < S; i++) t.push_back((uint32_t)i | (N << 8) | (N << 16));
+    for (int i = 0; i < S; i++) for (int j = 0; j < D && j < i; j++) t.push_back((uint32_t)i | ((uint32_t)j << 8) | (N << 16));
+    for (int i = 0; i < T; i++) for (int j = 0; j < i; j++) for (int k = 0; k < j; k++) t.push_back((uint32_t)i | ((uint32_t)j << 8) | ((uint32_t)k << 16));
+    return t;
+}
+static int osd_nflip(int S, int T) { return S > T ? S : T; }
+
+struct ft8rx_hashes { hostmsg::Hashes H; };      // persistent call-hash table (databases.py:8): ft8rx_hashes_* in include/ft8rx.h
+
 static size_t sync_lds_bytes(const ft8rx_config& c) { const size_t nrows = (size_t)(c.h0_hi - c.h0_lo + 24); return nrows * 16 * sizeof(double) + (nrows * 29 + 512) * sizeof(float); }
 static std::string g_create_err;
 
@@ -62,6 +79,8 @@ struct ft8rx_handle {
     hipEvent_t ev_chunk[16];
     Tables T;
     std::vector<void*> allocs;
+    struct Chunk { void* p; size_t cap, used; };
+    std::vector<Chunk> arena;        // scratch of the stage entry points (struct Scratch)
     int16_t* d_audio;            // staging for host-pointer entry points
     float* d_grid;
     float* d_best_score; int32_t* d_best_h0;
@@ -70,6 +89,7 @@ struct ft8rx_handle {
     Att *d_att0, *d_attG, *d_attB, *d_attO;
     cpx *d_A, *d_Z, *d_spec;
     ft8rx_event* d_ev; int32_t* d_evcount;
+    const uint32_t* d_trials; int n_trials;      // OSD trial list of this configuration
     // Result slots.  A batch writes its records/events into slot k % 2 (slot 0 = d_rec/d_ncand/d_ev/d_evcount above) and, when its
     // kernels are done, the copy stream moves them into page-locked host buffers while the next batch computes into the other
     // slot; ft8rx_fetch_results hands out the oldest unfetched batch.  At most two batches' results are retained.
@@ -113,10 +133,23 @@ template <typename T> static int upload(ft8rx_handle* h, const T** dst, const st
     *dst = p; return 0;
 }
 
-struct Scratch {     // RAII device scratch for the test entry points
-    ft8rx_handle* h; std::vector<void*> p;
-    ~Scratch() { for (void* q : p) hipFree(q); }
-    template <typename T> T* get(size_t n) { void* q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T*)q; }
+// Device scratch of the stage entry points: bump allocation out of chunks the handle keeps (h->arena), so that after the first call
+// of a given size ft8rx_ldpc / ft8rx_osd / ... allocate nothing (the reference-style function API in pyft8_amd/decoders.py calls
+// them once per vector).  A Scratch object resets the arena when it goes out of scope; chunks are released by ft8rx_destroy.
+struct Scratch {
+    ft8rx_handle* h;
+    ~Scratch() { for (auto& c : h->arena) c.used = 0; }
+    void* raw(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (!bytes) bytes = 256;
+        for (auto& c : h->arena) if (c.cap - c.used >= bytes) { void* q = (char*)c.p + c.used; c.used += bytes; return q; }
+        const size_t cap = bytes > ((size_t)1 << 20) ? bytes : ((size_t)1 << 20);
+        void* q = nullptr;
+        if (hipMalloc(&q, cap) != hipSuccess) return nullptr;
+        h->arena.push_back({q, cap, bytes});
+        return q;
+    }
+    template <typename T> T* get(size_t n) { return (T*)raw(n * sizeof(T)); }
     template <typename T> T* put(const T* src, size_t n) { T* q = get<T>(n); if (q && hipMemcpy(q, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr; return q; }
 };
 
@@ -127,6 +160,7 @@ int ft8rx_default_config(ft8rx_config* c) {
     c->sync_score_min = 85.0f; c->max_cands = 200; c->f0_lo = 32; c->f0_hi = 960; c->h0_lo = -37; c->h0_hi = 87;
     c->bp_nc0_a = 35; c->bp_iters_a = 5; c->bp_nc0_b = 90; c->bp_iters_b = 20; c->osd_single = 30; c->osd_double = 2;
     c->llr_sd_min = 5.0f;
+    c->osd_triple = 0; c->osd_max_hd = 0;
     return 0;
 }
 
@@ -147,6 +181,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
     for (void* p : h->allocs) hipFree(p);
+    for (auto& c : h->arena) hipFree(c.p);
     for (auto e : h->pev) hipEventDestroy(e);
     for (int i = 0; i < 8; i++) { if (h->sub[i]) hipStreamDestroy(h->sub[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     if (h->copy_s) hipStreamDestroy(h->copy_s);
@@ -168,8 +203,9 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     if (!cfg || !out || max_frames < 1) { set_err(nullptr, "ft8rx_create: bad arguments"); return -1; }
     if (cfg->max_cands < 1 || cfg->max_cands > MAXC || cfg->f0_lo < 4 || cfg->f0_hi > 960 || cfg->f0_lo >= cfg->f0_hi ||
         cfg->h0_hi <= cfg->h0_lo || cfg->h0_hi - cfg->h0_lo > 352 || cfg->bp_nc0_a > cfg->bp_nc0_b || cfg->bp_iters_a > cfg->bp_iters_b ||
-        cfg->osd_single < 0 || cfg->osd_single > 64 || cfg->osd_double < 0 ||
-        1 + cfg->osd_single + cfg->osd_single * cfg->osd_double > OSD_MAXTRIALS) {
+        cfg->osd_single < 0 || cfg->osd_single > OSD_MAXFLIP || cfg->osd_double < 0 || cfg->osd_double > OSD_MAXFLIP ||
+        cfg->osd_triple < 0 || cfg->osd_triple > 40 || cfg->osd_max_hd < 0 || cfg->osd_max_hd > 174 ||
+        osd_trial_table(cfg->osd_single, cfg->osd_double, cfg->osd_triple).size() > OSD_MAXTRIALS) {
         set_err(nullptr, "ft8rx_create: configuration out of the supported range"); return -1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_err(nullptr, "ft8rx_create: no HIP device available (this library has no CPU fallback)"); return -3; }
@@ -248,8 +284,25 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     }
     {   // CRC-14 syndromes of the 77 unit messages (bit-serial definition, decoders.py:123-129)
         uint16_t syn[77];
-        for (int pos = 0; pos < 77; pos++) syn[pos] = (uint16_t)ft8_crc14_serial_host(pos < 64 ? (1ull << pos) : 0ull, pos >= 64 ? (1ull << (pos - 64)) : 0ull);
+        for (int pos = 0; pos < 77; pos++) syn[pos] = (uint16_t)hostmsg::crc14_serial(pos < 64 ? (1ull << pos) : 0ull, pos >= 64 ? (1ull << (pos - 64)) : 0ull);
         ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CRC_SYN), syn, sizeof(syn)) == hipSuccess;
+    }
+    {   // OSD: G0 column-wise (91 row bits per column) and the byte-wise CRC syndrome table of the 91-bit word
+        static uint32_t g0t[192][3];
+        memset(g0t, 0, sizeof(g0t));
+        for (int r = 0; r < 91; r++) for (int v = 0; v < 174; v++) if ((FT8_G0[r][v >> 6] >> (v & 63)) & 1ull) g0t[v][r >> 5] |= 1u << (r & 31);
+        ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_G0T), g0t, sizeof(g0t)) == hipSuccess;
+        uint16_t syn91[96]; memset(syn91, 0, sizeof(syn91));
+        for (int v = 0; v < 91; v++) {
+            if (v < 77) { const int pos = 76 - v; syn91[v] = (uint16_t)hostmsg::crc14_serial(pos < 64 ? (1ull << pos) : 0ull, pos >= 64 ? (1ull << (pos - 64)) : 0ull); }
+            else syn91[v] = (uint16_t)(1u << (13 - (v - 77)));
+        }
+        static uint16_t ct[12][256];
+        for (int b = 0; b < 12; b++) for (int x = 0; x < 256; x++) { uint16_t a = 0; for (int t = 0; t < 8; t++) if ((x >> t) & 1) a ^= syn91[8 * b + t]; ct[b][x] = a; }
+        ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CRC_T), ct, sizeof(ct)) == hipSuccess;
+        const std::vector<uint32_t> tr = osd_trial_table(cfg->osd_single, cfg->osd_double, cfg->osd_triple);
+        h->n_trials = (int)tr.size();
+        if (upload(h, &h->d_trials, tr)) ok = false;
     }
     if (!ok) { set_err(nullptr, "ft8rx_create: device table upload failed"); ft8rx_destroy(h); return -2; }
     if (sync_lds_bytes(*cfg) > 65536) ok &= hipFuncSetAttribute((const void*)k_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sync_lds_bytes(*cfg)) == hipSuccess;
@@ -324,7 +377,8 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     STAGE("select1");
     k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attG, attB, B, c);
     STAGE("osd");
-    k_osd<<<B * MAXC * 10, 64, 0, s>>>(0, llr0, saved, attB, rec, ncand, attO, ev, evc, c.osd_single, c.osd_double);
+    k_osd<<<B * MAXC * 10, 64, 0, s>>>(0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials,
+                                       osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd);
     STAGE("select2");
     k_select2<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attO, B);
     if (prof) hipEventRecord(h->pev[h->pnames.size()], s);
@@ -435,6 +489,23 @@ int ft8rx_fetch_results_view(ft8rx_handle* h, int B, const ft8rx_record** record
     if (events) *events = h->h_ev[slot];
     if (event_counts) *event_counts = h->h_evc[slot];
     if (h->inflight) { h->slot_fetch ^= 1; h->inflight--; }
+    return 0;
+}
+
+int ft8rx_results_to_device(ft8rx_handle* h, int B, ft8rx_record* d_records, int32_t* d_counts, ft8rx_event* d_events, int32_t* d_event_counts) {
+    if (!h || B < 1 || B > h->max_frames) return -1;
+    if (h->last_slot < 0) { set_err(h, "ft8rx_results_to_device: nothing has been enqueued"); return -1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int slot = h->last_slot;
+    if (B > h->slot_B[slot]) { set_err(h, "ft8rx_results_to_device: %d frames requested, the batch had %d", B, h->slot_B[slot]); return -1; }
+    HIPCHK(h, hipStreamSynchronize(h->stream));                      // the batch's kernels are done (results sit in s_*[slot])
+    const int mc = h->cfg.max_cands;
+    if (d_counts) HIPCHK(h, hipMemcpyAsync(d_counts, h->s_ncand[slot], sizeof(int32_t) * B, hipMemcpyDeviceToDevice, h->stream));
+    if (d_records) HIPCHK(h, hipMemcpy2DAsync(d_records, sizeof(ft8rx_record) * mc, h->s_rec[slot], sizeof(ft8rx_record) * MAXC,
+                                              sizeof(ft8rx_record) * mc, B, hipMemcpyDeviceToDevice, h->stream));
+    if (d_event_counts) HIPCHK(h, hipMemcpyAsync(d_event_counts, h->s_evcount[slot], sizeof(int32_t) * B, hipMemcpyDeviceToDevice, h->stream));
+    if (d_events) HIPCHK(h, hipMemcpyAsync(d_events, h->s_ev[slot], sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -568,20 +639,33 @@ int ft8rx_ldpc(ft8rx_handle* h, const float* llr, int n, int max_ncheck0, int ma
     return 0;
 }
 
-int ft8rx_osd(ft8rx_handle* h, const float* llr, int n, int singleflips, int doubleflips, int32_t* ok, uint64_t* msg_lo,
-              uint64_t* msg_hi, int32_t* trial) {
+int ft8rx_osd_ext(ft8rx_handle* h, const float* llr, int n, int singleflips, int doubleflips, int tripleflips, int max_hd,
+                  int32_t* ok, uint64_t* msg_lo, uint64_t* msg_hi, int32_t* trial, int32_t* hd) {
     if (!h || !llr || n < 1) return -1;
-    if (singleflips < 0 || singleflips > 64 || doubleflips < 0 || 1 + singleflips + singleflips * doubleflips > OSD_MAXTRIALS) { set_err(h, "ft8rx_osd: flip counts out of range"); return -1; }
+    if (singleflips < 0 || singleflips > OSD_MAXFLIP || doubleflips < 0 || doubleflips > OSD_MAXFLIP || tripleflips < 0 || tripleflips > 40 ||
+        max_hd < 0 || max_hd > 174) { set_err(h, "ft8rx_osd: flip counts out of range"); return -1; }
+    const std::vector<uint32_t> tr = osd_trial_table(singleflips, doubleflips, tripleflips);
+    if (tr.size() > OSD_MAXTRIALS) { set_err(h, "ft8rx_osd: %zu trials exceed %d", tr.size(), OSD_MAXTRIALS); return -1; }
     HIPCHK(h, hipSetDevice(h->device));
     Scratch S{h};
     float* d_in = S.put(llr, (size_t)n * 174); NEED(d_in);
+    uint32_t* d_tr = S.put(tr.data(), tr.size()); NEED(d_tr);
     Att* d_att = S.get<Att>(n); NEED(d_att);
-    k_osd<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, nullptr, d_att, nullptr, nullptr, singleflips, doubleflips);
+    k_osd<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, nullptr, d_att, nullptr, nullptr, d_tr, (int)tr.size(),
+                                   osd_nflip(singleflips, tripleflips), max_hd);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<Att> a(n);
     HIPCHK(h, hipMemcpy(a.data(), d_att, sizeof(Att) * n, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; i++) { ok[i] = a[i].ok; msg_lo[i] = a[i].lo; msg_hi[i] = a[i].hi; trial[i] = a[i].ok ? a[i].n_its : -1; }
+    for (int i = 0; i < n; i++) {
+        ok[i] = a[i].ok; msg_lo[i] = a[i].lo; msg_hi[i] = a[i].hi; trial[i] = a[i].ok ? a[i].n_its : -1;
+        if (hd) hd[i] = a[i].ok ? a[i].pad[0] : -1;
+    }
     return 0;
+}
+
+int ft8rx_osd(ft8rx_handle* h, const float* llr, int n, int singleflips, int doubleflips, int32_t* ok, uint64_t* msg_lo,
+              uint64_t* msg_hi, int32_t* trial) {
+    return ft8rx_osd_ext(h, llr, n, singleflips, doubleflips, 0, 0, ok, msg_lo, msg_hi, trial, nullptr);
 }
 
 int ft8rx_crc_valid(ft8rx_handle* h, const float* cw91, int n, int32_t* res, uint64_t* msg_lo, uint64_t* msg_hi) {
@@ -689,25 +773,7 @@ int ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int B, ft8rx_subsig* sigs,
 
 int ft8rx_encode_tones(const uint64_t* msg_lo, const uint64_t* msg_hi, int n, uint8_t* tones) {
     if (!msg_lo || !msg_hi || !tones || n < 0) return -1;
-    static const uint8_t costas[7] = {3, 1, 4, 0, 6, 5, 2}, gray[8] = {0, 1, 3, 2, 5, 6, 4, 7};
-    for (int i = 0; i < n; i++) {
-        const uint64_t lo = msg_lo[i], hi = msg_hi[i] & 0x1FFFull;
-        const unsigned crc = ft8_crc14_serial_host(lo, hi);
-        uint64_t cw[3] = {0, 0, 0};                                    // codeword bit v at word v >> 6, bit v & 63
-        for (int r = 0; r < 91; r++) {                                 // message bit r: 77 message bits (bit 76 first), then the CRC
-            unsigned b;
-            if (r < 77) { const int pos = 76 - r; b = (unsigned)((pos >= 64 ? (hi >> (pos - 64)) : (lo >> pos)) & 1u); }
-            else b = (crc >> (13 - (r - 77))) & 1u;
-            if (b) { cw[0] ^= FT8_G0[r][0]; cw[1] ^= FT8_G0[r][1]; cw[2] ^= FT8_G0[r][2]; }
-        }
-        uint8_t* t = tones + (size_t)i * 79;
-        for (int k = 0; k < 7; k++) { t[k] = costas[k]; t[36 + k] = costas[k]; t[72 + k] = costas[k]; }
-        for (int sidx = 0; sidx < 58; sidx++) {
-            unsigned v = 0;
-            for (int b = 0; b < 3; b++) { const int bit = 3 * sidx + b; v = (v << 1) | (unsigned)((cw[bit >> 6] >> (bit & 63)) & 1ull); }
-            t[(sidx < 29 ? 7 : 14) + sidx] = gray[v];
-        }
-    }
+    for (int i = 0; i < n; i++) hostmsg::encode_tones(msg_lo[i], msg_hi[i], tones + (size_t)i * 79);
     return 0;
 }
 
@@ -742,21 +808,21 @@ int ft8rx_synth_frames(ft8rx_handle* h, uint64_t seed, int first_index, int n_fr
 }
 
 int ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, const ft8rx_event* events, const int32_t* event_counts,
-                        int n_frames, int max_cands, ft8rx_message* out, int max_msgs, int32_t* out_counts, int n_threads) {
-    if (!records || !counts || !events || !event_counts || !out || !out_counts || n_frames < 1 || max_cands < 1 || max_msgs < 1) return -1;
-    if (n_threads < 1) n_threads = 1;
-    if (n_threads > n_frames) n_threads = n_frames;
-    auto work = [&](int t) {
-        for (int f = t; f < n_frames; f += n_threads) {
-            int nev = event_counts[f] < FT8RX_EVENT_CAP ? event_counts[f] : FT8RX_EVENT_CAP;
-            out_counts[f] = hostmsg::package_frame(records + (size_t)f * max_cands, counts[f], events + (size_t)f * FT8RX_EVENT_CAP, nev,
-                                                   out + (size_t)f * max_msgs, max_msgs);
-        }
-    };
-    if (n_threads == 1) { work(0); return 0; }
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_threads; t++) pool.emplace_back(work, t);
-    for (auto& th : pool) th.join();
+                        int n_frames, int max_cands, ft8rx_message* out, int max_msgs, int32_t* out_counts, int n_threads,
+                        ft8rx_hashes* table, int32_t* flags) {
+    return hostmsg::package_batch(records, counts, events, event_counts, n_frames, max_cands, out, max_msgs, out_counts, n_threads,
+                                  table ? &table->H : nullptr, flags);
+}
+
+ft8rx_hashes* ft8rx_hashes_create(void) { return new (std::nothrow) ft8rx_hashes(); }
+void ft8rx_hashes_destroy(ft8rx_hashes* t) { delete t; }
+int ft8rx_hashes_clear(ft8rx_hashes* t) { if (!t) return -1; t->H.m.clear(); return 0; }
+int ft8rx_hashes_add(ft8rx_hashes* t, const char* call) { if (!t || !call) return -1; t->H.add(call); return 0; }
+int ft8rx_hashes_size(const ft8rx_hashes* t) { return t ? (int)t->H.m.size() : -1; }
+
+int ft8rx_set_reject_log(const char* path) {
+    std::lock_guard<std::mutex> lk(hostmsg::g_reject_mu);
+    hostmsg::g_reject_log = path ? path : "";
     return 0;
 }
 

@@ -1,5 +1,6 @@
 // host_messages.hpp -- native host message layer: 77-bit words -> strings, call hashes, duplicate filter (decoders.py:16-115, databases.py:10-26, receiver.py:51-66)
-// Part of libft8rx.so; included by ft8rx.hip (single translation unit: the kernels share __constant__/__device__ tables).
+// Part of libft8rx.so; included by ft8rx.hip.  Pure host C++ (needs only include/ft8rx.h and ft8_tables.h): it is also compiled on
+// its own by g++ -fsanitize=address,undefined for the host sanitizer target (oracle/Makefile `asan`, tests/host_asan_driver.cpp).
 #ifndef FT8RX_HOST_MESSAGES_HPP
 #define FT8RX_HOST_MESSAGES_HPP
 
@@ -8,10 +9,25 @@
 // (databases.py:8-26) and the per-frame replay of records/events in the reference's emit order with its duplicate
 // filter (receiver.py:51-66, 389-398).  Pure host code, no HIP: frames are independent and are packaged by a pool
 // of threads so that the Python surface is not the bottleneck behind ~26 k decoded frames/s.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
 #include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
 #include <thread>
 #include <unordered_map>
 namespace hostmsg {
+// optional reject log: the reference appends every call that fails simple_validate_call to 'rejected_callsigns.txt' in the
+// working directory (decoders.py:114-115).  Off by default; ft8rx_set_reject_log(path) turns it on for the process.
+static std::string g_reject_log;
+static std::mutex g_reject_mu;
+static void log_reject(const std::string& call) {
+    if (g_reject_log.empty()) return;
+    std::lock_guard<std::mutex> lk(g_reject_mu);
+    if (FILE* f = fopen(g_reject_log.c_str(), "a")) { fprintf(f, "%s\n", call.c_str()); fclose(f); }
+}
 static const char A37[] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ";
 static const char A38[] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ/";
 static const char A27[] = " ABCDEFGHIJKLMNOPQRSTUVWXYZ";
@@ -46,6 +62,7 @@ static bool plausible(const std::string& c) {
     int x0 = a36(c[0]), x1 = a36(c[1]);
     return x0 >= 0 && x1 >= 0 && ((FT8_PFX2[x0] >> x1) & 1ULL) && dig(c[2]);
 }
+static bool validate(const std::string& c) { const bool ok = plausible(c); if (!ok) log_reject(c); return ok; }
 static bool field29(uint32_t v29, int i3, Hashes& H, std::string& out) {
     const uint32_t flag = v29 & 1u, n28 = v29 >> 1;
     char buf[24];
@@ -66,7 +83,7 @@ static bool field29(uint32_t v29, int i3, Hashes& H, std::string& out) {
         ch[2] = (char)('0' + v % 10); v /= 10; ch[1] = A37[1 + v % 36]; v /= 36; ch[0] = A37[v % 37];
         call = strip(ch);
     }
-    if (!plausible(call)) return false;
+    if (!validate(call)) return false;
     if (flag) {
         call += (i3 == 2) ? "/P" : "/R";
         if (i3 != 2 && !(call[0] == 'A' || call[0] == 'K' || call[0] == 'N' || call[0] == 'W')) return false;
@@ -109,7 +126,8 @@ static bool unpack(uint64_t lo, uint64_t hi, Hashes& H, std::string f[3]) {
     return false;
 }
 struct Ev { int cand, ipass, slot, seq; uint64_t lo, hi; };
-static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, int nev, ft8rx_message* out, int cap) {
+// -> number of messages written (<= cap).  *flags: FT8RX_PKG_MSG_TRUNCATED if more than cap messages were emitted.
+static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, int nev, ft8rx_message* out, int cap, Hashes& H, int* flags) {
     std::vector<Ev> E; E.reserve((size_t)nev);
     for (int i = 0; i < nev; i++) E.push_back({ev[i].cand, ev[i].ipass, ev[i].slot, ev[i].seq, ev[i].msg_lo, ev[i].msg_hi});
     std::sort(E.begin(), E.end(), [](const Ev& a, const Ev& b) {
@@ -120,7 +138,7 @@ static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, 
         const int st = rec[i].status;
         last[i] = st == FT8RX_ST_DECODED ? rec[i].ipass : st == FT8RX_ST_STOP_GRID_SD ? 0 : (st == FT8RX_ST_STOP_COSTAS || st == FT8RX_ST_STOP_FINE_SD) ? 1 : 7;
     }
-    Hashes H; std::vector<std::string> seen; int nm = 0;
+    std::vector<std::string> seen; int nm = 0;
     for (int rnd = 0; rnd < 8; rnd++) {
         order.clear();
         for (int i = 0; i < n; i++) if (last[i] >= rnd) order.push_back(i);
@@ -163,7 +181,68 @@ static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, 
             nm++;
         }
     }
+    if (nm > cap) { if (flags) *flags |= FT8RX_PKG_MSG_TRUNCATED; nm = cap; }
     return nm;
+}
+
+// CRC-14 of a 77-bit message, bit-serial (decoders.py:123-129)
+static inline unsigned crc14_serial(uint64_t lo, uint64_t hi) {
+    unsigned r = 0;
+    for (int i = 0; i < 96; i++) {
+        unsigned b = 0;
+        if (i < 77) { int pos = 76 - i; b = (unsigned)((pos >= 64 ? (hi >> (pos - 64)) : (lo >> pos)) & 1u); }
+        unsigned top = (r >> 13) & 1u;
+        r = ((r << 1) & 0x3FFFu) | b;
+        if (top) r ^= 0x2757u;
+    }
+    return r;
+}
+// 77-bit word -> 79 tones (transmitter.py:181-223 encode_bits77): CRC-14, LDPC(174,91) systematic encode, Gray map, Costas framing
+static void encode_tones(uint64_t lo, uint64_t hi, uint8_t* t) {
+    static const uint8_t costas[7] = {3, 1, 4, 0, 6, 5, 2}, gray[8] = {0, 1, 3, 2, 5, 6, 4, 7};
+    hi &= 0x1FFFull;
+    const unsigned crc = crc14_serial(lo, hi);
+    uint64_t cw[3] = {0, 0, 0};                                    // codeword bit v at word v >> 6, bit v & 63
+    for (int r = 0; r < 91; r++) {                                 // message bit r: 77 message bits (bit 76 first), then the CRC
+        unsigned b;
+        if (r < 77) { const int pos = 76 - r; b = (unsigned)((pos >= 64 ? (hi >> (pos - 64)) : (lo >> pos)) & 1u); }
+        else b = (crc >> (13 - (r - 77))) & 1u;
+        if (b) { cw[0] ^= FT8_G0[r][0]; cw[1] ^= FT8_G0[r][1]; cw[2] ^= FT8_G0[r][2]; }
+    }
+    for (int k = 0; k < 7; k++) { t[k] = costas[k]; t[36 + k] = costas[k]; t[72 + k] = costas[k]; }
+    for (int sidx = 0; sidx < 58; sidx++) {
+        unsigned v = 0;
+        for (int b = 0; b < 3; b++) { const int bit = 3 * sidx + b; v = (v << 1) | (unsigned)((cw[bit >> 6] >> (bit & 63)) & 1ull); }
+        t[(sidx < 29 ? 7 : 14) + sidx] = gray[v];
+    }
+}
+
+// records/events of n_frames frames -> messages; table == nullptr: a fresh hash table per frame (frames spread over n_threads
+// threads); table != nullptr: frames in order on the caller's thread, all sharing (and updating) that table.
+static int package_batch(const ft8rx_record* records, const int32_t* counts, const ft8rx_event* events, const int32_t* event_counts,
+                         int n_frames, int max_cands, ft8rx_message* out, int max_msgs, int32_t* out_counts, int n_threads,
+                         Hashes* table, int32_t* flags) {
+    if (!records || !counts || !events || !event_counts || !out || !out_counts || n_frames < 1 || max_cands < 1 || max_msgs < 1) return -1;
+    if (n_threads < 1 || table) n_threads = 1;
+    if (n_threads > n_frames) n_threads = n_frames;
+    auto work = [&](int t) {
+        for (int f = t; f < n_frames; f += n_threads) {
+            int fl = 0;
+            int nev = event_counts[f];
+            if (nev > FT8RX_EVENT_CAP) { nev = FT8RX_EVENT_CAP; fl |= FT8RX_PKG_EVENTS_TRUNCATED; }
+            if (nev < 0) nev = 0;
+            int n = counts[f] < 0 ? 0 : (counts[f] > max_cands ? max_cands : counts[f]);
+            Hashes local;
+            out_counts[f] = package_frame(records + (size_t)f * max_cands, n, events + (size_t)f * FT8RX_EVENT_CAP, nev,
+                                          out + (size_t)f * max_msgs, max_msgs, table ? *table : local, &fl);
+            if (flags) flags[f] = fl;
+        }
+    };
+    if (n_threads == 1) { work(0); return 0; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; t++) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
+    return 0;
 }
 }  // namespace hostmsg
 

@@ -185,7 +185,7 @@ __global__ void k_select2(ft8rx_record* rec, const int32_t* ncand, const Att* at
         const Att& a = attO[(size_t)c * 10 + s];
         if (a.ok) {
             r.status = FT8RX_ST_DECODED; r.ipass = (s < 5) ? 5 : 6; r.ap = (uint8_t)(s % 5);
-            r.method = (s < 5) ? FT8RX_M_OSD : FT8RX_M_LDPC_B_OSD; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+            r.method = (s < 5) ? FT8RX_M_OSD : FT8RX_M_LDPC_B_OSD; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; r.osd_hd = a.pad[0]; return; }
     }
     r.status = FT8RX_ST_EXHAUSTED;
 }

@@ -4,28 +4,49 @@
 #define FT8RX_OSD_HPP
 
 // ------------------------------------------------------------------------------------ OSD (decoders.py:223-272)
-// One wavefront per attempt.  Lane r holds generator row r (and row 64+r for r<27) in registers.
+// One wavefront per attempt, three phases:
+//   1. reliability order: LDS bitonic network over 256 composite keys (fixed tie rule for the reference's unstable argsort);
+//   2. most-reliable-basis Gauss-Jordan over GF(2) with the generator held COLUMN-wise: lane l owns columns l, 64+l, 128+l
+//      of G0 (91 row bits each, 3 x u32).  A visited column is broadcast to scalar registers; "independent of the accepted
+//      columns" is then a scalar test (any 1 in an unlocked row), the pivot row a scalar find-first-set, and the elimination
+//      one masked XOR per owned column -- no ballots, no cross-lane shuffles, nothing on the dependent chain but readlanes;
+//   3. trials: CRC-14 is linear, so each trial's syndrome is the XOR of the precomputed syndromes of the order-0 codeword
+//      and of its flip rows; a lane tests one trial with three 16-bit LDS reads.  Only zero-syndrome trials (2^-14 of them)
+//      rebuild the codeword, run the validity predicate and log the reference's unpack() call.
+// The trial list (order 0, single flips, the reference's restricted double flips, then the build's order-3 extension) is a
+// table built by the host from the configuration, in the reference's trial order (decoders.py:248-272).
 FT8_DEV uint64_t shfl64(uint64_t v, int src) {
     uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
 }
-FT8_DEV uint64_t xor_reduce64(uint64_t v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)(v >> 32), o);
-        v ^= ((uint64_t)hi << 32) | lo;
-    }
-    return v;
+
+#define OSD_MAXFLIP 64            /* flip rows kept per attempt (singles / order-3 depth <= 64) */
+#define OSD_MAXTRIALS 16384       /* trial index must fit the 16-bit seq of the event log */
+#define OSD_NONE 0xFFu            /* "no flip" in a packed trial entry (i | j << 8 | k << 16) */
+
+__device__ uint32_t d_G0T[192][3];       // column v of G0 = [I | A^T]: row bits 0..31, 32..63, 64..90 (columns >= 174 are zero)
+__device__ uint16_t d_CRC_T[12][256];    // syndrome of byte b (codeword bits 8b .. 8b+7, bits >= 91 ignored) of the 91-bit word:
+                                         // crc14(message) ^ received crc field == XOR of the table entries of its 12 bytes
+
+FT8_DEV unsigned osd_syndrome(uint64_t w0, uint64_t w1) {
+    unsigned s = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) s ^= d_CRC_T[b][(w0 >> (8 * b)) & 0xFF];
+#pragma unroll
+    for (int b = 0; b < 4; b++) s ^= d_CRC_T[8 + b][(w1 >> (8 * b)) & 0xFF];
+    return s;
 }
 
-#define OSD_MAXTRIALS 512
 // mode 0: pipeline (work = (candidate, slot 0..9)); mode 2: raw vectors
 __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,
                                             const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,
                                             const int32_t* __restrict__ ncand, Att* __restrict__ attO,
-                                            ft8rx_event* ev, int32_t* evcount, int singles, int doubles) {
+                                            ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,
+                                            int nflip, int max_hd) {
     __shared__ float llr[176];
     __shared__ uint64_t skey[256];
-    __shared__ uint64_t flip[64][2];
+    __shared__ uint64_t flip[OSD_MAXFLIP + 1][3];          // [OSD_MAXFLIP] = 0: the "no flip" row
+    __shared__ uint16_t fsyn[OSD_MAXFLIP + 2];
     const int lane = threadIdx.x;
     int frame = 0, ci = 0, slot = 0; size_t vec = blockIdx.x;
     if (mode == 0) {
@@ -54,6 +75,7 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
         skey[i] = key;
     }
     __syncthreads();
+#ifndef OSD_TIMING_SKIP_SORT            /* timing-only builds (tools/ab_variants.sh): never defined in the product */
     for (int size = 2; size <= 256; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
 #pragma unroll
@@ -67,94 +89,100 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
             __syncthreads();
         }
     }
-    // ---- Gauss-Jordan over GF(2), most-reliable-basis selection.  The sorted column order and the hard
-    // decisions are lifted into registers / wave-uniform masks so the dependent chain of one elimination step
-    // is readlane -> bit test -> ballot -> ctz -> readlane (no LDS access on the critical path).
+#endif
     const int ord0 = (int)(uint32_t)skey[lane], ord1 = (int)(uint32_t)skey[64 + lane], ord2 = (lane < 46) ? (int)(uint32_t)skey[128 + lane] : 0;
     const uint64_t hard0 = __ballot(llr[lane] > 0.0f), hard1 = __ballot(llr[64 + lane] > 0.0f),
                    hard2 = __ballot(lane < 46 && llr[128 + (lane < 46 ? lane : 0)] > 0.0f);
-    uint64_t a0 = d_G0[lane][0], a1 = d_G0[lane][1], a2 = d_G0[lane][2];
-    const bool hasB = lane < 27;
-    uint64_t b0 = hasB ? d_G0[64 + lane][0] : 0, b1 = hasB ? d_G0[64 + lane][1] : 0, b2 = hasB ? d_G0[64 + lane][2] : 0;
-    // Basis exchange.  G0 = [I | A^T] is already reduced for the systematic basis: row r owns unit column r.
-    // Columns are visited in reliability order exactly as in the reference (decoders.py:228-242) and accepted
-    // iff independent of the columns accepted so far, but
-    //   * a row is "locked" once its basis column has been accepted; an UNLOCKED row r always still owns its original
-    //     column r (rows only change basis column at the moment they are locked), so "column c is the unit column of
-    //     an unlocked row" is the wave-uniform test  c < 91 && !locked(c): such a column is accepted by setting one
-    //     bit -- no row operation, no ballot, no broadcast;
-    //   * any other column is accepted iff it has a 1 in some unlocked row; one elimination step then makes it that
-    //     row's unit column.
-    // The selected basis, the reduced rows and the acceptance order k are identical to plain Gauss-Jordan; about 40 %
-    // of the accepted columns need no row operation.  All bookkeeping is wave-uniform (scalar registers):
-    // lockA/lockB = locked rows 0..63 / 64..90, hmA/hmB = locked rows whose accepted column has hard decision 1.
-    uint64_t lockA = 0, lockB = ~((1ull << 27) - 1), hmA = 0, hmB = 0;
-    __shared__ uint8_t prow[96];                             // prow[k] = row locked by the k-th accepted column
+    // ---- Gauss-Jordan, generator held column-wise.  Column c of the current matrix is a 91-bit vector over the rows; a row is
+    // "locked" once it has been made the unit row of an accepted column.  Visiting column c (in reliability order, exactly as
+    // decoders.py:228-242): it is independent of the accepted columns iff it has a 1 in an unlocked row; the lowest such row r
+    // becomes its pivot (which row is picked does not change the result: the reduced matrix for a given basis is unique up to
+    // the row labels, and the codeword / flip rows below are label-free); clearing the other 1s of column c = adding row r to
+    // those rows = XORing (column c minus bit r) into every column that has a 1 in row r.  A column that already is a unit
+    // column needs no update at all (the systematic columns that are still untouched: about 40 % of the basis).
+    // lock / hm (locked rows whose accepted column has hard decision 1) / the visited column live in scalar registers.
+    uint32_t x00 = d_G0T[lane][0], x01 = d_G0T[lane][1], x02 = d_G0T[lane][2];
+    uint32_t x10 = d_G0T[64 + lane][0], x11 = d_G0T[64 + lane][1], x12 = d_G0T[64 + lane][2];
+    uint32_t x20 = d_G0T[128 + lane][0], x21 = d_G0T[128 + lane][1], x22 = d_G0T[128 + lane][2];
+    uint32_t lock0 = 0, lock1 = 0, lock2 = ~((1u << 27) - 1u), hm0 = 0, hm1 = 0, hm2 = 0;
+    int prowA = 0, prowB = 0;                  // prow[k] = row locked by the k-th accepted column: lane k of prowA (k < 64) / lane k - 64 of prowB
     int k = 0;
+#ifdef OSD_TIMING_SKIP_ELIM
+    k = 91;
+#endif
     for (int ic = 0; ic < 174 && k < 91; ic++) {
-        const int sel = ic >> 6, il = ic & 63;
-        const int col = __builtin_amdgcn_readlane(sel == 0 ? ord0 : (sel == 1 ? ord1 : ord2), il);
-        const int w = col >> 6, sh = col & 63;
-        const uint64_t hw = (w == 0) ? hard0 : (w == 1) ? hard1 : hard2;
-        const uint64_t hard = (hw >> sh) & 1ull;
-        int row = -1;
-        if (col < 91 && !(((col < 64 ? lockA : lockB) >> (col & 63)) & 1ull)) row = col;      // still a unit column
-        else {
-            const uint64_t wa = (w == 0) ? a0 : (w == 1) ? a1 : a2;
-            const uint64_t wb = (w == 0) ? b0 : (w == 1) ? b1 : b2;
-            const bool bitA = (wa >> sh) & 1ull, bitB = (wb >> sh) & 1ull;
-            const uint64_t mA = __ballot(bitA) & ~lockA, mB = __ballot(bitB) & ~lockB;
-            if (!mA && !mB) continue;                        // dependent on the accepted columns
-            const bool inA = (mA != 0);
-            const int src = inA ? __builtin_ctzll(mA) : __builtin_ctzll(mB);
-            const uint64_t p0 = shfl64(inA ? a0 : b0, src), p1 = shfl64(inA ? a1 : b1, src), p2 = shfl64(inA ? a2 : b2, src);
-            if (bitA && !(inA && lane == src)) { a0 ^= p0; a1 ^= p1; a2 ^= p2; }
-            if (bitB && !(!inA && lane == src)) { b0 ^= p0; b1 ^= p1; b2 ^= p2; }
-            row = inA ? src : 64 + src;
+        const int col = __builtin_amdgcn_readlane((ic < 64) ? ord0 : ((ic < 128) ? ord1 : ord2), ic & 63);
+        const int sel = col >> 6, cl = col & 63;
+        uint32_t c0, c1, c2;
+        if (sel == 0) { c0 = __builtin_amdgcn_readlane(x00, cl); c1 = __builtin_amdgcn_readlane(x01, cl); c2 = __builtin_amdgcn_readlane(x02, cl); }
+        else if (sel == 1) { c0 = __builtin_amdgcn_readlane(x10, cl); c1 = __builtin_amdgcn_readlane(x11, cl); c2 = __builtin_amdgcn_readlane(x12, cl); }
+        else { c0 = __builtin_amdgcn_readlane(x20, cl); c1 = __builtin_amdgcn_readlane(x21, cl); c2 = __builtin_amdgcn_readlane(x22, cl); }
+        const uint32_t a0 = c0 & ~lock0, a1 = c1 & ~lock1, a2 = c2 & ~lock2;
+        if (!(a0 | a1 | a2)) continue;                        // dependent on the accepted columns
+        const int r = a0 ? __builtin_ctz(a0) : (a1 ? 32 + __builtin_ctz(a1) : 64 + __builtin_ctz(a2));
+        const uint32_t bit = 1u << (r & 31);
+        const uint32_t b0 = (r < 32) ? bit : 0u, b1 = (r >= 32 && r < 64) ? bit : 0u, b2 = (r >= 64) ? bit : 0u;
+        const uint32_t m0 = c0 & ~b0, m1 = c1 & ~b1, m2 = c2 & ~b2;
+        if (m0 | m1 | m2) {
+            if ((x00 & b0) | (x01 & b1) | (x02 & b2)) { x00 ^= m0; x01 ^= m1; x02 ^= m2; }
+            if ((x10 & b0) | (x11 & b1) | (x12 & b2)) { x10 ^= m0; x11 ^= m1; x12 ^= m2; }
+            if ((x20 & b0) | (x21 & b1) | (x22 & b2)) { x20 ^= m0; x21 ^= m1; x22 ^= m2; }
         }
-        if (row < 64) { lockA |= 1ull << row; hmA |= hard << row; }
-        else { lockB |= 1ull << (row - 64); hmB |= hard << (row - 64); }
-        if (lane == 0) prow[k] = (uint8_t)row;
+        lock0 |= b0; lock1 |= b1; lock2 |= b2;
+        const uint64_t hw = (sel == 0) ? hard0 : ((sel == 1) ? hard1 : hard2);
+        if ((hw >> cl) & 1ull) { hm0 |= b0; hm1 |= b1; hm2 |= b2; }
+        if (lane == (k & 63)) { if (k < 64) prowA = r; else prowB = r; }
         k++;
     }
-    // order-0 codeword (message part = first 91 bits): XOR of the locked rows whose accepted column has hard bit 1
-    const bool hardA = (hmA >> lane) & 1ull, hardB = (hmB >> lane) & 1ull;
-    uint64_t c0 = (hardA ? a0 : 0) ^ (hardB ? b0 : 0), c1 = (hardA ? a1 : 0) ^ (hardB ? b1 : 0);
-    c0 = xor_reduce64(c0); c1 = xor_reduce64(c1);
-    __syncthreads();
-    // flip rows: flip[i] = row locked by accepted column 90 - i (the least reliable basis members first)
-    {
-        const int i = lane;
-        const int r = (i < 64 && 90 - i >= 0 && 90 - i < k) ? prow[90 - i] : 0;
-        const uint64_t fa0 = shfl64(a0, r & 63), fa1 = shfl64(a1, r & 63), fb0 = shfl64(b0, r & 63), fb1 = shfl64(b1, r & 63);
-        flip[i][0] = (r < 64) ? fa0 : fb0;
-        flip[i][1] = (r < 64) ? fa1 : fb1;
+    // order-0 codeword: bit v = parity of (column v AND hm) -- the XOR of the locked rows whose accepted column has hard bit 1
+    const uint64_t cw0 = __ballot((__popc(x00 & hm0) + __popc(x01 & hm1) + __popc(x02 & hm2)) & 1),
+                   cw1 = __ballot((__popc(x10 & hm0) + __popc(x11 & hm1) + __popc(x12 & hm2)) & 1),
+                   cw2 = __ballot((__popc(x20 & hm0) + __popc(x21 & hm1) + __popc(x22 & hm2)) & 1);
+    // flip rows: flip[i] = the row locked by accepted column 90 - i (the least reliable basis members first), as 174 column bits
+#ifdef OSD_TIMING_SKIP_FLIPS
+    nflip = 0;
+#endif
+    for (int i = 0; i < nflip; i++) {
+        const int kk = 90 - i;
+        uint64_t f0 = 0, f1 = 0, f2 = 0;
+        if (kk >= 0 && kk < k) {
+            const int r = (kk < 64) ? __builtin_amdgcn_readlane(prowA, kk) : __builtin_amdgcn_readlane(prowB, kk - 64);
+            const uint32_t bit = 1u << (r & 31);
+            if (r < 32)      { f0 = __ballot(x00 & bit); f1 = __ballot(x10 & bit); f2 = __ballot(x20 & bit); }
+            else if (r < 64) { f0 = __ballot(x01 & bit); f1 = __ballot(x11 & bit); f2 = __ballot(x21 & bit); }
+            else             { f0 = __ballot(x02 & bit); f1 = __ballot(x12 & bit); f2 = __ballot(x22 & bit); }
+        }
+        if (lane == 0) { flip[i][0] = f0; flip[i][1] = f1; flip[i][2] = f2; }
     }
+    if (lane == 0) { flip[OSD_MAXFLIP][0] = 0; flip[OSD_MAXFLIP][1] = 0; flip[OSD_MAXFLIP][2] = 0; fsyn[OSD_MAXFLIP] = 0; }
     __syncthreads();
-    // trial t in the reference's order (decoders.py:248-272): 0 = order-0, 1..S = single flips i = t-1, then the
-    // restricted double flips (i, j), i < S, j < min(i, D), i-major.
-    int npairs = 0;
-    for (int i = 0; i < singles; i++) npairs += (i < doubles) ? i : doubles;
-    const int ntr = 1 + singles + npairs;
-    const int dtri = doubles * (doubles - 1) / 2;          // pairs with i < D
-    const uint64_t M1 = (1ull << 27) - 1;
+    const uint64_t M1 = (1ull << 27) - 1, M2 = (1ull << 46) - 1;
+    if (lane < nflip) fsyn[lane] = (uint16_t)osd_syndrome(flip[lane][0], flip[lane][1] & M1);
+    const unsigned syn_c = osd_syndrome(cw0, cw1 & M1);
+    __syncthreads();
     Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
     const int ipass = (slot < 5) ? 5 : 6;
+#ifdef OSD_TIMING_SKIP_TRIALS
+    ntr = 0;
+#endif
     for (int base = 0; base < ntr; base += 64) {
         const int t = base + lane;
-        int r = 0; uint64_t lo = 0, hi = 0;
+        bool hit = false; int i = OSD_MAXFLIP, j = OSD_MAXFLIP, q = OSD_MAXFLIP;
         if (t < ntr) {
-            int i = -1, j = -1;
-            if (t >= 1 && t <= singles) i = t - 1;
-            else if (t > singles) {
-                const int u = t - 1 - singles;
-                if (u < dtri) { i = 1; while ((i + 1) * i / 2 <= u) i++; j = u - i * (i - 1) / 2; }
-                else { const int v = u - dtri; i = doubles + v / doubles; j = v - (v / doubles) * doubles; }
-            }
-            uint64_t w0 = c0, w1 = c1;
-            if (i >= 0) { w0 ^= flip[i][0]; w1 ^= flip[i][1]; }
-            if (j >= 0) { w0 ^= flip[j][0]; w1 ^= flip[j][1]; }
-            r = ft8_crc_check(w0, w1 & M1, &lo, &hi);
+            const uint32_t e = trials[t];
+            i = e & 0xFF; j = (e >> 8) & 0xFF; q = (e >> 16) & 0xFF;
+            if (i == OSD_NONE) i = OSD_MAXFLIP;
+            if (j == OSD_NONE) j = OSD_MAXFLIP;
+            if (q == OSD_NONE) q = OSD_MAXFLIP;
+            hit = (syn_c ^ fsyn[i] ^ fsyn[j] ^ fsyn[q]) == 0;
+        }
+        if (!__ballot(hit)) continue;                         // no CRC-consistent word among these 64 trials (the usual case)
+        int r = 0, hd = 0; uint64_t lo = 0, hi = 0;
+        if (hit) {
+            const uint64_t w0 = cw0 ^ flip[i][0] ^ flip[j][0] ^ flip[q][0], w1 = cw1 ^ flip[i][1] ^ flip[j][1] ^ flip[q][1],
+                           w2 = cw2 ^ flip[i][2] ^ flip[j][2] ^ flip[q][2];
+            hd = __popcll(w0 ^ hard0) + __popcll(w1 ^ hard1) + __popcll((w2 ^ hard2) & M2);
+            if (!(max_hd > 0 && hd > max_hd)) r = ft8_crc_check(w0, w1 & M1, &lo, &hi);     // gate (extension): no unpack() call beyond max_hd
         }
         const uint64_t acc = __ballot(r == 2);
         const int win = acc ? __builtin_ctzll(acc) : 64;
@@ -162,6 +190,7 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
         if (acc) {
             res.ok = 1; res.lo = shfl64(lo, win); res.hi = shfl64(hi, win); res.n_its = (int16_t)(base + win);
             res.method = (slot < 5) ? FT8RX_M_OSD : FT8RX_M_LDPC_B_OSD;
+            res.pad[0] = (uint8_t)__shfl(hd, win);            // Hamming distance of the accepted codeword to the hard decisions
             break;
         }
     }

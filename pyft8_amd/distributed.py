@@ -3,7 +3,13 @@
 Frames are fully independent (per-frame hash table, per-frame duplicate filter), so the decode itself needs
 no collective: rank r decodes the contiguous block shard(n, r, world).  The only exchange is the final gather
 of fixed-capacity record/event blocks to rank 0 (RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for
-tests).  The reference has no counterpart."""
+tests).  The reference has no counterpart.
+
+Two gather entry points, same result on rank `dst` (the concatenation over ranks in rank order = global frame order for shard()):
+  gather_results(rec, cnt, ev, evc)       host arrays in, through the backend's device (gloo: CPU tensors; nccl: one H2D per rank)
+  gather_results_device(handle, n_frames) nccl only: the latest batch's results go device -> device into torch buffers
+                                          (ft8rx_results_to_device), RCCL gathers them over xGMI, and rank `dst` makes the single
+                                          D2H copy -- no host round trip on the sending ranks."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -20,21 +26,33 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
+def _counts(n, dev, group):
+    world = dist.get_world_size(group)
+    t = torch.tensor([n], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(counts, t, group=group)
+    return [int(c.item()) for c in counts]
+
+
+def _gather_rows(t, counts, dst, group):
+    """t: uint8 [counts[rank], row] on the backend's device -> on dst a list of per-rank tensors (padded to max(counts) rows)."""
+    rank = dist.get_rank(group)
+    nmax = max(counts)
+    if t.shape[0] < nmax:
+        t = torch.cat([t, torch.zeros((nmax - t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)])
+    out = [torch.empty_like(t) for _ in counts] if rank == dst else None
+    dist.gather(t.contiguous(), out, dst=dst, group=group)
+    return out
+
+
 def _gather_bytes(arr, dst, group):
     """Gather one numpy array per rank (same dtype/shape[1:], possibly different shape[0]) to `dst`."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = _device()
-    n = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    row = int(np.prod(arr.shape[1:])) * arr.dtype.itemsize
-    pad = np.zeros((max(counts), row), np.uint8)
-    pad[:arr.shape[0]] = np.ascontiguousarray(arr).view(np.uint8).reshape(arr.shape[0], row)
-    t = torch.from_numpy(pad).to(dev)
-    out = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-    dist.gather(t, out, dst=dst, group=group)
-    if rank != dst:
+    counts = _counts(arr.shape[0], dev, group)
+    row = int(np.prod(arr.shape[1:], dtype=np.int64)) * arr.dtype.itemsize
+    flat = np.ascontiguousarray(arr).view(np.uint8).reshape(arr.shape[0], row)
+    out = _gather_rows(torch.from_numpy(flat.copy()).to(dev), counts, dst, group)
+    if out is None:
         return None
     parts = [o.cpu().numpy()[:c].reshape(-1).view(arr.dtype).reshape((c,) + arr.shape[1:]) for o, c in zip(out, counts)]
     return np.concatenate(parts)
@@ -47,3 +65,27 @@ def gather_results(rec, cnt, ev, evc, dst=0, group=None):
         return rec, cnt, ev, evc
     outs = [_gather_bytes(a, dst, group) for a in (rec, cnt, ev, evc)]
     return tuple(outs) if dist.get_rank(group) == dst else None
+
+
+def gather_results_device(handle, n_frames, dst=0, group=None):
+    """RCCL gather of the handle's latest batch straight from device memory (backend nccl).  -> like gather_results."""
+    from . import _lib
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return handle.fetch(n_frames)
+    if dist.get_backend(group) != "nccl":
+        raise _lib.Ft8rxError("gather_results_device needs the nccl (RCCL) backend; use gather_results with gloo")
+    dev = _device()
+    B, mc = int(n_frames), int(handle.cfg.max_cands)
+    shapes = [(B, mc * _lib.RECORD_DTYPE.itemsize), (B, 4), (B, _lib.EVENT_CAP * _lib.EVENT_DTYPE.itemsize), (B, 4)]
+    bufs = [torch.empty(s, dtype=torch.uint8, device=dev) for s in shapes]
+    handle.results_to_device(B, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr())
+    counts = _counts(B, dev, group)
+    outs = [_gather_rows(b, counts, dst, group) for b in bufs]
+    if dist.get_rank(group) != dst:
+        return None
+    dts = [(_lib.RECORD_DTYPE, (mc,)), (np.dtype(np.int32), ()), (_lib.EVENT_DTYPE, (_lib.EVENT_CAP,)), (np.dtype(np.int32), ())]
+    res = []
+    for out, (dt, tail) in zip(outs, dts):
+        parts = [o[:c].cpu().numpy().reshape(-1).view(dt).reshape((c,) + tail) for o, c in zip(out, counts)]
+        res.append(np.concatenate(parts))
+    return tuple(res)

@@ -13,6 +13,7 @@ frames ("frame-complete" semantics) in batches on the GPU.  Messages 
 `on_message(dict)` with the reference's keys, on the caller's thread, in the reference's emit order.
 There is no CPU path: without libft8rx.so and an MI355X the constructor raises.
 """
+import threading as _threading
 import time as _time
 
 import numpy as np
@@ -111,6 +112,7 @@ class AudioIn:
         self.cycle_spectrum = None
         self.cycles_completed = 0
         self._ready = []                 # (int16 frame, cycle start time) of completed, not yet decoded cycles
+        self._lock = _threading.Lock()   # _callback may run on an audio thread, poll() on the manage_cycle stand-in
         d = WATERFALL_DOWNSAMPLE
         self.waterfall_data = {"data": self.search_grid[::d, ::d].T, "df": self.df * d, "dt": self.dt * d,
                                "sig_w": int(79 * self.search_hps / d), "sig_h": int(8 * self.search_bpt / d),
@@ -134,16 +136,20 @@ class AudioIn:
         self.audio_buffer[:-n] = self.audio_buffer[n:]
         self.audio_buffer[-n:] = samples
         self.search_grid_ptr = (self.search_grid_ptr + 1) % self.search_hops_per_grid
+        # a cycle is complete when the pointer reaches a multiple of 375 -- decided BEFORE the wall-clock re-sync below, which
+        # moves the pointer away from 0 whenever the stream lags the clock (normal after PortAudio's start-up latency)
+        cycle_done = self.search_grid_ptr % self.search_hops_per_cycle == 0
         if self.search_grid_ptr == 0:
             tg = self._grid_time()
             if tg > 0.1:
                 self.search_grid_ptr = int(tg * self.search_hops_per_grid / (2 * T_CYC))
         self.search_grid[self.search_grid_ptr, :] = self._rx._handle(1).hop_spectrum(self.audio_buffer[-self.search_fft_len:])
-        if self.search_grid_ptr % self.search_hops_per_cycle == 0:      # the 375th hop of a cycle just landed
+        if cycle_done:                                                   # the last hop of a cycle just landed
             self._audio = self.audio_buffer.copy()
             self.cycle_spectrum = None
             self.cycles_completed += 1
-            self._ready.append((self._audio, self._rx.time_source()))
+            with self._lock:
+                self._ready.append((self._audio, self._rx.time_source()))
         return (None, 0)                 # (None, pyaudio.paContinue)
 
     def get_cycle_spectrum(self):
@@ -171,6 +177,7 @@ class Receiver:
         self.device = device
         self._h = None
         self._sub = None                              # handle for search() over a sub-range of f0 indices
+        self.call_hashes = _lib.CallHashTable()       # persistent across the cycles of the stream (poll); batches use fresh ones
         self._handle(max_frames)                      # fail loudly now if there is no GPU / library
         self.audio_in = AudioIn(search_freq_range, self)
 
@@ -346,14 +353,22 @@ class Receiver:
     # ---- streaming mode (stands in for the manage_cycle thread, receiver.py:372-412)
     def poll(self):
         """Decode every cycle that audio_in._callback has completed since the last call; messages go to on_message
-        on the caller's thread.  -> list of message dicts.  Call it from your own loop/thread (e.g. every 0.1 s)."""
+        on the caller's thread.  -> list of message dicts.  Receiver.start() runs this on a daemon thread (the stand-in for
+        manage_cycle); without it, call poll() from your own loop (e.g. every 0.1 s).
+
+        Unlike batched decode_frames (independent frames, a fresh call-hash table per frame), the stream is ONE receiver: the
+        frames share the persistent table self.call_hashes, as the reference's process-global databases.call_hashes does
+        (databases.py:8), so a hashed / non-standard call heard in cycle N resolves `<...>` in cycle N+1."""
         out = []
-        while self.audio_in._ready:
-            frame, t_end = self.audio_in._ready.pop(0)
+        while True:
+            with self.audio_in._lock:
+                if not self.audio_in._ready:
+                    break
+                frame, t_end = self.audio_in._ready.pop(0)
             t0 = T_CYC * int((t_end - T_CYC / 2) / T_CYC)              # start of the cycle that just ended
             cs = _time.strftime("%y%m%d_%H%M%S", _time.gmtime(t0))
             rec, cnt, ev, evc = self._handle(1).decode_batch(frame[None])
-            msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=1)
+            msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=1, table=self.call_hashes)
             out += _m.message_dicts(msgs[0], mcnt[0], cyclestart_string=cs, band=self.band,
                                     odd_even=int((t0 % (2 * T_CYC)) / T_CYC), on_message=self.on_message)
         return out
