@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--no-host-entry", action="store_true", help="skip the informational host-pointer (PCIe-inclusive) passes, whose "
                     "chunked launches would mix part-batch kernels into a rocprofv3 per-kernel average")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for flow tests on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="flow tests on a box with fewer GPUs than ranks: rank r uses device r %% device_count "
+                    "(gloo always does this; RCCL itself refuses two ranks on one device)")
     ap.add_argument("--signals", type=int, default=50, help="signals per synthetic frame (config 1/2: 50, config 4: <= 10)")
     ap.add_argument("--snr", type=float, nargs=2, default=(-10.0, 10.0), metavar=("LO", "HI"), help="SNR range in dB / 2500 Hz")
     ap.add_argument("--bp-iters", type=int, default=None, help="extension knob: iterations of the second BP stage (reference 20; config 2: 30)")
@@ -198,7 +200,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
-    if args.backend != "nccl":
+    if args.backend != "nccl" or args.share_gpu:
         local = local % torch.cuda.device_count()          # flow test: several ranks may share one GPU
     torch.cuda.set_device(local)
     if world > 1:

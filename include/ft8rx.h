@@ -166,6 +166,9 @@ int  ft8rx_valid77(ft8rx_handle* h, const uint64_t* msg_lo, const uint64_t* msg_
  * signal_table: n_frames*n_signals records laid out as pyft8_amd/synth.py:SIGNAL_DTYPE; pulse_cumsum: 5761 doubles. */
 int  ft8rx_synth_frames(ft8rx_handle* h, uint64_t seed, int first_index, int n_frames, int n_signals,
                         const void* signal_table, int signal_bytes, const double* pulse_cumsum, int16_t* d_audio);
+/* same; no_noise != 0 leaves the Philox noise out (parity tests of the signal part against the numpy twin pyft8_amd/synth.py) */
+int  ft8rx_synth_frames_ex(ft8rx_handle* h, uint64_t seed, int first_index, int n_frames, int n_signals,
+                           const void* signal_table, int signal_bytes, const double* pulse_cumsum, int16_t* d_audio, int no_noise);
 /* Host message layer (pure host code, no GPU needed): replays each frame's records + events in the reference's emit
  * order -- hash-table side effects of every unpack() call (decoders.py:44,92; databases.py:10-26), duplicate filter
  * (receiver.py:51-66), round/llr_sd ordering of manage_cycle (receiver.py:389-398) -- and renders the message tuples.

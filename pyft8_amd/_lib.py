@@ -355,16 +355,18 @@ class Handle:
         self._chk(lib().ft8rx_copy_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr), C.c_uint64(out.nbytes)), "ft8rx_copy_to_host")
         return out
 
-    def synth_frames(self, d_audio_ptr, start, count, n_signals=50, snr_range=(-10.0, 10.0), seed=0x4654385F53594E54):
-        """Fill the device buffer at d_audio_ptr ([count][180000] int16) with synthetic frames; returns the truth list."""
+    def synth_frames(self, d_audio_ptr, start, count, n_signals=50, snr_range=(-10.0, 10.0), seed=0x4654385F53594E54, noise=True,
+                     return_table=False):
+        """Fill the device buffer at d_audio_ptr ([count][180000] int16) with synthetic frames; returns the truth list (and the
+        signal table handed to the kernel if return_table).  noise=False leaves the Philox noise out (parity tests)."""
         from . import synth
         recs, truth = synth.device_signal_table(start, count, n_signals, snr_range)
         assert recs.dtype.itemsize == synth.SIGNAL_DTYPE.itemsize
         q = np.ascontiguousarray(synth.pulse_cumsum(), np.float64)
-        self._chk(lib().ft8rx_synth_frames(self._h, C.c_uint64(seed), int(start), int(count), int(n_signals),
-                                           recs.ctypes.data_as(C.c_void_p), int(recs.dtype.itemsize), _ptr(q, C.c_double),
-                                           C.c_void_p(d_audio_ptr)), "ft8rx_synth_frames")
-        return truth
+        self._chk(lib().ft8rx_synth_frames_ex(self._h, C.c_uint64(seed), int(start), int(count), int(n_signals),
+                                              recs.ctypes.data_as(C.c_void_p), int(recs.dtype.itemsize), _ptr(q, C.c_double),
+                                              C.c_void_p(d_audio_ptr), int(not noise)), "ft8rx_synth_frames")
+        return (truth, recs) if return_table else truth
 
     def math_probe(self, which, x):
         if which == 2:

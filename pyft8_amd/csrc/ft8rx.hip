@@ -794,17 +794,22 @@ int ft8rx_free_host(ft8rx_handle* h, void* p) {          // h may be NULL (buffe
     return 0;
 }
 
-int ft8rx_synth_frames(ft8rx_handle* h, uint64_t seed, int first_index, int n_frames, int n_signals,
-                       const void* signal_table, int signal_bytes, const double* pulse_cumsum, int16_t* d_audio) {
+int ft8rx_synth_frames_ex(ft8rx_handle* h, uint64_t seed, int first_index, int n_frames, int n_signals,
+                          const void* signal_table, int signal_bytes, const double* pulse_cumsum, int16_t* d_audio, int no_noise) {
     if (!h || !signal_table || !pulse_cumsum || !d_audio || n_frames < 1 || n_signals < 0 || n_signals > 64) return -1;
     if (signal_bytes != (int)sizeof(SynthSig)) { set_err(h, "ft8rx_synth_frames: signal record is %d bytes, expected %d", signal_bytes, (int)sizeof(SynthSig)); return -1; }
     HIPCHK(h, hipSetDevice(h->device));
     Scratch S{h};
     SynthSig* d_s = S.put((const SynthSig*)signal_table, (size_t)n_frames * (n_signals ? n_signals : 1)); NEED(d_s);
     double* d_q = S.put(pulse_cumsum, 5761); NEED(d_q);
-    k_synth<<<dim3((FT8RX_NSAMP / 4 + 255) / 256, n_frames), 256, 0, h->stream>>>(d_audio, d_s, n_signals, d_q, (uint32_t)seed, (uint32_t)(seed >> 32), first_index);
+    k_synth<<<dim3((FT8RX_NSAMP / 4 + 255) / 256, n_frames), 256, 0, h->stream>>>(d_audio, d_s, n_signals, d_q, (uint32_t)seed, (uint32_t)(seed >> 32), first_index, no_noise);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
+}
+
+int ft8rx_synth_frames(ft8rx_handle* h, uint64_t seed, int first_index, int n_frames, int n_signals,
+                       const void* signal_table, int signal_bytes, const double* pulse_cumsum, int16_t* d_audio) {
+    return ft8rx_synth_frames_ex(h, seed, first_index, n_frames, n_signals, signal_table, signal_bytes, pulse_cumsum, d_audio, 0);
 }
 
 int ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, const ft8rx_event* events, const int32_t* event_counts,

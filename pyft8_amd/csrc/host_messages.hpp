@@ -126,13 +126,17 @@ static bool unpack(uint64_t lo, uint64_t hi, Hashes& H, std::string f[3]) {
     return false;
 }
 struct Ev { int cand, ipass, slot, seq; uint64_t lo, hi; };
+static bool ev_before(const Ev& a, const Ev& b) {          // the reference's call order: candidate, ladder step, attempt, order inside it
+    if (a.cand != b.cand) return a.cand < b.cand;
+    if (a.ipass != b.ipass) return a.ipass < b.ipass;
+    if (a.slot != b.slot) return a.slot < b.slot;
+    return a.seq < b.seq;
+}
 // -> number of messages written (<= cap).  *flags: FT8RX_PKG_MSG_TRUNCATED if more than cap messages were emitted.
 static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, int nev, ft8rx_message* out, int cap, Hashes& H, int* flags) {
     std::vector<Ev> E; E.reserve((size_t)nev);
     for (int i = 0; i < nev; i++) E.push_back({ev[i].cand, ev[i].ipass, ev[i].slot, ev[i].seq, ev[i].msg_lo, ev[i].msg_hi});
-    std::sort(E.begin(), E.end(), [](const Ev& a, const Ev& b) {
-        if (a.cand != b.cand) return a.cand < b.cand; if (a.ipass != b.ipass) return a.ipass < b.ipass;
-        if (a.slot != b.slot) return a.slot < b.slot; return a.seq < b.seq; });
+    std::sort(E.begin(), E.end(), ev_before);
     std::vector<int> last(n), order; order.reserve(n);
     for (int i = 0; i < n; i++) {
         const int st = rec[i].status;
@@ -155,9 +159,7 @@ static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, 
             }
             std::string f[3], got[3]; bool have = false;
             Ev key{i, rnd, -1, -1, 0, 0};
-            auto it = std::lower_bound(E.begin(), E.end(), key, [](const Ev& a, const Ev& b) {
-                if (a.cand != b.cand) return a.cand < b.cand; if (a.ipass != b.ipass) return a.ipass < b.ipass;
-                if (a.slot != b.slot) return a.slot < b.slot; return a.seq < b.seq; });
+            auto it = std::lower_bound(E.begin(), E.end(), key, ev_before);
             int pslot = -2, pseq = -2;
             for (; it != E.end() && it->cand == i && it->ipass == rnd; ++it) {
                 if (here && (it->slot > sslot || (it->slot == sslot && it->seq > sseq))) break;

@@ -28,7 +28,8 @@ FT8_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 
 // one thread = 4 consecutive samples of one frame
 __global__ __launch_bounds__(256) void k_synth(int16_t* __restrict__ audio, const SynthSig* __restrict__ sigs, int nsig,
-                                               const double* __restrict__ Q /*[5761]*/, uint32_t seed_lo, uint32_t seed_hi, int first_index) {
+                                               const double* __restrict__ Q /*[5761]*/, uint32_t seed_lo, uint32_t seed_hi, int first_index,
+                                               int no_noise) {
     const int f = blockIdx.y;
     const int n0 = 4 * (blockIdx.x * 256 + threadIdx.x);
     if (n0 >= FT8RX_NSAMP) return;
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void k_synth(int16_t* __restrict__ audio, cons
         x[0] = ra * cos(6.283185307179586 * u1); x[1] = ra * sin(6.283185307179586 * u1);
         x[2] = rb * cos(6.283185307179586 * u3); x[3] = rb * sin(6.283185307179586 * u3);
     }
+    if (no_noise) { x[0] = 0.0; x[1] = 0.0; x[2] = 0.0; x[3] = 0.0; }      // parity tests: the signal part alone
     const SynthSig* S = sigs + (size_t)f * nsig;
     const double Qtot = Q[5760];
     for (int sg = 0; sg < nsig; sg++) {

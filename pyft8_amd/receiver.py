@@ -12,6 +12,12 @@ The reference is a real-time, one-frame-per-15-s receiver driven by PortAudio; t
 frames ("frame-complete" semantics) in batches on the GPU.  Messages are delivered through
 `on_message(dict)` with the reference's keys, on the caller's thread, in the reference's emit order.
 There is no CPU path: without libft8rx.so and an MI355X the constructor raises.
+
+Live use: like the reference, the constructor starts the receiver when an audio source exists -- PortAudio through
+PyAudio if that module is importable (reference receiver.py:252, 266-270), or any iterator of 480-sample int16 hops passed as
+`audio_source` -- plus a daemon thread that stands in for Receiver.manage_cycle (receiver.py:336, 372-412): it wakes every 0.1 s on
+the `time_source` / `sleep` seam (time_utils.py:7-14) and decodes every completed cycle (poll()).  `Receiver.start()` / `.stop()`
+do the same explicitly.
 """
 import threading as _threading
 import time as _time
@@ -70,6 +76,18 @@ class Candidate:
         self.decode_result = None
 
 
+def _pyaudio_device(audio_in, keywords):
+    """True iff PyAudio is importable and a capture device matches `keywords` (sets audio_in.input_device_idx like the reference)."""
+    try:
+        import pyaudio
+    except ImportError:
+        return False
+    try:
+        return audio_in._find_input_device(keywords, pyaudio.PyAudio()) is not None
+    except Exception:       # noqa: BLE001 -- no usable PortAudio host: behave like "no device"
+        return False
+
+
 def _as_frames(audio_i16):
     """[B, 180000] int16 as is; lists / short frames through frames_from_ragged."""
     if isinstance(audio_i16, np.ndarray) and audio_i16.dtype == np.int16 and audio_i16.ndim == 2 and audio_i16.shape[1] == _lib.NSAMP:
@@ -92,8 +110,11 @@ class AudioIn:
     Unlike the reference, decoding is triggered when a cycle's 375 hops are complete (Receiver.poll), not at
     hop 260 -- the frame-complete semantics of this build."""
 
-    def __init__(self, search_freq_range, receiver):
+    def __init__(self, search_freq_range, receiver, input_device_keywords=None):
         self.input_device_idx = None
+        self.input_device_keywords = input_device_keywords
+        self.stream = None
+        self._feeder = None
         self.search_hps, self.search_bpt = 4, 2
         self.search_freq_range = search_freq_range
         self.search_fft_len = 3840
@@ -121,6 +142,61 @@ class AudioIn:
     def _grid_time(self):
         return self._rx.time_source() % (2 * T_CYC)
 
+    # ---- audio sources (reference receiver.py:252-270)
+    def _find_input_device(self, input_device_keywords, pya):
+        """First PortAudio device whose name contains every comma-separated keyword (reference receiver.py:254-264)."""
+        for dev_idx in range(pya.get_device_count()):
+            name = pya.get_device_info_by_index(dev_idx)["name"]
+            if all(pat in name for pat in input_device_keywords.replace(" ", "").split(",")):
+                self.input_device_idx = dev_idx
+                break
+        return self.input_device_idx
+
+    def open(self, source=None):
+        """Start feeding _callback.
+        source None : PortAudio capture through PyAudio (imported lazily; reference receiver.py:266-270): int16 mono 12 kHz,
+                      480 frames per buffer, this object's _callback as the stream callback;
+        otherwise   : any iterable of hops -- 480 int16 samples as an array or bytes -- consumed by a daemon thread that calls
+                      _callback per hop.  Pacing is the iterator's business (a live source blocks until the next hop exists; a
+                      file replayer sleeps; a test advances its virtual clock inside the generator)."""
+        if source is None:
+            try:
+                import pyaudio
+            except ImportError as e:
+                raise _lib.Ft8rxError("AudioIn.open(): PyAudio is not installed -- pass an iterator of 480-sample int16 hops instead") from e
+            pya = pyaudio.PyAudio()
+            if self.input_device_idx is None and self.input_device_keywords:
+                self._find_input_device(self.input_device_keywords, pya)
+            self.stream = pya.open(format=pyaudio.paInt16, channels=1, rate=SAMP_RATE, input=True, input_device_index=self.input_device_idx,
+                                   frames_per_buffer=self.samples_perhop, stream_callback=self._pa_callback)
+            self.stream.start_stream()
+            return self
+
+        def feed():
+            for hop in source:
+                if self._rx._stop.is_set():
+                    break
+                self._callback(hop if isinstance(hop, (bytes, bytearray, memoryview)) else np.ascontiguousarray(hop, np.int16).tobytes(),
+                               self.samples_perhop, None, None)
+            self.source_exhausted = True
+        self.source_exhausted = False
+        self._feeder = _threading.Thread(target=feed, name="ft8rx-audio-in", daemon=True)
+        self._feeder.start()
+        return self
+
+    def _pa_callback(self, in_data, frame_count, time_info, status_flags):
+        import pyaudio
+        self._callback(in_data, frame_count, time_info, status_flags)
+        return (None, pyaudio.paContinue)
+
+    def close(self):
+        if self.stream is not None:
+            try:
+                self.stream.stop_stream()
+                self.stream.close()
+            finally:
+                self.stream = None
+
     def load_frame(self, audio_i16):
         """Frame-complete stand-in for 375 calls of _callback (receiver.py:295-306)."""
         self._audio = np.ascontiguousarray(audio_i16, np.int16).reshape(_lib.NSAMP)
@@ -143,7 +219,8 @@ class AudioIn:
             tg = self._grid_time()
             if tg > 0.1:
                 self.search_grid_ptr = int(tg * self.search_hops_per_grid / (2 * T_CYC))
-        self.search_grid[self.search_grid_ptr, :] = self._rx._handle(1).hop_spectrum(self.audio_buffer[-self.search_fft_len:])
+        with self._rx._hlock:
+            self.search_grid[self.search_grid_ptr, :] = self._rx._handle(1).hop_spectrum(self.audio_buffer[-self.search_fft_len:])
         if cycle_done:                                                   # the last hop of a cycle just landed
             self._audio = self.audio_buffer.copy()
             self.cycle_spectrum = None
@@ -164,9 +241,17 @@ class AudioIn:
 class Receiver:
     def __init__(self, input_device_keywords, on_message, sync_score_min=85, max_cands=200,
                  search_freq_range=[100, 3000], search_time_range=[-2.5 + 0.5, 2.5 + 0.5], verbose=False,
-                 device=0, max_frames=1, time_source=None, **extension_knobs):
+                 device=0, max_frames=1, time_source=None, sleep=None, audio_source=None, autostart=None, **extension_knobs):
+        if search_freq_range[1] > 3000 or search_freq_range[0] < 12.5:
+            # the reference sizes its grid from search_freq_range (receiver.py:234-240); this build's spectrogram / cycle-spectrum
+            # layouts are fixed at the default 976 columns / 49152 bins (INTEGRATION.md "limits")
+            raise _lib.Ft8rxError(f"search_freq_range {list(search_freq_range)} outside the supported [12.5, 3000] Hz")
         self.on_message = on_message
         self.time_source = time_source or _time.time          # the reference's time_utils seam (time_utils.py:7-8)
+        self.sleep = sleep or _time.sleep                     # time_utils.py:13-14
+        self._stop = _threading.Event()
+        self._thread = None
+        self._hlock = _threading.RLock()                      # one handle, two threads (audio callback, manage_cycle stand-in)
         self.sync_score_min, self.max_cands = sync_score_min, max_cands
         self.verbose = verbose
         self.band = None
@@ -179,7 +264,42 @@ class Receiver:
         self._sub = None                              # handle for search() over a sub-range of f0 indices
         self.call_hashes = _lib.CallHashTable()       # persistent across the cycles of the stream (poll); batches use fresh ones
         self._handle(max_frames)                      # fail loudly now if there is no GPU / library
-        self.audio_in = AudioIn(search_freq_range, self)
+        self.audio_in = AudioIn(search_freq_range, self, input_device_keywords)
+        # The reference starts its audio thread and manage_cycle in the constructor (receiver.py:252, 336).  Same here when there
+        # is something to listen to: an explicit audio_source, or PortAudio (PyAudio importable and a device matches the keywords).
+        if autostart is None:
+            autostart = audio_source is not None or (bool(input_device_keywords) and _pyaudio_device(self.audio_in, input_device_keywords))
+        if autostart:
+            self.start(audio_source)
+
+    # ---- the manage_cycle stand-in (reference receiver.py:336, 372-412)
+    def start(self, audio_source=None):
+        """Open the audio source (AudioIn.open) and start the daemon that decodes completed cycles: every 0.1 s (the reference's
+        poll period, receiver.py:383) it calls poll(); on_message runs on that thread, as in the reference.  Unlike the
+        reference, whose daemon dies on the first exception, an exception is kept in .thread_error and the loop ends."""
+        if self._thread is not None and self._thread.is_alive():
+            return self
+        self._stop.clear()
+        self.thread_error = None
+        if audio_source is not None or self.audio_in.stream is None and self.audio_in._feeder is None:
+            self.audio_in.open(audio_source)
+
+        def manage_cycle():
+            try:
+                while not self._stop.is_set():
+                    self.sleep(0.1)
+                    self.poll()
+            except Exception as e:              # noqa: BLE001 -- surfaced to the owner instead of silently killing the daemon
+                self.thread_error = e
+        self._thread = _threading.Thread(target=manage_cycle, name="ft8rx-manage-cycle", daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self, timeout=5.0):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout)
+        self.audio_in.close()
 
     def _handle(self, n_frames):
         if self._h is None or self._h.max_frames < n_frames:
@@ -367,7 +487,8 @@ class Receiver:
                 frame, t_end = self.audio_in._ready.pop(0)
             t0 = T_CYC * int((t_end - T_CYC / 2) / T_CYC)              # start of the cycle that just ended
             cs = _time.strftime("%y%m%d_%H%M%S", _time.gmtime(t0))
-            rec, cnt, ev, evc = self._handle(1).decode_batch(frame[None])
+            with self._hlock:
+                rec, cnt, ev, evc = self._handle(1).decode_batch(frame[None])
             msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=1, table=self.call_hashes)
             out += _m.message_dicts(msgs[0], mcnt[0], cyclestart_string=cs, band=self.band,
                                     odd_even=int((t0 % (2 * T_CYC)) / T_CYC), on_message=self.on_message)

@@ -132,6 +132,24 @@ def _gfsk_pulse(bt=2.0):
 _PULSE = None
 
 
+def tones_to_phase(tones, f0):
+    """79 tones -> the GFSK phase (radians) at each of the 79*1920 samples.  Modelled on the reference transmitter's
+    symbols_to_complex_audio (transmitter.py:52-70): same pulse, same dummy edge symbols; the reference accumulates the phase
+    inclusively, so its waveform is this one advanced by exactly one sample (tests/test_synth.py pins that against a golden of
+    the reference's own output)."""
+    global _PULSE
+    if _PULSE is None:
+        _PULSE = _gfsk_pulse()
+    n = len(tones)
+    ext = [tones[0]] + list(tones) + [tones[-1]]          # dummy edge symbols
+    dphi = np.zeros((n + 2) * NSPS + 2 * NSPS)
+    for i, t in enumerate(ext):
+        dphi[i * NSPS:i * NSPS + 3 * NSPS] += t * _PULSE
+    dphi = dphi[int(1.5 * NSPS) + NSPS // 2: int(1.5 * NSPS) + NSPS // 2 + n * NSPS]
+    dphi = 2 * np.pi * (f0 + 6.25 * dphi) / FS
+    return np.cumsum(dphi) - dphi
+
+
 def tones_to_wave(tones, f0):
     """79 tones -> real GFSK waveform, 79*1920 samples, unit amplitude."""
     global _PULSE
@@ -267,3 +285,54 @@ def device_signal_table(start, count, n_signals=50, snr_range=(-10.0, 10.0), see
             tr.append(dict(msg=" ".join(msg), f0=float(f0), t0=float(t0), snr=float(snr)))
         truth.append(tr)
     return recs, truth
+
+
+# ----------------------------------------------------------------------------- numpy twins of the device generator (k_synth)
+DEVICE_SEED = 0x4654385F53594E54        # default seed of _lib.Handle.synth_frames
+
+
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 on uint32 arrays (the counter-based generator of csrc/kernels/synth.hpp)."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    c0, c1, c2, c3 = (np.asarray(x, np.uint32).copy() for x in (c0, c1, c2, c3))
+    k0, k1 = np.uint32(k0), np.uint32(k1)
+    for _ in range(10):
+        p0 = M0 * c0.astype(np.uint64)
+        p1 = M1 * c2.astype(np.uint64)
+        n0 = (p1 >> np.uint64(32)).astype(np.uint32) ^ c1 ^ k0
+        n1 = p1.astype(np.uint32)
+        n2 = (p0 >> np.uint64(32)).astype(np.uint32) ^ c3 ^ k1
+        n3 = p0.astype(np.uint32)
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = np.uint32((int(k0) + 0x9E3779B9) & 0xFFFFFFFF)
+        k1 = np.uint32((int(k1) + 0xBB67AE85) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def device_noise(frame_index, seed=DEVICE_SEED):
+    """The unit-variance noise k_synth adds to frame `frame_index` (float64[180000]): counter = (sample group, frame index), key =
+    seed; two Box-Muller pairs per group of four samples."""
+    g = np.arange(NFRAME // 4, dtype=np.uint32)
+    z = np.zeros_like(g)
+    r = _philox4x32_10(g, np.full_like(g, np.uint32(frame_index & 0xFFFFFFFF)), z, z, seed & 0xFFFFFFFF, seed >> 32)
+    u = [(x.astype(np.float64) + 0.5) * (1.0 / 4294967296.0) for x in r]
+    ra, rb = np.sqrt(-2.0 * np.log(u[0])), np.sqrt(-2.0 * np.log(u[2]))
+    out = np.empty(NFRAME)
+    out[0::4] = ra * np.cos(6.283185307179586 * u[1])
+    out[1::4] = ra * np.sin(6.283185307179586 * u[1])
+    out[2::4] = rb * np.cos(6.283185307179586 * u[3])
+    out[3::4] = rb * np.sin(6.283185307179586 * u[3])
+    return out
+
+
+def device_frame(frame_index, table_row, n_signals, noise=True, seed=DEVICE_SEED):
+    """numpy twin of one k_synth frame from its signal table row (device_signal_table): int16[180000]."""
+    x = device_noise(frame_index, seed) if noise else np.zeros(NFRAME)
+    for s in range(n_signals):
+        r = table_row[s]
+        tones = [int(t) for t in r["ext"][1:80]]
+        w = tones_to_wave(tones, float(r["f0"]))
+        i0 = int(r["i0"])
+        lo, hi = max(i0, 0), min(i0 + len(w), NFRAME)
+        x[lo:hi] += float(r["amp"]) * w[lo - i0:hi - i0]
+    return np.clip(np.rint(x * 1000.0), -32768, 32767).astype(np.int16)

@@ -1,0 +1,57 @@
+// host_asan_driver.cpp -- host sanitizer target for the product's pure-host C++.  TEST INFRASTRUCTURE.
+// Compiles pyft8_amd/csrc/host_messages.hpp on its own (g++ -fsanitize=address,undefined; no HIP) and drives the native message
+// layer -- unpack / call hashes / ordered replay / duplicate filter / tone encoder -- with (a) a records+events dump of a real frame
+// written by the test (argv[1]: n, nev, then the raw ft8rx_record[n] and ft8rx_event[nev] bytes) and (b) random 77-bit words,
+// multi-threaded, with fresh and with persistent hash tables, including truncating capacities.
+//   make -C oracle asan && oracle/_build/asan_host [dump.bin]
+#include <stdio.h>
+#include <stdlib.h>
+#include <random>
+#include "../include/ft8rx.h"
+#include "../pyft8_amd/csrc/ft8_tables.h"
+#include "../pyft8_amd/csrc/host_messages.hpp"
+
+int main(int argc, char** argv) {
+    std::mt19937_64 rng(12345);
+    const int MC = 200;
+    std::vector<ft8rx_record> rec; std::vector<ft8rx_event> ev; int n = 0, nev = 0;
+    if (argc > 1) {
+        FILE* f = fopen(argv[1], "rb");
+        if (!f) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
+        int32_t hdr[2];
+        if (fread(hdr, 4, 2, f) != 2) return 2;
+        n = hdr[0]; nev = hdr[1];
+        rec.resize(MC); ev.resize(FT8RX_EVENT_CAP);
+        if ((int)fread(rec.data(), sizeof(ft8rx_record), n, f) != n || (int)fread(ev.data(), sizeof(ft8rx_event), nev, f) != nev) return 2;
+        fclose(f);
+    }
+    // (a) the dumped frame, 8 copies over 4 threads, then sequentially against one persistent table, then with a tiny capacity
+    long total = 0;
+    if (n) {
+        const int B = 8;
+        std::vector<ft8rx_record> R((size_t)B * MC); std::vector<ft8rx_event> E((size_t)B * FT8RX_EVENT_CAP);
+        std::vector<int32_t> cnt(B, n), evc(B, nev), oc(B), fl(B);
+        for (int b = 0; b < B; b++) { std::copy(rec.begin(), rec.end(), R.begin() + (size_t)b * MC); std::copy(ev.begin(), ev.end(), E.begin() + (size_t)b * FT8RX_EVENT_CAP); }
+        std::vector<ft8rx_message> out((size_t)B * MC);
+        if (hostmsg::package_batch(R.data(), cnt.data(), E.data(), evc.data(), B, MC, out.data(), MC, oc.data(), 4, nullptr, fl.data())) return 3;
+        for (int b = 0; b < B; b++) { if (oc[b] != oc[0] || fl[b]) return 4; total += oc[b]; }
+        hostmsg::Hashes H;
+        if (hostmsg::package_batch(R.data(), cnt.data(), E.data(), evc.data(), B, MC, out.data(), MC, oc.data(), 4, &H, fl.data())) return 3;
+        evc[3] = FT8RX_EVENT_CAP + 100; cnt[5] = MC + 50;                      // overflowing counts are clamped and flagged
+        if (hostmsg::package_batch(R.data(), cnt.data(), E.data(), evc.data(), B, MC, out.data(), 3, oc.data(), 2, nullptr, fl.data())) return 3;
+        if (!(fl[3] & FT8RX_PKG_EVENTS_TRUNCATED) || !(fl[0] & FT8RX_PKG_MSG_TRUNCATED) || oc[0] != 3) return 5;
+        printf("frame dump: %d candidates, %d events, %d messages per frame\n", n, nev, (int)(total / B));
+    }
+    // (b) random words through unpack (all i3 values, hashed calls, boundaries) and the encoder
+    hostmsg::Hashes H; std::string f[3]; long ok = 0; uint8_t tones[79]; unsigned acc = 0;
+    for (int i = 0; i < 200000; i++) {
+        uint64_t lo = rng(), hi = rng() & 0x1FFF;
+        if (i % 3 == 0) lo = (lo & ~7ull) | 1;
+        if (i % 5 == 0) lo = (lo & ~7ull) | 4;
+        if (i % 7 == 0) { lo &= 0xFFFFFFFFFFFFull; hi = 0; }
+        ok += hostmsg::unpack(lo, hi, H, f);
+        if (i % 16 == 0) { hostmsg::encode_tones(lo, hi, tones); acc += tones[40]; }
+    }
+    printf("random words: %ld unpacked, %zu hash keys, tone checksum %u\n", ok, H.m.size(), acc);
+    return 0;
+}

@@ -32,7 +32,7 @@ def test_c_abi_exports_every_declared_symbol():
 def test_record_layouts_match_header():
     from pyft8_amd import _lib
     assert _lib.RECORD_DTYPE.itemsize == 48 and _lib.EVENT_DTYPE.itemsize == 24
-    assert ctypes.sizeof(_lib.Config) == 13 * 4
+    assert ctypes.sizeof(_lib.Config) == 15 * 4          # include/ft8rx.h: 13 reference-derived fields + osd_triple, osd_max_hd
     plans = _lib.fft_plans()
     assert int(np.prod(plans["plan1920"])) == 1920 and int(np.prod(plans["plan3200"])) == 3200
     assert int(np.prod(plans["plan300"])) * int(np.prod(plans["plan320"])) == 96000
@@ -144,6 +144,71 @@ def test_native_packager_matches_python_and_reference(name):
             assert a[key] == b[key]
     trunc = sorted(" ".join(x.decode() for x in m["f"]).replace("<...>", "#") for m in msgs[1][:cnt[1]])
     assert trunc == sorted(" ".join(m["msg_tuple"]).replace("<...>", "#") for m in js["messages"])
+
+
+def test_native_packager_flags_clamp_and_persistent_table(tmp_path):
+    """counts never exceed the message capacity (truncation is flagged, not silent), an overflowed event log is flagged
+    and warned about, and a persistent call-hash table carries hashed calls from one frame to the next (databases.py:8)."""
+    import warnings
+    from pyft8_amd import _lib, messages as M
+    audio, gold, js = load_golden("test_09")
+    rec, n, ev, nev = records_from_oracle(oracle_frame(audio))
+    evp = np.zeros(_lib.EVENT_CAP, _lib.EVENT_DTYPE); evp[:len(ev)] = ev[:_lib.EVENT_CAP]
+    recs, evs = rec[None], evp[None]
+    nmsg = len(js["messages"])
+    # capacity smaller than the message list: clamped + flagged + warned
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        msgs, cnt, flags = _lib.package_batch(recs, np.array([n], np.int32), evs, np.array([nev], np.int32), max_msgs=5, return_flags=True)
+    assert cnt[0] == 5 and msgs.shape == (1, 5) and flags[0] & _lib.PKG_MSG_TRUNCATED
+    assert any(issubclass(x.category, _lib.Ft8rxTruncationWarning) for x in w)
+    # default capacity = record capacity: cannot truncate
+    msgs, cnt, flags = _lib.package_batch(recs, np.array([n], np.int32), evs, np.array([nev], np.int32), return_flags=True)
+    assert cnt[0] == nmsg and flags[0] == 0 and msgs.shape[1] == recs.shape[1]
+    # event count beyond the log capacity: flagged
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _, cnt2, flags = _lib.package_batch(recs, np.array([n], np.int32), evs, np.array([_lib.EVENT_CAP + 7], np.int32), return_flags=True)
+    assert flags[0] & _lib.PKG_EVENTS_TRUNCATED and any(issubclass(x.category, _lib.Ft8rxTruncationWarning) for x in w)
+    # persistent table: test_09 prints "<...> OR18OSB RR73" (OR18OSB defines its hash there); a second pass over the same frame with
+    # the SAME table must resolve nothing new for standard calls but keeps the table filled; a fresh table per frame forgets
+    tab = _lib.CallHashTable()
+    assert len(tab) == 0
+    m1, c1 = _lib.package_batch(recs, np.array([n], np.int32), evs, np.array([nev], np.int32), table=tab)
+    assert len(tab) > 30                                   # 3 keys (10/12/22 bits) per call heard
+    texts1 = [" ".join(x.decode() for x in m["f"]) for m in m1[0][:c1[0]]]
+    assert texts1 == [" ".join(m["msg_tuple"]) for m in js["messages"]]
+    # a frame that refers to OR18OSB by hash only: i3 = 1 word with a hashed first call
+    tab2 = M.CallHashes(); tab2.add("OR18OSB")
+    h22 = [k for k in tab2.by_hash if k[1] == 22][0][0]
+    import oracle as O
+    n28 = 2063592 + h22
+    # "<OR18OSB> G4ABC IO91": build from the pieces of a golden standard message (call_b / grid of the first golden pack entry)
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "messages.json")))
+    w0 = int(d["pack"][0]["bits77"], 16)
+    word = (w0 & ((1 << 48) - 1)) | ((n28 << 1) << 48)
+    word = (word & ~7) | 1
+    r2 = np.zeros_like(rec); r2[0] = rec[0]; r2[0]["status"] = 1; r2[0]["ipass"] = 0; r2[0]["method"] = 0; r2[0]["ap"] = 0
+    r2[0]["msg_lo"] = word & (2 ** 64 - 1); r2[0]["msg_hi"] = word >> 64
+    e2 = np.zeros((1, _lib.EVENT_CAP), _lib.EVENT_DTYPE)
+    fresh, cf = _lib.package_batch(r2[None], np.array([1], np.int32), e2, np.array([0], np.int32))
+    kept, ck = _lib.package_batch(r2[None], np.array([1], np.int32), e2, np.array([0], np.int32), table=tab)
+    assert cf[0] == ck[0] == 1
+    assert fresh[0][0]["f"][0] == b"<...>" and kept[0][0]["f"][0] == b"<OR18OSB>"
+    tab.clear(); assert len(tab) == 0
+    tab.add("OR18OSB"); assert len(tab) == 3
+    # optional reject log (decoders.py:114-115): off by default, one line per rejected call when a path is set
+    log = tmp_path / "rejected_callsigns.txt"
+    bad = (w0 & ~(((1 << 29) - 1) << 48)) | ((((2063592 + 4194304 + 5) << 1)) << 48)      # call_a = an implausible 28-bit call
+    r3 = r2.copy(); r3[0]["msg_lo"] = bad & (2 ** 64 - 1); r3[0]["msg_hi"] = bad >> 64
+    _lib.package_batch(r3[None], np.array([1], np.int32), e2, np.array([0], np.int32))
+    assert not log.exists()
+    _lib.set_reject_log(str(log))
+    try:
+        _, c3 = _lib.package_batch(r3[None], np.array([1], np.int32), e2, np.array([0], np.int32))
+    finally:
+        _lib.set_reject_log(None)
+    assert c3[0] == 0 and log.exists() and len(log.read_text().split()) >= 1
 
 
 def test_native_packager_throughput():
