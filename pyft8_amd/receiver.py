@@ -38,7 +38,10 @@ def config_from_kwargs(sync_score_min=85, max_cands=200, search_freq_range=(100,
         sync_score_min=float(sync_score_min), max_cands=int(max_cands),
         f0_lo=int(search_freq_range[0] / df), f0_hi=int(search_freq_range[1] / df),
         h0_lo=int((search_time_range[0] + 0.5) * 4 * SYM_RATE), h0_hi=int((search_time_range[1] + 0.5) * 4 * SYM_RATE))
-    for k, v in ext.items():          # extension knobs: bp_iters_b, osd_single, osd_double, ...
+    known = {f[0] for f in _lib.Config._fields_}
+    for k, v in ext.items():          # extension knobs: bp_iters_b, osd_single, osd_double, osd_triple, osd_max_hd, ...
+        if k not in known:            # like the reference's fixed signature (e.g. the CLI's misspelt `search_timerange`, pyft8.py:137)
+            raise TypeError(f"Receiver() got an unexpected keyword argument '{k}'")
         setattr(cfg, k, v)
     return cfg
 

@@ -85,3 +85,45 @@ def special_message_words():
     take(lambda w, r: r.endswith(" RRR") or r.endswith(" 73"), 3)
     take(lambda w, r: " R+" in r or " R-" in r, 3)
     return pick
+
+
+def load_light_frames():
+    """The light goldens of oracle/gen_golden_light.py: (entry, audio) per frame; the audio is regenerated from the recipe."""
+    from pyft8_amd import synth
+    d = json.load(open(os.path.join(GOLDEN, "light_frames.json")))
+    out = []
+    for e in d["frames"]:
+        key = ("light", e["index"])
+        if key not in _cache:
+            _cache[key] = synth.make_frame(e["index"], n_signals=e["recipe"]["n_signals"], snr_range=tuple(e["recipe"]["snr_range"]))
+        out.append((e, _cache[key]))
+    return out
+
+
+def check_against_light_golden(e, cands, outcomes, msgs):
+    """cands: [(f0, h0)], outcomes: [(ipass, text) | None] per candidate, msgs: message dicts in emit order -- against one light
+    golden entry.  Everything must equal the REFERENCE's result, except on the frames that carry an `expected_difference` marker,
+    where the named candidates (and only those) must show the build's documented outcome instead.  -> number of messages."""
+    xd = e.get("expected_difference")
+    ref_c = [(c[0], c[1]) for c in e["cands"]]
+    want_c = [tuple(c) for c in xd["candidate_order_oracle"]] if xd and xd.get("candidate_order_oracle") else ref_c
+    assert list(cands) == want_c
+    ref_out = {kk: (tuple(o) if o else None) for kk, o in zip(ref_c, e["outcome"])}
+    special = {tuple(d["cand"]): (tuple(d["oracle"]) if d["oracle"] else None) for d in (xd["candidates"] if xd else [])}
+    for kk, o in zip(cands, outcomes):
+        assert o == (special[kk] if kk in special else ref_out[kk]), (e["index"], kk, o, ref_out[kk], special.get(kk))
+    txt = [" ".join(m["msg_tuple"]) for m in msgs]
+    if xd:
+        assert txt == xd["oracle_messages"], e["index"]
+        assert special and all(special[kk] != ref_out[kk] for kk in special)          # the marker names a real deviation
+    else:
+        assert txt == [" ".join(m["msg_tuple"]) for m in e["messages"]], e["index"]
+    by_txt = {" ".join(m["msg_tuple"]): m for m in e["messages"]}
+    moved = {o[1] for o in list(special.values()) + [ref_out[kk] for kk in special] if o}
+    for m in msgs:
+        ref = by_txt.get(" ".join(m["msg_tuple"]))
+        if ref is None or " ".join(m["msg_tuple"]) in moved:
+            continue
+        for key in ("tsec", "fHz", "their_snr", "all_txt_format", "tweaks", "decode_notes", "cyclestart_string", "their_tx_cycle"):
+            assert m[key] == ref[key], (e["index"], key, m[key], ref[key])
+    return len(txt)

@@ -274,6 +274,42 @@ def test_decode_batch_golden_frames(H, ocfg):
         _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], load_golden(name)[2], ocfg)
 
 
+def test_light_goldens_on_the_gpu():
+    """28 more frames pinned to the REAL reference (tests/golden/light_frames.json, oracle/gen_golden_light.py): every Receiver kwargs
+    set of the live cross-check, plus the five frames where the build knowingly deviates (OSD tie order, last-ulp LLR) with their
+    expected-difference markers -- candidate lists, per-candidate (ipass, text) and all message dict fields, through the C ABI."""
+    from conftest import check_against_light_golden, load_light_frames
+    from pyft8_amd import _lib, messages as M
+    from pyft8_amd.receiver import config_from_kwargs
+    groups = {}
+    for e, audio in load_light_frames():
+        groups.setdefault(json.dumps(e["kwargs"], sort_keys=True), []).append((e, audio))
+    n_msgs = n_dev = 0
+    for key, items in groups.items():
+        cfg = config_from_kwargs(**json.loads(key))
+        h = _lib.Handle(cfg, max_frames=len(items))
+        rec, cnt, ev, evc = h.decode_batch(np.stack([a for _, a in items]))
+        h.close()
+        for i, (e, audio) in enumerate(items):
+            n = int(cnt[i])
+            cands = [(int(r["f0_idx"]), int(r["h0_idx"])) for r in rec[i, :n]]
+            tab = M.CallHashes()
+            outs = []
+            for r in rec[i, :n]:
+                if int(r["status"]) == 1:
+                    t = M.unpack((int(r["msg_hi"]) << 64) | int(r["msg_lo"]), tab)
+                    outs.append((int(r["ipass"]), " ".join(t or ())))
+                else:
+                    outs.append(None)
+            msgs = M.package_frame(rec[i], n, ev[i], int(evc[i]), cyclestart_string="700101_000015")
+            for (f0, h0, sc), r in zip(e["cands"], rec[i, :n]):
+                if "expected_difference" not in e:
+                    assert abs(float(r["score"]) - sc) <= 1e-5 * abs(sc)
+            n_msgs += check_against_light_golden(e, cands, outs, msgs)
+            n_dev += "expected_difference" in e
+    assert n_msgs > 400 and n_dev == 5
+
+
 def test_decode_batch_synthetic_vs_oracle(H, ocfg):
     from pyft8_amd import synth
     audio = synth.make_batch(1000, 8)

@@ -44,6 +44,8 @@ def test_config_from_receiver_kwargs():
     assert (c.f0_lo, c.f0_hi, c.h0_lo, c.h0_hi, c.max_cands, c.sync_score_min) == (32, 960, -37, 87, 200, 85.0)
     c = config_from_kwargs(sync_score_min=100, max_cands=150, bp_iters_b=30)        # pyft8.py:136 intent + extension knob
     assert (c.max_cands, c.sync_score_min, c.bp_iters_b) == (150, 100.0, 30)
+    with pytest.raises(TypeError):                                                  # pyft8.py:137 passes `search_timerange`: the
+        config_from_kwargs(search_timerange=[-2, 3])                                # reference's constructor rejects it, so does this one
 
 
 @pytest.mark.parametrize("name", GOLDEN_FRAMES)
