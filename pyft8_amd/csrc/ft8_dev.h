@@ -220,19 +220,29 @@ struct Fused2 {
 // 8 tones of one 32-sample symbol, shared by 4 lanes (n2 = lane & 3):  32 = 4 x 8 decimation in time.
 //   u[k] = DFT8_k(x[4 n1 + n2]) on lane n2;  X[k] = ((u0 + u1 W^k) + u2 W^2k) + u3 W^3k on the quad leader.
 // `x` holds this lane's 8 samples; returns |X[k]| in mag[0..7] (valid on lanes with n2 == 0).
-FT8_DEV void sym32_quad(cpx* x, int n2, int lane, const cpx* __restrict__ w32, float* mag) {
+// The quad sum uses DPP quad_perm broadcasts (lane o of the quad as the second operand of a plain v_add): the same three adds in the
+// same order as a shuffle-based reduction, without the LDS crossbar round trips of ds_bpermute.
+template <int O> FT8_DEV float quad_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x55 * O, 0xf, 0xf, true));      // quad_perm:[O,O,O,O]
+}
+// NT = number of tones wanted (7: a Costas score never reads tone 7, receiver.py:203); wq[k] = W32^(n2 k), this lane's twiddles,
+// loaded once per thread (sym32_twiddles).
+FT8_DEV void sym32_twiddles(const cpx* __restrict__ w32, int n2, cpx* wq) {
+#pragma unroll
+    for (int k = 1; k < 8; k++) wq[k] = w32[(n2 * k) & 31];
+    wq[0] = make_float2(1.0f, -0.0f);
+}
+template <int NT>
+FT8_DEV void sym32_quad(cpx* x, int n2, const cpx* wq, float* mag) {
     dft<8>(x);
-    const int base = lane & ~3;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < NT; k++) {
         cpx t = x[k];
-        if (k != 0 && n2 != 0) t = cmul(t, w32[(n2 * k) & 31]);
+        if (k != 0) t = (n2 != 0) ? cmul(t, wq[k]) : t;        // (select, not a branch: the quad leader's W^0 term is used as is)
         cpx acc = t;                                   // quad leader: its own term is u0
-#pragma unroll
-        for (int o = 1; o < 4; o++) {
-            cpx v = make_float2(__shfl(t.x, base + o), __shfl(t.y, base + o));
-            acc = cadd(acc, v);
-        }
+        acc = cadd(acc, make_float2(quad_lane<1>(t.x), quad_lane<1>(t.y)));
+        acc = cadd(acc, make_float2(quad_lane<2>(t.x), quad_lane<2>(t.y)));
+        acc = cadd(acc, make_float2(quad_lane<3>(t.x), quad_lane<3>(t.y)));
         mag[k] = sqrtf(acc.x * acc.x + acc.y * acc.y);
     }
 }

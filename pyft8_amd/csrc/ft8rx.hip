@@ -831,6 +831,17 @@ int ft8rx_set_reject_log(const char* path) {
     return 0;
 }
 
+#ifdef FINE_TIMING
+int ft8rx_debug_fine_times(ft8rx_handle* h, unsigned long long* out32, int reset) {      // timing-only builds (tools/fine_timing.sh)
+    if (!h) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    if (out32) HIPCHK(h, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_fine_t), sizeof(unsigned long long) * 32));
+    if (reset) { unsigned long long z[32] = {0}; HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_fine_t), z, sizeof(z))); }
+    return 0;
+}
+#endif
+
 int ft8rx_math_probe(ft8rx_handle* h, int which, const float* x, int n, float* y) {
     if (!h || !x || !y || n < 1) return -1;
     HIPCHK(h, hipSetDevice(h->device));

@@ -16,53 +16,81 @@
 #endif
 #define FINE_INV 0.0003125f
 
-// conj(taper * spec) for bin k of the rolled 3200-bin slice (receiver.py:180-185); k < 850 or k >= 3050.
-// `sl` is the candidate's spectrum window staged in LDS: sl[i] = spec[fb0 - 182 + i], i < 1064 (covers every ftweak);
-// off = ftweak + 182.
+// Input of the inverse transform = conj(taper * spec) over the rolled 3200-bin slice (receiver.py:180-185); bins 850 .. 3049 are zero.
+// `sl` is the candidate's spectrum window staged in LDS: sl[i] = spec[fb0 - 182 + i], i < 1064 (covers every ftweak); off = ftweak + 182:
+//   bin k < 850         = sl[off + k],              tapered by taper[k - 750] for k >= 750
+//   bin k = 3050 + j    = sl[off - 150 + j],        tapered by taper[j] for j < 100
+// Taper products are formed in fp64 and rounded once (the reference multiplies complex64 by a float64 ramp).
 #define FINE_SLICE 1064
-FT8_DEV cpx fine_input(const cpx* sl, int off, int k, const double* __restrict__ taper) {
-    cpx v; int ti;
-    if (k < 850) { v = sl[off + k]; ti = (k >= 750) ? k - 750 : -1; }
-    else { const int j = k - 3050; v = sl[off - 150 + j]; ti = (j < 100) ? j : -1; }
-    if (ti >= 0) { const double t = taper[ti]; v.x = (float)((double)v.x * t); v.y = (float)((double)v.y * t); }
-    v.y = -v.y;
-    return v;
-}
+FT8_DEV cpx fine_taper(cpx v, double t) { return make_float2((float)((double)v.x * t), (float)((double)v.y * t)); }
+FT8_DEV cpx fine_conj(cpx v) { return make_float2(v.x, -v.y); }
 
 // forward FFT of the conjugated slice into z (unscaled, unconjugated), natural Stockham layout, in place.
 // (Measured alternatives, profiles/r01_notes.md: 256-thread blocks 7.96 ms, bank-conflict-free padded/transposed
 // inter-stage layouts 6.92 ms, this version 6.36 ms per 256 frames: the kernel is latency/barrier bound.)
-
-// The stages are written for any FINE_NT in {64, 128}: a thread owns ceil(groups / FINE_NT) groups of each stage,
-// loads all of them, passes the barrier, then computes and stores them (in place).  With FINE_NT = 64 the block is a
-// single wavefront, the "barriers" are free and every lane carries 3-4 independent groups (ILP instead of TLP).
+//
+// Pass [8]: n = 3200, s = 1, m = 400: butterfly p reads bins p + 400 j, of which only j = 0, 1, (2 if p < 50), (7 if p >= 250) are
+// non-zero.  Thread tid owns p = tid + 128 i, i < 4 (i = 3: tid < 16).  The code is STRAIGHT-LINE: every load of the stage is issued
+// up front from clamped addresses and absent / untapered inputs are resolved by selects, never by divergent branches -- a branch
+// around a dependent LDS or table load costs a full round trip per basic block (the r01 kernel had 13 of them in this stage; r02_notes).
+// Which inputs exist / are tapered is static per round:
+//   i = 0 (p <  128): bins p, p+400;            p+800 (tapered, index p + 50) for p < 50
+//   i = 1 (p <  256): bins p, p+400;            p+2800 = 3050 + (p-250) (tapered) for p >= 250
+//   i = 2 (p <  384): bins p, p+400 (tapered for p >= 350), p+2800 (tapered for p < 350): exactly one of the two is tapered
+//   i = 3 (p <  400): bins p, p+400 (tapered, index p - 350), p+2800 (untapered)
+// Twiddle multiplies are unconditional: W^0 = (1, -0) is an exact identity (the skip rule "j p = 0" of the contract only avoids it).
+static_assert(FINE_NT == 128, "fine_stage1 is written for 128 threads");
 FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W,
                          const double* __restrict__ taper, int tid) {
-    // pass [8]: n = 3200, s = 1, m = 400: butterfly p reads bins p + 400 j; only j = 0, 1, (2 if p < 50), (7 if p >= 250)
-    // are non-zero.  All global loads of the thread are issued before the first butterfly.
-    constexpr int R = (400 + FINE_NT - 1) / FINE_NT;
     const cpx zero = make_float2(0.0f, 0.0f);
-    cpx in0[R], in1[R], in7[R], in2;
+    const cpx* s0 = S + fb + tid;                    // bin p of round i at s0[128 i]
+    const cpx* s7 = S + fb - 150 - 250 + tid;        // bin p + 2800 = 3050 + (p - 250) of round i at s7[128 i]
+    // ---- loads (LDS slice + taper table), all issued before the first butterfly
+    const cpx a00 = s0[0], a01 = s0[400];
+    const cpx a10 = s0[128], a11 = s0[528];
+    const cpx a20 = s0[256], a21 = s0[656];
+    const bool r3 = tid < 16;
+    const int t3 = r3 ? tid : 0;
+    const cpx a30 = s0[384 + t3 - tid], a31 = s0[784 + t3 - tid];
+    const bool has02 = tid < 50;
+    const cpx a02r = s0[has02 ? 800 : 0];
+    const double t02 = taper[has02 ? tid + 50 : 0];
+    const bool has17 = tid >= 122;                    // p = tid + 128 >= 250
+    const cpx a17r = s7[has17 ? 128 : 250];           // (250: any in-range address, p = tid + 250)
+    const double t17 = taper[has17 ? tid - 122 : 0];
+    const cpx a27r = s7[256];                          // p = tid + 256 >= 250 always
+    const bool tap21 = tid >= 94;                      // p >= 350: bin p + 400 is tapered (index p - 350), else bin p + 2800 (index p - 250)
+    const double t2 = taper[tap21 ? tid - 94 : tid + 6];
+    const cpx a37r = s7[384 + t3 - tid];
+    const double t31 = taper[34 + t3];                 // p + 400 - 750 = 34 + tid
+    // ---- resolve
+    const cpx a02 = has02 ? fine_taper(a02r, t02) : zero;
+    const cpx a17 = has17 ? fine_taper(a17r, t17) : zero;
+    const cpx sel2 = fine_taper(tap21 ? a21 : a27r, t2);
+    const cpx b21 = tap21 ? sel2 : a21, a27 = tap21 ? a27r : sel2;
+    const cpx b31 = fine_taper(a31, t31);
+    cpx a[4][8];
 #pragma unroll
-    for (int i = 0; i < R; i++) {
-        const int p = tid + FINE_NT * i;
-        const bool on = p < 400;
-        in0[i] = on ? fine_input(S, fb, p, taper) : zero;
-        in1[i] = on ? fine_input(S, fb, p + 400, taper) : zero;
-        in7[i] = (on && p >= 250) ? fine_input(S, fb, p + 2800, taper) : zero;
-    }
-    in2 = (tid < 50) ? fine_input(S, fb, tid + 800, taper) : zero;
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int i = 0; i < R; i++) {
-        const int p = tid + FINE_NT * i;
-        if (p < 400) {
-            cpx a[8];
-            a[0] = in0[i]; a[1] = in1[i]; a[2] = (i == 0) ? in2 : zero;
-            a[3] = zero; a[4] = zero; a[5] = zero; a[6] = zero; a[7] = in7[i];
-            dft<8>(a);
-            z[8 * p] = a[0];
+        for (int j = 2; j < 7; j++) a[i][j] = zero;
+    a[0][0] = fine_conj(a00); a[0][1] = fine_conj(a01); a[0][2] = fine_conj(a02); a[0][7] = zero;
+    a[1][0] = fine_conj(a10); a[1][1] = fine_conj(a11); a[1][7] = fine_conj(a17);
+    a[2][0] = fine_conj(a20); a[2][1] = fine_conj(b21); a[2][7] = fine_conj(a27);
+    a[3][0] = fine_conj(a30); a[3][1] = fine_conj(b31); a[3][7] = fine_conj(a37r);
 #pragma unroll
-            for (int j = 1; j < 8; j++) { cpx v = a[j]; if (p != 0) v = cmul(v, W[j * p]); z[8 * p + j] = v; }
+    for (int i = 0; i < 4; i++) {
+        const int p = tid + 128 * i;
+        const int pw = (i < 3) ? p : 384 + t3;          // clamped: twiddle addresses stay in range for the idle threads of round 3
+        cpx w[8];
+#pragma unroll
+        for (int j = 1; j < 8; j++) w[j] = W[j * pw];
+        dft<8>(a[i]);
+#pragma unroll
+        for (int j = 1; j < 8; j++) a[i][j] = cmul(a[i][j], w[j]);
+        if (i < 3 || r3) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) z[8 * p + j] = a[i][j];
         }
     }
     __syncthreads();
@@ -85,11 +113,9 @@ FT8_DEV void fine_stage2(cpx* z, const cpx* w400, int tid) {
 #pragma unroll
             for (int jp = 0; jp < 4; jp++) {
                 dft<4>(a[r][jp]);
-                const int pq = pp + 25 * jp;
-                if (pq != 0) {
+                const int pq = pp + 25 * jp;            // (pq = 0: W^0 = (1, -0), an exact identity -- no branch)
 #pragma unroll
-                    for (int j = 1; j < 4; j++) a[r][jp][j] = cmul(a[r][jp][j], w400[j * pq]);
-                }
+                for (int j = 1; j < 4; j++) a[r][jp][j] = cmul(a[r][jp][j], w400[j * pq]);
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -97,10 +123,8 @@ FT8_DEV void fine_stage2(cpx* z, const cpx* w400, int tid) {
 #pragma unroll
                 for (int jp = 0; jp < 4; jp++) b[jp] = a[r][jp][j];
                 dft<4>(b);
-                if (pp != 0) {
 #pragma unroll
-                    for (int jp = 1; jp < 4; jp++) b[jp] = cmul(b[jp], w400[4 * jp * pp]);
-                }
+                for (int jp = 1; jp < 4; jp++) b[jp] = cmul(b[jp], w400[4 * jp * pp]);
 #pragma unroll
                 for (int jp = 0; jp < 4; jp++) a[r][jp][j] = b[jp];
             }
@@ -147,13 +171,14 @@ FT8_DEV void fine_fft(const cpx* S, int fb, cpx* z, const cpx* w400, const Table
 }
 
 // |32-pt DFT| tones 0..7 of the symbol starting at sample i0, computed by the 4 lanes of a quad
-FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, int lane, const cpx* w32, float* mag) {
+template <int NT>
+FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, const cpx* wq, float* mag) {
     if (i0 < 0) i0 = 0;
     if (i0 > 3168) i0 = 3168;
     cpx x[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; n1++) { cpx v = z[i0 + 4 * n1 + n2]; x[n1] = make_float2(v.x * FINE_INV, -(v.y * FINE_INV)); }
-    sym32_quad(x, n2, lane, w32, mag);
+    sym32_quad<NT>(x, n2, wq, mag);
 }
 
 __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
@@ -189,6 +214,8 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         __syncthreads();
     }
     const cpx* S = slice;
+    cpx wq[8];
+    sym32_twiddles(w32, tid & 3, wq);                             // every symbol DFT of this thread uses n2 = tid & 3
     const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
     // Score of one Costas block (contract): per symbol a the quad leader forms on_a = |tone costas[a]| and off_a = sum of
     // the other six tones (b ascending) in fp64 from its registers; after ONE barrier every thread combines
@@ -202,12 +229,12 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         const bool valid = qd < 56;
         const int ti = valid ? qd / 7 : 0, a = valid ? qd - 7 * ti : 0;
         float mag[8];
-        fine_sym_quad(z, tb0 - 8 + 2 * ti + 32 * (36 + a), n2, lane, w32, mag);
+        fine_sym_quad<7>(z, tb0 - 8 + 2 * ti + 32 * (36 + a), n2, wq, mag);
         if (valid && n2 == 0) {
             const int c = d_COSTAS[a];
-            double off = 0.0, on = 0.0;
+            double off = 0.0, on = 0.0;         // branch-free: adding +0.0 for the Costas tone leaves the running sum unchanged
 #pragma unroll
-            for (int b = 0; b < 7; b++) { if (b == c) on = (double)mag[b]; else off += (double)mag[b]; }
+            for (int b = 0; b < 7; b++) { const double m = (double)mag[b]; on = (b == c) ? m : on; off += (b == c) ? 0.0 : m; }
             dsum[(ti * 7 + a) * 2] = on; dsum[(ti * 7 + a) * 2 + 1] = off;
         }
     }
@@ -233,12 +260,12 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
                 const int qd = tid >> 2, n2 = tid & 3;
                 const bool valid = qd < 7;
                 float mag[8];
-                fine_sym_quad(z, tb0 + tt + 32 * (36 + (valid ? qd : 0)), n2, lane, w32, mag);
+                fine_sym_quad<7>(z, tb0 + tt + 32 * (36 + (valid ? qd : 0)), n2, wq, mag);
                 if (valid && n2 == 0) {
                     const int c = d_COSTAS[qd];
                     double off = 0.0, on = 0.0;
 #pragma unroll
-                    for (int b = 0; b < 7; b++) { if (b == c) on = (double)mag[b]; else off += (double)mag[b]; }
+                    for (int b = 0; b < 7; b++) { const double m = (double)mag[b]; on = (b == c) ? m : on; off += (b == c) ? 0.0 : m; }
                     dsum[qd * 2] = on; dsum[qd * 2 + 1] = off;
                 }
             }
@@ -256,7 +283,7 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;
         const bool valid = sy < 79;
         float mag[8];
-        fine_sym_quad(z, tb0 + tt + 32 * (valid ? sy : 0), n2, lane, w32, mag);
+        fine_sym_quad<8>(z, tb0 + tt + 32 * (valid ? sy : 0), n2, wq, mag);
         if (valid && n2 == 0) {
 #pragma unroll
             for (int b = 0; b < 8; b++) mg[sy * 8 + b] = mag[b];
