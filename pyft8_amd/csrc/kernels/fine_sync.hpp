@@ -15,6 +15,29 @@
 #define FINE_WV 2
 #endif
 #define FINE_INV 0.0003125f
+#ifndef FINE_UNROLL_SCAN
+#define FINE_UNROLL_SCAN 1
+#endif
+#ifndef FINE_UNROLL_GRID
+#define FINE_UNROLL_GRID 1
+#endif
+
+// Timing-only instrumentation (build with -DFINE_TIMING, tools/fine_timing.py; never defined in the product): wave 0 of every block
+// accumulates the shader cycles between consecutive marks into an LDS table and flushes it to g_fine_t[] once at the end.
+#ifdef FINE_TIMING
+__device__ unsigned long long g_fine_t[32];
+#define FT_DECL __shared__ unsigned long long ft_l[16]; if (tid < 16) ft_l[tid] = 0; __syncthreads(); unsigned long long ft_prev = __builtin_readcyclecounter();
+#define FT_ARG , unsigned long long& ft_prev, unsigned long long* ft_l
+#define FT_PASS , ft_prev, ft_l
+#define FT(i) do { if (tid == 0) { unsigned long long ft_now = __builtin_readcyclecounter(); ft_l[i] += ft_now - ft_prev; ft_prev = __builtin_readcyclecounter(); } } while (0)
+#define FT_FLUSH do { __syncthreads(); if (tid < 16) atomicAdd(&g_fine_t[tid], ft_l[tid]); } while (0)
+#else
+#define FT_DECL
+#define FT_ARG
+#define FT_PASS
+#define FT(i) do { } while (0)
+#define FT_FLUSH do { } while (0)
+#endif
 
 // Input of the inverse transform = conj(taper * spec) over the rolled 3200-bin slice (receiver.py:180-185); bins 850 .. 3049 are zero.
 // `sl` is the candidate's spectrum window staged in LDS: sl[i] = spec[fb0 - 182 + i], i < 1064 (covers every ftweak); off = ftweak + 182:
@@ -41,7 +64,7 @@ FT8_DEV cpx fine_conj(cpx v) { return make_float2(v.x, -v.y); }
 // Twiddle multiplies are unconditional: W^0 = (1, -0) is an exact identity (the skip rule "j p = 0" of the contract only avoids it).
 static_assert(FINE_NT == 128, "fine_stage1 is written for 128 threads");
 FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W,
-                         const double* __restrict__ taper, int tid) {
+                         const double* __restrict__ taper, int tid FT_ARG) {
     const cpx zero = make_float2(0.0f, 0.0f);
     const cpx* s0 = S + fb + tid;                    // bin p of round i at s0[128 i]
     const cpx* s7 = S + fb - 150 - 250 + tid;        // bin p + 2800 = 3050 + (p - 250) of round i at s7[128 i]
@@ -92,17 +115,24 @@ FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W
 #pragma unroll
             for (int j = 0; j < 8; j++) z[8 * p + j] = a[i][j];
         }
+#ifdef FINE_S1_SPLIT
+        if (i == 1) __builtin_amdgcn_sched_barrier(0);        // (experiment) two rounds at a time: lower register pressure
+#endif
     }
+    FT(1);
     __syncthreads();
+    FT(2);
 }
-FT8_DEV void fine_stage2(cpx* z, const cpx* w400, int tid) {
+FT8_DEV void fine_stage2(cpx* z, const cpx* w400, int tid FT_ARG) {
     typedef Fused2<3200, 400, 8, 4, 4> F;                         // passes [4,4]: n = 400, s = 8; 200 groups
     constexpr int R = (F::groups + FINE_NT - 1) / FINE_NT;
     cpx a[R][4][4];
     // group g = (pp = g / 8, q = g % 8): in  q + 8(pp + 25 j' + 100 j),  out  q + 8 j + 32 (4 pp + j')
 #pragma unroll
     for (int r = 0; r < R; r++) { const int g = tid + FINE_NT * r; if (g < F::groups) F::load_affine<200, 800>(z, g, a[r]); }
+    FT(3);
     __syncthreads();
+    FT(4);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int g = tid + FINE_NT * r;
@@ -131,19 +161,23 @@ FT8_DEV void fine_stage2(cpx* z, const cpx* w400, int tid) {
             F::store_affine<32, 8>(z, (g & 7) + 128 * (g >> 3), a[r]);
         }
     }
+    FT(5);
     __syncthreads();
+    FT(6);
 }
 // Only output samples in [lo, hi) are needed (the scoring IFFTs read one Costas block = ~230 samples): a final
 // radix-5 butterfly (q, j) produces samples q + 128 j + 640 j', at most one of which can fall in a window
 // shorter than 640, so butterflies with no sample in the window are skipped.  Needed outputs are bit-identical.
-FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int hi) {
+FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int hi FT_ARG) {
     typedef Fused2<3200, 25, 128, 5, 5> F;                        // passes [5,5]: n = 25, s = 128; 128 groups
     constexpr int R = F::groups / FINE_NT;
     cpx a[R][5][5];
     // group q: in  q + 128 (j' + 5 j),  out  q + 128 j + 640 j'
 #pragma unroll
     for (int r = 0; r < R; r++) F::load_affine<128, 640>(z, tid + FINE_NT * r, a[r]);
+    FT(7);
     __syncthreads();
+    FT(8);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int q = tid + FINE_NT * r;
@@ -162,12 +196,20 @@ FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int
             }
         }
     }
+    FT(9);
     __syncthreads();
+    FT(10);
 }
-FT8_DEV void fine_fft(const cpx* S, int fb, cpx* z, const cpx* w400, const Tables& T, int tid, int lo, int hi) {
-    fine_stage1(S, fb, z, T.W3200, T.taper, tid);
-    fine_stage2(z, w400, tid);
-    fine_stage3(z, T.W3200, tid, lo, hi);
+#ifdef FINE_NOINLINE
+__device__ __attribute__((noinline))
+#else
+FT8_DEV
+#endif
+void fine_fft(const cpx* S, int fb, cpx* z, const cpx* w400, const Tables& T, int tid, int lo, int hi FT_ARG) {
+    FT(0);
+    fine_stage1(S, fb, z, T.W3200, T.taper, tid FT_PASS);
+    fine_stage2(z, w400, tid FT_PASS);
+    fine_stage3(z, T.W3200, tid, lo, hi FT_PASS);
 }
 
 // |32-pt DFT| tones 0..7 of the symbol starting at sample i0, computed by the 4 lanes of a quad
@@ -186,7 +228,15 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
                                                   const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
                                                   float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
     __shared__ cpx z[3200];
+#ifndef FINE_NO_SLICE
     __shared__ cpx slice[FINE_SLICE];  // the candidate's 1064 spectrum bins, read by the first stage of all ten IFFTs
+#else
+    cpx* slice = z;                    // (experiment) no staging: stage 1 reads the spectrum window from global memory; the LLR scratch aliases z
+#endif
+#ifdef FINE_PAD_LDS                    /* (experiment) fewer k_fine blocks per CU, leaving LDS and registers for other streams' kernels */
+    __shared__ float pad_lds[FINE_PAD_LDS];
+    if (cfg.max_cands < 0) { pad_lds[threadIdx.x * 17 % FINE_PAD_LDS] = 1.0f; __syncthreads(); if (t_sd) t_sd[0] = pad_lds[cfg.max_cands & 1023]; }
+#endif
     __shared__ __attribute__((aligned(8))) float mg[640];   // scoring (on, off) sums as fp64, later the [79][8] grid
     __shared__ cpx w400[400];          // W3200[8 t]: every twiddle of the [4,4] stage
     float* p = reinterpret_cast<float*>(slice);      // [464] the slice is dead once the last IFFT has run: reuse it
@@ -209,11 +259,18 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
     const int fb0 = 50 * f0;                                      // int(0.5 + fHz*16)
     {
         const cpx* __restrict__ Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
+#ifndef FINE_NO_SLICE
         for (int i = tid; i < FINE_SLICE; i += FINE_NT) slice[i] = Sg[i];
+#endif
         for (int i = tid; i < 400; i += FINE_NT) w400[i] = T.W3200[8 * i];
         __syncthreads();
     }
+#ifndef FINE_NO_SLICE
     const cpx* S = slice;
+#else
+    const cpx* __restrict__ S = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
+#endif
+    FT_DECL
     cpx wq[8];
     sym32_twiddles(w32, tid & 3, wq);                             // every symbol DFT of this thread uses n2 = tid & 3
     const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
@@ -222,8 +279,8 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
     // S1 = sum_a on_a, S2 = sum_a off_a (a ascending) and score = (float)(S1 + w6 S2) -- no serial chain, no broadcast.
     double* dsum = reinterpret_cast<double*>(mg);              // [8][7][2] (on, off); mg is free until the final grid
     // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
-    fine_fft(S, 182, z, w400, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43);   // the 8 time tweaks of the middle Costas block
-#pragma unroll 1
+    fine_fft(S, 182, z, w400, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43 FT_PASS);   // the 8 time tweaks of the middle Costas block
+#pragma unroll FINE_UNROLL_SCAN
     for (int r = 0; r < (224 + FINE_NT - 1) / FINE_NT; r++) {
         const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
         const bool valid = qd < 56;
@@ -255,7 +312,7 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         float s;
         if (fcur == 0) s = score_f0;             // same series, same offset: identical value
         else {
-            fine_fft(S, 182 + fcur, z, w400, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43);
+            fine_fft(S, 182 + fcur, z, w400, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43 FT_PASS);
             if (tid < 64) {                       // 7 symbols x 4 lanes on wavefront 0
                 const int qd = tid >> 2, n2 = tid & 3;
                 const bool valid = qd < 7;
@@ -269,7 +326,9 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
                     dsum[qd * 2] = on; dsum[qd * 2 + 1] = off;
                 }
             }
+            FT(11);
             __syncthreads();
+            FT(12);
             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int a = 0; a < 7; a++) { s1 += dsum[a * 2]; s2 += dsum[a * 2 + 1]; }
@@ -277,8 +336,8 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         }
         if (i == 0 || s > best) { best = s; ft = fcur; }
     }
-    fine_fft(S, 182 + ft, z, w400, T, tid, 0, 3200);   // full series for the 79 x 8 grid
-#pragma unroll 1
+    fine_fft(S, 182 + ft, z, w400, T, tid, 0, 3200 FT_PASS);   // full series for the 79 x 8 grid
+#pragma unroll FINE_UNROLL_GRID
     for (int r = 0; r < (316 + FINE_NT - 1) / FINE_NT; r++) {                 // full 79 x 8 grid
         const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;
         const bool valid = sy < 79;
@@ -315,6 +374,8 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         float* out = llr0 + (size_t)blockIdx.x * 174;
         for (int i = tid; i < 174; i += FINE_NT) out[i] = llr[i];
     }
+    FT(13);
+    FT_FLUSH;
     if (tid == 0) {
         if (trip) { int32_t* o = t_out + 5 * (size_t)blockIdx.x; o[0] = ret; o[1] = tt; o[2] = ft; o[3] = nsync; o[4] = snr; t_sd[blockIdx.x] = sd; }
         else {

@@ -15,31 +15,34 @@ FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __r
                              cpx* z, cpx* w240, int tid) {
     const cpx* __restrict__ W = T.W1920;
     for (int i = tid; i < 240; i += SPEC_NT) w240[i] = W[8 * i];
-    {   // pass [8]: n = 1920, s = 1, m = 240: butterfly p reads samples m = p + 240 j
+    {   // pass [8]: n = 1920, s = 1, m = 240: butterfly p reads samples m = p + 240 j.  Straight-line: loads from clamped addresses,
+        // zeros by select (hops before the frame start), twiddle multiplies unconditional (W^0 = (1, -0) is an exact identity).
         cpx v[2][8];
+        cpx w[2][8];
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int p = tid + SPEC_NT * i;
+            const int pc = (p < 240) ? p : 239;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const int m = p + 240 * j, i0 = base + 2 * m;
-                float x0 = 0.0f, x1 = 0.0f;
-                if (p < 240 && i0 >= 0) {
-                    const short2 sm = *reinterpret_cast<const short2*>(a + i0);
-                    const float2 w = *reinterpret_cast<const float2*>(T.win + 2 * m);
-                    x0 = (float)sm.x * w.x; x1 = (float)sm.y * w.y;
-                }
-                v[i][j] = make_float2(x0, x1);
+                const int m = pc + 240 * j, i0 = base + 2 * m;
+                const short2 sm = *reinterpret_cast<const short2*>(a + (i0 >= 0 ? i0 : 0));
+                const float2 wn = *reinterpret_cast<const float2*>(T.win + 2 * m);
+                const float x0 = (float)sm.x * wn.x, x1 = (float)sm.y * wn.y;
+                v[i][j] = (i0 >= 0) ? make_float2(x0, x1) : make_float2(0.0f, 0.0f);
             }
+#pragma unroll
+            for (int j = 1; j < 8; j++) w[i][j] = W[j * pc];
         }
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int p = tid + SPEC_NT * i;
-            if (p < 240) {
-                dft<8>(v[i]);
-                z[8 * p] = v[i][0];
+            dft<8>(v[i]);
 #pragma unroll
-                for (int j = 1; j < 8; j++) { cpx t = v[i][j]; if (p != 0) t = cmul(t, W[j * p]); z[8 * p + j] = t; }
+            for (int j = 1; j < 8; j++) v[i][j] = cmul(v[i][j], w[i][j]);
+            if (p < 240) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) z[8 * p + j] = v[i][j];
             }
         }
     }
@@ -56,10 +59,8 @@ FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __r
             for (int jp = 0; jp < 4; jp++) {
                 dft<4>(v[jp]);
                 const int pq = pp + 15 * jp;
-                if (pq != 0) {
 #pragma unroll
-                    for (int j = 1; j < 4; j++) v[jp][j] = cmul(v[jp][j], w240[j * pq]);          // W1920[j p 8]
-                }
+                for (int j = 1; j < 4; j++) v[jp][j] = cmul(v[jp][j], w240[j * pq]);          // W1920[j p 8]
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -67,10 +68,8 @@ FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __r
 #pragma unroll
                 for (int jp = 0; jp < 4; jp++) u[jp] = v[jp][j];
                 dft<4>(u);
-                if (pp != 0) {
 #pragma unroll
-                    for (int jp = 1; jp < 4; jp++) u[jp] = cmul(u[jp], w240[4 * jp * pp]);        // W1920[j' pp 32]
-                }
+                for (int jp = 1; jp < 4; jp++) u[jp] = cmul(u[jp], w240[4 * jp * pp]);        // W1920[j' pp 32]
 #pragma unroll
                 for (int jp = 0; jp < 4; jp++) v[jp][j] = u[jp];
             }
