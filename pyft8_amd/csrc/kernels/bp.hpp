@@ -9,7 +9,10 @@
 // reference's np.add.at order; everything exchanged through LDS; parity via __ballot.
 // mode 0: pipeline ipass 0 (GOOD91 then BP(nc0_a, iters_a)), mode 1: pipeline fine stage
 // (GOOD91 for ap<2, BP(nc0_b, iters_b), save output llr), mode 2: raw vectors (tests).
-__global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ llr_in, ft8rx_record* __restrict__ rec,
+#ifndef BP_WV
+#define BP_WV 7          /* <= 72 VGPRs: 7 waves per SIMD; measured 1.76 -> 1.68 ms for both BP launches (profiles/r02_notes.md) */
+#endif
+__global__ __launch_bounds__(64, BP_WV) void k_bp(int mode, const float* __restrict__ llr_in, ft8rx_record* __restrict__ rec,
                                            const int32_t* __restrict__ ncand, Att* __restrict__ attG, Att* __restrict__ attB,
                                            float* __restrict__ saved, ft8rx_event* ev, int32_t* evcount, ft8rx_config cfg,
                                            int max_nc0, int max_iters) {
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(64) void k_bp(int mode, const float* __restrict__ l
     }
     if (mode == 0) { if (lane == 0) attB[vec * 5 + ap] = doneG ? resG : res; return; }
     if (lane == 0) { attB[vec * 5 + ap] = res; if (ap < 2) attG[vec * 2 + ap] = resG; }
+#ifndef BP_TIMING_NO_SAVED
     if (res.has_out) for (int i = lane; i < 174; i += 64) saved[(vec * 5 + ap) * 174 + i] = llr[i];
+#endif
 }
 
 // first success in ladder order after ipass 0 (receiver.py:72-78)

@@ -25,17 +25,7 @@ FT8_DEV uint64_t shfl64(uint64_t v, int src) {
 #define OSD_NONE 0xFFu            /* "no flip" in a packed trial entry (i | j << 8 | k << 16) */
 
 __device__ uint32_t d_G0T[192][3];       // column v of G0 = [I | A^T]: row bits 0..31, 32..63, 64..90 (columns >= 174 are zero)
-__device__ uint16_t d_CRC_T[12][256];    // syndrome of byte b (codeword bits 8b .. 8b+7, bits >= 91 ignored) of the 91-bit word:
-                                         // crc14(message) ^ received crc field == XOR of the table entries of its 12 bytes
-
-FT8_DEV unsigned osd_syndrome(uint64_t w0, uint64_t w1) {
-    unsigned s = 0;
-#pragma unroll
-    for (int b = 0; b < 8; b++) s ^= d_CRC_T[b][(w0 >> (8 * b)) & 0xFF];
-#pragma unroll
-    for (int b = 0; b < 4; b++) s ^= d_CRC_T[8 + b][(w1 >> (8 * b)) & 0xFF];
-    return s;
-}
+FT8_DEV unsigned osd_syndrome(uint64_t w0, uint64_t w1) { return ft8_crc_syndrome(w0, w1); }     // table d_CRC_T: ft8_dev.h
 
 // mode 0: pipeline (work = (candidate, slot 0..9)); mode 2: raw vectors
 __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,
