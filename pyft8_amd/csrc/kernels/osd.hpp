@@ -20,10 +20,11 @@ FT8_DEV uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-#define OSD_MAXFLIP 64            /* flip rows kept per attempt (singles / order-3 depth <= 64) */
+#define OSD_MAXFLIP 62            /* flip rows kept per attempt (singles / doubles / order-3 depth <= 62: one bit each in a 64-bit word) */
 #define OSD_MAXTRIALS 16384       /* trial index must fit the 16-bit seq of the event log */
 #define OSD_NONE 0xFFu            /* "no flip" in a packed trial entry (i | j << 8 | k << 16) */
 
+__device__ uint16_t d_SYN91[96];         // CRC syndrome of codeword bit v alone (v < 77: message bit, 77..90: the CRC field bit itself)
 __device__ uint32_t d_G0T[192][3];       // column v of G0 = [I | A^T]: row bits 0..31, 32..63, 64..90 (columns >= 174 are zero)
 FT8_DEV unsigned osd_syndrome(uint64_t w0, uint64_t w1) { return ft8_crc_syndrome(w0, w1); }     // table d_CRC_T: ft8_dev.h
 
@@ -35,8 +36,10 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
                                             int nflip, int max_hd) {
     __shared__ float llr[176];
     __shared__ uint64_t skey[256];
-    __shared__ uint64_t flip[OSD_MAXFLIP + 1][3];          // [OSD_MAXFLIP] = 0: the "no flip" row
-    __shared__ uint16_t fsyn[OSD_MAXFLIP + 2];
+    __shared__ uint64_t ftab[192];                         // per column (natural order): bit i = flip i covers it, bit 63 = order-0 codeword bit
+    __shared__ uint32_t frow[3 * (OSD_MAXFLIP + 1)];       // unit vectors of the flip columns (their pivot rows)
+    __shared__ uint32_t hmw[3];
+    __shared__ uint16_t fsyn[OSD_MAXFLIP + 2];             // [i] flip i, [OSD_MAXFLIP] = 0 ("no flip"), [OSD_MAXFLIP + 1] order-0 codeword
     const int lane = threadIdx.x;
     int frame = 0, ci = 0, slot = 0; size_t vec = blockIdx.x;
     if (mode == 0) {
@@ -80,76 +83,112 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
         }
     }
 #endif
+    // ---- Gauss-Jordan over GF(2), generator held column-wise in SORTED order: lane l of register set s owns the column at
+    // reliability position 64 s + l (91 row bits: rows 0..63 as two u32, rows 64..90 in a third).  A row is "locked" once it has
+    // been made the unit row of an accepted column.  Visiting position ic (decoders.py:228-242 visits the columns in this order):
+    // the column is broadcast to scalar registers (3 readlanes of a statically known register -- the loop is split per register
+    // set); it is independent of the accepted columns iff it has a 1 in an unlocked row; its lowest such row r becomes the pivot
+    // (which row is picked does not change the result: the reduced matrix of a given basis is unique up to row labels, and the
+    // codeword / flip rows below are label-free); clearing the column's other 1s = adding row r to those rows = XORing (column
+    // minus bit r) into every column that has a 1 in row r.  A column that already is a unit vector needs no update at all (the
+    // still untouched systematic columns: about 40 % of the basis).  The scalar pipe issues one instruction per cycle per CU and
+    // is this kernel's bottleneck (profiles/r02_notes.md), so the bookkeeping is kept to lock words and one accepted-position bit
+    // per step; everything that can wait (hard-decision mask, flip rows, syndromes) is done afterwards on the vector side.
     const int ord0 = (int)(uint32_t)skey[lane], ord1 = (int)(uint32_t)skey[64 + lane], ord2 = (lane < 46) ? (int)(uint32_t)skey[128 + lane] : 0;
+    const bool has2 = lane < 46;
+    uint32_t x00 = d_G0T[ord0][0], x01 = d_G0T[ord0][1], x02 = d_G0T[ord0][2];
+    uint32_t x10 = d_G0T[ord1][0], x11 = d_G0T[ord1][1], x12 = d_G0T[ord1][2];
+    uint32_t x20 = has2 ? d_G0T[ord2][0] : 0u, x21 = has2 ? d_G0T[ord2][1] : 0u, x22 = has2 ? d_G0T[ord2][2] : 0u;
+    // hard decisions: in natural order (distance test of the slow path) and per sorted position
     const uint64_t hard0 = __ballot(llr[lane] > 0.0f), hard1 = __ballot(llr[64 + lane] > 0.0f),
-                   hard2 = __ballot(lane < 46 && llr[128 + (lane < 46 ? lane : 0)] > 0.0f);
-    // ---- Gauss-Jordan, generator held column-wise.  Column c of the current matrix is a 91-bit vector over the rows; a row is
-    // "locked" once it has been made the unit row of an accepted column.  Visiting column c (in reliability order, exactly as
-    // decoders.py:228-242): it is independent of the accepted columns iff it has a 1 in an unlocked row; the lowest such row r
-    // becomes its pivot (which row is picked does not change the result: the reduced matrix for a given basis is unique up to
-    // the row labels, and the codeword / flip rows below are label-free); clearing the other 1s of column c = adding row r to
-    // those rows = XORing (column c minus bit r) into every column that has a 1 in row r.  A column that already is a unit
-    // column needs no update at all (the systematic columns that are still untouched: about 40 % of the basis).
-    // lock / hm (locked rows whose accepted column has hard decision 1) / the visited column live in scalar registers.
-    uint32_t x00 = d_G0T[lane][0], x01 = d_G0T[lane][1], x02 = d_G0T[lane][2];
-    uint32_t x10 = d_G0T[64 + lane][0], x11 = d_G0T[64 + lane][1], x12 = d_G0T[64 + lane][2];
-    uint32_t x20 = d_G0T[128 + lane][0], x21 = d_G0T[128 + lane][1], x22 = d_G0T[128 + lane][2];
-    uint32_t lock0 = 0, lock1 = 0, lock2 = ~((1u << 27) - 1u), hm0 = 0, hm1 = 0, hm2 = 0;
-    int prowA = 0, prowB = 0;                  // prow[k] = row locked by the k-th accepted column: lane k of prowA (k < 64) / lane k - 64 of prowB
+                   hard2 = __ballot(has2 && llr[128 + (has2 ? lane : 0)] > 0.0f);
+    const bool hs0 = llr[ord0] > 0.0f, hs1 = llr[ord1] > 0.0f, hs2 = has2 && llr[ord2] > 0.0f;
+    uint64_t lock01 = 0; uint32_t lock2 = ~((1u << 27) - 1u);
+    uint64_t acc0 = 0, acc1 = 0, acc2 = 0;             // accepted positions per register set
     int k = 0;
 #ifdef OSD_TIMING_SKIP_ELIM
     k = 91;
 #endif
-    for (int ic = 0; ic < 174 && k < 91; ic++) {
-        const int col = __builtin_amdgcn_readlane((ic < 64) ? ord0 : ((ic < 128) ? ord1 : ord2), ic & 63);
-        const int sel = col >> 6, cl = col & 63;
-        uint32_t c0, c1, c2;
-        if (sel == 0) { c0 = __builtin_amdgcn_readlane(x00, cl); c1 = __builtin_amdgcn_readlane(x01, cl); c2 = __builtin_amdgcn_readlane(x02, cl); }
-        else if (sel == 1) { c0 = __builtin_amdgcn_readlane(x10, cl); c1 = __builtin_amdgcn_readlane(x11, cl); c2 = __builtin_amdgcn_readlane(x12, cl); }
-        else { c0 = __builtin_amdgcn_readlane(x20, cl); c1 = __builtin_amdgcn_readlane(x21, cl); c2 = __builtin_amdgcn_readlane(x22, cl); }
-        const uint32_t a0 = c0 & ~lock0, a1 = c1 & ~lock1, a2 = c2 & ~lock2;
-        if (!(a0 | a1 | a2)) continue;                        // dependent on the accepted columns
-        const int r = a0 ? __builtin_ctz(a0) : (a1 ? 32 + __builtin_ctz(a1) : 64 + __builtin_ctz(a2));
-        const uint32_t bit = 1u << (r & 31);
-        const uint32_t b0 = (r < 32) ? bit : 0u, b1 = (r >= 32 && r < 64) ? bit : 0u, b2 = (r >= 64) ? bit : 0u;
-        const uint32_t m0 = c0 & ~b0, m1 = c1 & ~b1, m2 = c2 & ~b2;
-        if (m0 | m1 | m2) {
-            if ((x00 & b0) | (x01 & b1) | (x02 & b2)) { x00 ^= m0; x01 ^= m1; x02 ^= m2; }
-            if ((x10 & b0) | (x11 & b1) | (x12 & b2)) { x10 ^= m0; x11 ^= m1; x12 ^= m2; }
-            if ((x20 & b0) | (x21 & b1) | (x22 & b2)) { x20 ^= m0; x21 ^= m1; x22 ^= m2; }
-        }
-        lock0 |= b0; lock1 |= b1; lock2 |= b2;
-        const uint64_t hw = (sel == 0) ? hard0 : ((sel == 1) ? hard1 : hard2);
-        if ((hw >> cl) & 1ull) { hm0 |= b0; hm1 |= b1; hm2 |= b2; }
-        if (lane == (k & 63)) { if (k < 64) prowA = r; else prowB = r; }
-        k++;
+#define OSD_STEP(XA, XB, XC, ACC, IL)                                                                                              \
+    {                                                                                                                              \
+        const uint32_t c0 = __builtin_amdgcn_readlane(XA, IL), c1 = __builtin_amdgcn_readlane(XB, IL), c2 = __builtin_amdgcn_readlane(XC, IL); \
+        const uint64_t c01 = ((uint64_t)c1 << 32) | c0;                                                                            \
+        const uint64_t a01 = c01 & ~lock01; const uint32_t a2 = c2 & ~lock2;                                                       \
+        if (a01 | a2) {                                        /* else: dependent on the accepted columns */                       \
+            const uint64_t b01 = a01 & (0 - a01);              /* lowest unlocked row with a 1 */                                  \
+            const uint32_t b2 = a01 ? 0u : (a2 & (0u - a2));                                                                       \
+            const uint64_t m01 = c01 & ~b01; const uint32_t m2 = c2 & ~b2;                                                         \
+            if (m01 | m2) {                                                                                                        \
+                const uint32_t b0 = (uint32_t)b01, b1 = (uint32_t)(b01 >> 32), m0 = (uint32_t)m01, m1 = (uint32_t)(m01 >> 32);     \
+                { const bool t = ((x00 & b0) | (x01 & b1) | (x02 & b2)) != 0; x00 ^= t ? m0 : 0u; x01 ^= t ? m1 : 0u; x02 ^= t ? m2 : 0u; } \
+                { const bool t = ((x10 & b0) | (x11 & b1) | (x12 & b2)) != 0; x10 ^= t ? m0 : 0u; x11 ^= t ? m1 : 0u; x12 ^= t ? m2 : 0u; } \
+                { const bool t = ((x20 & b0) | (x21 & b1) | (x22 & b2)) != 0; x20 ^= t ? m0 : 0u; x21 ^= t ? m1 : 0u; x22 ^= t ? m2 : 0u; } \
+            }                                                                                                                      \
+            lock01 |= b01; lock2 |= b2;                                                                                            \
+            ACC |= 1ull << (IL);                                                                                                   \
+            k++;                                                                                                                   \
+        }                                                                                                                          \
     }
-    // order-0 codeword: bit v = parity of (column v AND hm) -- the XOR of the locked rows whose accepted column has hard bit 1
-    const uint64_t cw0 = __ballot((__popc(x00 & hm0) + __popc(x01 & hm1) + __popc(x02 & hm2)) & 1),
-                   cw1 = __ballot((__popc(x10 & hm0) + __popc(x11 & hm1) + __popc(x12 & hm2)) & 1),
-                   cw2 = __ballot((__popc(x20 & hm0) + __popc(x21 & hm1) + __popc(x22 & hm2)) & 1);
-    // flip rows: flip[i] = the row locked by accepted column 90 - i (the least reliable basis members first), as 174 column bits
-#ifdef OSD_TIMING_SKIP_FLIPS
-    nflip = 0;
-#endif
+    for (int il = 0; il < 64 && k < 91; il++) OSD_STEP(x00, x01, x02, acc0, il)
+    for (int il = 0; il < 64 && k < 91; il++) OSD_STEP(x10, x11, x12, acc1, il)
+    for (int il = 0; il < 46 && k < 91; il++) OSD_STEP(x20, x21, x22, acc2, il)
+#undef OSD_STEP
+    // Every accepted column is now a unit vector (its pivot row).  Acceptance order = position order, so the accepted column at
+    // position p is the kk-th accepted one with kk = number of accepted positions before p.
+    const bool in0 = (acc0 >> lane) & 1ull, in1 = (acc1 >> lane) & 1ull, in2 = (acc2 >> lane) & 1ull;
+    const int n0 = __popcll(acc0), n1 = __popcll(acc1);
+    const int kk0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(acc0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acc0, 0));
+    const int kk1 = n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(acc1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acc1, 0));
+    const int kk2 = n0 + n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(acc2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acc2, 0));
+    // flip i = the row locked by accepted column 90 - i (least reliable basis members first): that column's lane publishes its unit vector
+    if (lane < 3 * (OSD_MAXFLIP + 1)) frow[lane] = 0u;
+    if (64 + lane < 3 * (OSD_MAXFLIP + 1)) frow[64 + lane] = 0u;
+    if (128 + lane < 3 * (OSD_MAXFLIP + 1)) frow[128 + lane] = 0u;
+    if (192 + lane < 3 * (OSD_MAXFLIP + 1)) frow[192 + lane] = 0u;
+    __syncthreads();
+    { const int i = 90 - kk0; if (in0 && i >= 0 && i < nflip) { frow[3 * i] = x00; frow[3 * i + 1] = x01; frow[3 * i + 2] = x02; } }
+    { const int i = 90 - kk1; if (in1 && i >= 0 && i < nflip) { frow[3 * i] = x10; frow[3 * i + 1] = x11; frow[3 * i + 2] = x12; } }
+    { const int i = 90 - kk2; if (in2 && i >= 0 && i < nflip) { frow[3 * i] = x20; frow[3 * i + 1] = x21; frow[3 * i + 2] = x22; } }
+    // hm = rows whose accepted column has hard decision 1 (OR of those unit vectors): order-0 codeword bit of a column = parity(column & hm)
+    if (lane < 3) hmw[lane] = 0u;
+    __syncthreads();
+    {
+        const uint32_t h0 = ((in0 && hs0) ? x00 : 0u) | ((in1 && hs1) ? x10 : 0u) | ((in2 && hs2) ? x20 : 0u);
+        const uint32_t h1 = ((in0 && hs0) ? x01 : 0u) | ((in1 && hs1) ? x11 : 0u) | ((in2 && hs2) ? x21 : 0u);
+        const uint32_t h2 = ((in0 && hs0) ? x02 : 0u) | ((in1 && hs1) ? x12 : 0u) | ((in2 && hs2) ? x22 : 0u);
+        if (h0) atomicOr(&hmw[0], h0);
+        if (h1) atomicOr(&hmw[1], h1);
+        if (h2) atomicOr(&hmw[2], h2);
+    }
+    __syncthreads();
+    const uint32_t hm0 = hmw[0], hm1 = hmw[1], hm2 = hmw[2];
+    // per column: bit i = flip i has a 1 in this column (i < nflip <= 62), bit 63 = the order-0 codeword bit
+    uint64_t f0 = (uint64_t)((__popc(x00 & hm0) + __popc(x01 & hm1) + __popc(x02 & hm2)) & 1) << 63,
+             f1 = (uint64_t)((__popc(x10 & hm0) + __popc(x11 & hm1) + __popc(x12 & hm2)) & 1) << 63,
+             f2 = (uint64_t)((__popc(x20 & hm0) + __popc(x21 & hm1) + __popc(x22 & hm2)) & 1) << 63;
     for (int i = 0; i < nflip; i++) {
-        const int kk = 90 - i;
-        uint64_t f0 = 0, f1 = 0, f2 = 0;
-        if (kk >= 0 && kk < k) {
-            const int r = (kk < 64) ? __builtin_amdgcn_readlane(prowA, kk) : __builtin_amdgcn_readlane(prowB, kk - 64);
-            const uint32_t bit = 1u << (r & 31);
-            if (r < 32)      { f0 = __ballot(x00 & bit); f1 = __ballot(x10 & bit); f2 = __ballot(x20 & bit); }
-            else if (r < 64) { f0 = __ballot(x01 & bit); f1 = __ballot(x11 & bit); f2 = __ballot(x21 & bit); }
-            else             { f0 = __ballot(x02 & bit); f1 = __ballot(x12 & bit); f2 = __ballot(x22 & bit); }
-        }
-        if (lane == 0) { flip[i][0] = f0; flip[i][1] = f1; flip[i][2] = f2; }
+        const uint32_t r0 = frow[3 * i], r1 = frow[3 * i + 1], r2 = frow[3 * i + 2];      // broadcast reads (a unit vector, or 0 if absent)
+        f0 |= (uint64_t)(((x00 & r0) | (x01 & r1) | (x02 & r2)) != 0) << i;
+        f1 |= (uint64_t)(((x10 & r0) | (x11 & r1) | (x12 & r2)) != 0) << i;
+        f2 |= (uint64_t)(((x20 & r0) | (x21 & r1) | (x22 & r2)) != 0) << i;
     }
-    if (lane == 0) { flip[OSD_MAXFLIP][0] = 0; flip[OSD_MAXFLIP][1] = 0; flip[OSD_MAXFLIP][2] = 0; fsyn[OSD_MAXFLIP] = 0; }
+    // back to natural column order: ftab[column]
+    ftab[ord0] = f0; ftab[ord1] = f1; if (has2) ftab[ord2] = f2;
     __syncthreads();
+    // CRC syndromes (the CRC is linear): lane i < nflip takes flip i, lane 63 the order-0 codeword; the per-bit syndromes of the
+    // 91-bit word are constants of the CRC polynomial (d_SYN91, filled at create time)
+    {
+        const int bitsel = (lane < nflip) ? lane : 63;
+        unsigned sy = 0;
+#pragma unroll 7
+        for (int v = 0; v < 91; v++) sy ^= ((ftab[v] >> bitsel) & 1ull) ? (unsigned)d_SYN91[v] : 0u;
+        if (lane < nflip) fsyn[lane] = (uint16_t)sy;
+        if (lane == 63) fsyn[OSD_MAXFLIP + 1] = (uint16_t)sy;
+        if (lane == 0) fsyn[OSD_MAXFLIP] = 0;
+    }
+    __syncthreads();
+    const unsigned syn_c = fsyn[OSD_MAXFLIP + 1];
     const uint64_t M1 = (1ull << 27) - 1, M2 = (1ull << 46) - 1;
-    if (lane < nflip) fsyn[lane] = (uint16_t)osd_syndrome(flip[lane][0], flip[lane][1] & M1);
-    const unsigned syn_c = osd_syndrome(cw0, cw1 & M1);
-    __syncthreads();
     Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
     const int ipass = (slot < 5) ? 5 : 6;
 #ifdef OSD_TIMING_SKIP_TRIALS
@@ -166,23 +205,33 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
             if (q == OSD_NONE) q = OSD_MAXFLIP;
             hit = (syn_c ^ fsyn[i] ^ fsyn[j] ^ fsyn[q]) == 0;
         }
-        if (!__ballot(hit)) continue;                         // no CRC-consistent word among these 64 trials (the usual case)
-        int r = 0, hd = 0; uint64_t lo = 0, hi = 0;
-        if (hit) {
-            const uint64_t w0 = cw0 ^ flip[i][0] ^ flip[j][0] ^ flip[q][0], w1 = cw1 ^ flip[i][1] ^ flip[j][1] ^ flip[q][1],
-                           w2 = cw2 ^ flip[i][2] ^ flip[j][2] ^ flip[q][2];
-            hd = __popcll(w0 ^ hard0) + __popcll(w1 ^ hard1) + __popcll((w2 ^ hard2) & M2);
-            if (!(max_hd > 0 && hd > max_hd)) r = ft8_crc_check(w0, w1 & M1, &lo, &hi);     // gate (extension): no unpack() call beyond max_hd
+        uint64_t hits = __ballot(hit);
+        if (!hits) continue;                                  // no CRC-consistent word among these 64 trials (the usual case)
+        // slow path, in trial order: rebuild the candidate codeword (natural column order) from the per-column flip words, apply the
+        // distance gate, run the validity predicate, log the reference's unpack() call; the first accepted trial wins
+        bool done = false;
+        while (hits && !done) {
+            const int hl = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            const int hi_ = __shfl(i, hl), hj = __shfl(j, hl), hq = __shfl(q, hl);
+            const uint64_t msk = (1ull << 63) | ((hi_ < OSD_MAXFLIP) ? (1ull << hi_) : 0ull) | ((hj < OSD_MAXFLIP) ? (1ull << hj) : 0ull) |
+                                 ((hq < OSD_MAXFLIP) ? (1ull << hq) : 0ull);
+            const uint64_t w0 = __ballot(__popcll(ftab[lane] & msk) & 1), w1 = __ballot(__popcll(ftab[64 + lane] & msk) & 1),
+                           w2 = __ballot(has2 && (__popcll(ftab[128 + (has2 ? lane : 0)] & msk) & 1));
+            const int hd = __popcll(w0 ^ hard0) + __popcll(w1 ^ hard1) + __popcll((w2 ^ hard2) & M2);
+            if (max_hd > 0 && hd > max_hd) continue;          // gate (extension): no unpack() call beyond max_hd
+            uint64_t lo = 0, hi = 0;
+            const int r = ft8_crc_check(w0, w1 & M1, &lo, &hi);
+            const int t = base + hl;
+            if (r && lane == 0) log_event(ev, evcount, frame, ci, ipass, slot, t, lo, hi, r == 2);   // a call the reference made
+            if (r == 2) {
+                res.ok = 1; res.lo = lo; res.hi = hi; res.n_its = (int16_t)t;
+                res.method = (slot < 5) ? FT8RX_M_OSD : FT8RX_M_LDPC_B_OSD;
+                res.pad[0] = (uint8_t)hd;                     // Hamming distance of the accepted codeword to the hard decisions
+                done = true;
+            }
         }
-        const uint64_t acc = __ballot(r == 2);
-        const int win = acc ? __builtin_ctzll(acc) : 64;
-        if (r && lane <= win) log_event(ev, evcount, frame, ci, ipass, slot, t, lo, hi, r == 2);   // calls the reference made
-        if (acc) {
-            res.ok = 1; res.lo = shfl64(lo, win); res.hi = shfl64(hi, win); res.n_its = (int16_t)(base + win);
-            res.method = (slot < 5) ? FT8RX_M_OSD : FT8RX_M_LDPC_B_OSD;
-            res.pad[0] = (uint8_t)__shfl(hd, win);            // Hamming distance of the accepted codeword to the hard decisions
-            break;
-        }
+        if (done) break;
     }
     if (lane == 0) attO[vec] = res;
 }
