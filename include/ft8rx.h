@@ -109,6 +109,11 @@ int  ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int n_frames,
  * all have been fetched); at most two batches are retained -- a third enqueue drops the oldest.  Steady state:
  *   enqueue(0); for k = 1..: enqueue(k); fetch(k-1); <host message layer of k-1>   -- the GPU never waits for the host. */
 int  ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int n_frames);
+/* The same pipeline fed from HOST memory: the audio of batch k+1 is copied (in chunks, on a dedicated stream, into the second of two
+ * device staging buffers) while batch k computes, so in steady state  enqueue_host(k+1); fetch(k); <host layer of k>  hides the PCIe
+ * transfer behind the kernels.  `audio` must stay valid until the batch has been fetched; page-locked memory (ft8rx_alloc_host) makes
+ * the copies truly asynchronous. */
+int  ft8rx_enqueue_batch_host(ft8rx_handle* h, const int16_t* audio, int n_frames);
 int  ft8rx_sync(ft8rx_handle* h);
 int  ft8rx_fetch_results(ft8rx_handle* h, int n_frames, ft8rx_record* records, int32_t* counts,
                          ft8rx_event* events, int32_t* event_counts);

@@ -161,6 +161,15 @@ class Handle:
     def enqueue(self, d_audio_ptr, B):
         self._chk(lib().ft8rx_enqueue_batch(self._h, C.c_void_p(d_audio_ptr), int(B)), "ft8rx_enqueue_batch")
 
+    def enqueue_host(self, audio):
+        """Asynchronous decode of host audio (int16 [B, 180000], ideally from pinned_audio()): ft8rx_enqueue_batch_host.  The array
+        must stay alive and unchanged until the batch has been fetched."""
+        if audio.dtype != np.int16 or audio.ndim != 2 or audio.shape[1] != NSAMP or not audio.flags["C_CONTIGUOUS"]:
+            raise Ft8rxError(f"enqueue_host: audio must be a C-contiguous int16 [n_frames, {NSAMP}] array")
+        L = lib()
+        L.ft8rx_enqueue_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self._chk(L.ft8rx_enqueue_batch_host(self._h, audio.ctypes.data_as(C.c_void_p), int(audio.shape[0])), "ft8rx_enqueue_batch_host")
+
     def sync(self):
         self._chk(lib().ft8rx_sync(self._h), "ft8rx_sync")
 

@@ -223,7 +223,7 @@ struct Fused2 {
 // The quad sum uses DPP quad_perm broadcasts (lane o of the quad as the second operand of a plain v_add): the same three adds in the
 // same order as a shuffle-based reduction, without the LDS crossbar round trips of ds_bpermute.
 template <int O> FT8_DEV float quad_lane(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x55 * O, 0xf, 0xf, true));      // quad_perm:[O,O,O,O]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55 * O, 0xf, 0xf, false));      // quad_perm:[O,O,O,O]
 }
 // NT = number of tones wanted (7: a Costas score never reads tone 7, receiver.py:203); wq[k] = W32^(n2 k), this lane's twiddles,
 // loaded once per thread (sym32_twiddles).

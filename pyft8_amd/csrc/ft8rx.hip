@@ -82,6 +82,8 @@ struct ft8rx_handle {
     struct Chunk { void* p; size_t cap, used; };
     std::vector<Chunk> arena;        // scratch of the stage entry points (struct Scratch)
     int16_t* d_audio;            // staging for host-pointer entry points
+    int16_t* d_audio2;           // second staging buffer (allocated on first use): ft8rx_enqueue_batch_host double-buffers the H2D copies
+    hipStream_t h2d_s;           // host-to-device copies of the pipelined host entry: never queued behind kernels or result copies
     float* d_grid;
     float* d_best_score; int32_t* d_best_h0;
     ft8rx_record* d_rec; int32_t* d_ncand;
@@ -185,6 +187,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
     for (auto e : h->pev) hipEventDestroy(e);
     for (int i = 0; i < 8; i++) { if (h->sub[i]) hipStreamDestroy(h->sub[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     if (h->copy_s) hipStreamDestroy(h->copy_s);
+    if (h->h2d_s) hipStreamDestroy(h->h2d_s);
     for (int i = 0; i < 16; i++) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (int k = 0; k < 2; k++) {
@@ -213,7 +216,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     ft8rx_handle* h = new ft8rx_handle();
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
     h->n_streams = 4; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
-    h->copy_s = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
+    h->copy_s = nullptr; h->h2d_s = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
     for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
@@ -319,6 +322,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
         okc = okc && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
     okc = okc && hipStreamCreateWithFlags(&h->copy_s, hipStreamNonBlocking) == hipSuccess;
+    okc = okc && hipStreamCreateWithFlags(&h->h2d_s, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 16; i++) okc = okc && hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
     okc = okc && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < 2; k++) {
@@ -393,20 +397,32 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
 //   the dedicated copy stream (never queued behind kernels, so a pageable-memory copy blocks the host only for its own
 //   duration) and each chunk's chain waits for its copy's event.
 // When the kernels are done the copy stream moves the slot's results into the page-locked host buffers.
-static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* host_audio, int B) {
+// pipelined = true (ft8rx_enqueue_batch_host): the audio is staged in the buffer of this batch's result slot and its copies run on
+// their own stream, gated only by the previous user of that staging buffer (two batches ago), so they overlap the kernels of
+// the batch before.
+static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* host_audio, int B, bool pipelined = false) {
     HIPCHK(h, hipSetDevice(h->device));
     h->pnames.clear();
     if (h->inflight == 2) { h->slot_fetch ^= 1; h->inflight = 1; }          // the oldest unfetched batch is dropped
     const int slot = h->slot_enq;
+    int16_t* stage = h->d_audio;
+    hipStream_t cs = h->copy_s;
+    if (pipelined) {
+        if (slot == 1 && !h->d_audio2 && dalloc(h, &h->d_audio2, (size_t)h->max_frames * FT8RX_NSAMP)) return -2;
+        stage = slot ? h->d_audio2 : h->d_audio;
+        d_audio = stage;
+        cs = h->h2d_s;
+        HIPCHK(h, hipStreamWaitEvent(cs, h->ev_comp[slot], 0));             // the kernels that last read this staging buffer are done
+    }
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));          // the slot's previous results have left the device
     int nc = h->profiling ? 1 : (host_audio ? 2 * h->n_streams : h->n_streams);
     if (nc > B / 8) nc = B / 8;
     if (nc <= 1) {
-        if (host_audio) HIPCHK(h, hipMemcpyAsync(h->d_audio, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
+        if (host_audio) HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
         enqueue_chain(h, d_audio, 0, B, h->stream, h->profiling, slot);
     } else {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-        if (host_audio) HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_fork, 0));
+        if (host_audio && !pipelined) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_fork, 0));
         for (int i = 0; i < h->n_streams; i++) HIPCHK(h, hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
         const int per = (B + nc - 1) / nc;
         for (int k = 0; k < nc; k++) {
@@ -414,9 +430,9 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
             if (n <= 0) break;
             hipStream_t s = h->sub[k % h->n_streams];
             if (host_audio) {
-                HIPCHK(h, hipMemcpyAsync(h->d_audio + (size_t)f0 * FT8RX_NSAMP, host_audio + (size_t)f0 * FT8RX_NSAMP,
-                                         sizeof(int16_t) * (size_t)n * FT8RX_NSAMP, hipMemcpyHostToDevice, h->copy_s));
-                HIPCHK(h, hipEventRecord(h->ev_chunk[k], h->copy_s));
+                HIPCHK(h, hipMemcpyAsync(stage + (size_t)f0 * FT8RX_NSAMP, host_audio + (size_t)f0 * FT8RX_NSAMP,
+                                         sizeof(int16_t) * (size_t)n * FT8RX_NSAMP, hipMemcpyHostToDevice, cs));
+                HIPCHK(h, hipEventRecord(h->ev_chunk[k], cs));
                 HIPCHK(h, hipStreamWaitEvent(s, h->ev_chunk[k], 0));
             }
             enqueue_chain(h, d_audio, f0, n, s, false, slot);
@@ -445,6 +461,12 @@ int ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int B) {
     if (!h || !d_audio) return -1;
     if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_enqueue_batch: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
     return launch_batch(h, d_audio, nullptr, B);
+}
+
+int ft8rx_enqueue_batch_host(ft8rx_handle* h, const int16_t* audio, int B) {
+    if (!h || !audio) return -1;
+    if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_enqueue_batch_host: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
+    return launch_batch(h, nullptr, audio, B, true);
 }
 
 int ft8rx_set_streams(ft8rx_handle* h, int n) { if (!h || n < 1 || n > 8) return -1; h->n_streams = n; return 0; }

@@ -184,8 +184,8 @@ FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int
         F::compute_passA(0, a[r], W);
 #pragma unroll
         for (int j = 0; j < 5; j++) {
-            const int rr = q + 128 * j;
-            const int first = (lo <= rr) ? rr : rr + 640 * ((lo - rr + 639) / 640);   // smallest rr + 640 j' >= lo
+            const int rr = q + 128 * j;                                                 // < 640
+            const int first = rr + 640 * (lo / 640 + (rr < lo % 640 ? 1 : 0));          // smallest rr + 640 j' >= lo (lo is block-uniform)
             if (first < hi && first < 3200) {
                 cpx b[5];
 #pragma unroll

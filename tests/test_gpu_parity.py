@@ -488,6 +488,39 @@ def test_result_slots_pipeline_order():
     store.close()
 
 
+def test_pipelined_host_entry_matches_synchronous_decode():
+    """ft8rx_enqueue_batch_host (H2D of batch k+1 overlapping the kernels of batch k, two device staging buffers): a stream of
+    different batches from page-locked and from pageable host memory gives exactly the results of ft8rx_decode_batch, in order."""
+    from pyft8_amd import _lib, synth
+    B = 24
+    batches = [np.stack([synth.make_frame(52000 + 100 * k + i, n_signals=12, snr_range=(-10.0, 6.0)) for i in range(B)]) for k in range(4)]
+    h = _lib.Handle(max_frames=B)
+    want = [h.decode_batch(b) for b in batches]
+
+    def same(a, b):
+        (ra, ca, ea, na), (rb, cb, eb, nb) = a, b
+        if not (np.array_equal(ca, cb) and np.array_equal(na, nb)):
+            return False
+        return all(ra[f, :ca[f]].tobytes() == rb[f, :cb[f]].tobytes() and
+                   sorted(ea[f, :min(na[f], _lib.EVENT_CAP)].tolist()) == sorted(eb[f, :min(nb[f], _lib.EVENT_CAP)].tolist()) for f in range(B))
+    for pinned in (True, False):
+        bufs = []
+        for b in batches:
+            a = h.pinned_audio(B) if pinned else np.empty_like(b)
+            a[:] = b
+            bufs.append(a)
+        for rounds in range(2):                                  # steady state: enqueue(k+1) before fetch(k)
+            h.enqueue_host(bufs[0])
+            for k in range(1, 4):
+                h.enqueue_host(bufs[k])
+                assert same(h.fetch(B), want[k - 1]), (pinned, rounds, k)
+            assert same(h.fetch(B), want[3])
+    assert same(h.decode_batch(batches[1]), want[1])             # the synchronous entry still works in between
+    with pytest.raises(_lib.Ft8rxError):
+        h.enqueue_host(batches[0][:, :100])
+    h.close()
+
+
 def test_subtract_matches_reference_golden_and_oracle():
     """SURVEY 8f-4 primitive: ft8rx_subtract vs the reference's Receiver.subtract_signal run in isolation
     (tests/golden/subtract.npz, oracle/gen_golden_subtract.py) and vs the C oracle's restatement.  Floating-point stage:

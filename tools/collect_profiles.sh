@@ -4,11 +4,11 @@
 # rocprofv3 passes are separate runs (kernel trace + stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE), each with the
 # program itself after `--`.  Everything is bounded by `timeout`.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry --streams 1"
+BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0"
 
 timeout 900 python3 bench.py > "$OUT/${TAG}_bench_b256_s4.json" 2> "$OUT/${TAG}_bench_b256_s4.err"
 timeout 600 python3 bench.py --streams 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b256_s1.json" 2>> "$OUT/${TAG}_bench_b256_s4.err"
@@ -24,7 +24,7 @@ W=$(find "$OUT/${TAG}_pmcW" -name '*counter_collection.csv' | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_pmc.json" "$OUT/${TAG}_pmc_b256.txt" > /dev/null
 
 # BASELINE config 2 as stated (4096 frames, BP 30 iterations, OSD depth 2 = osd_012(30, 2)): rocprofv3 kernel stats + PMC traffic
-B2="python3 bench.py --frames 4096 --steps 2 --warmup 1 --bp-iters 30 --no-cpu-baseline --no-host-entry --streams 1"
+B2="python3 bench.py --config 2 --steps 2 --warmup 1 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0"
 rm -rf "$OUT/${TAG}_c2_stats" "$OUT/${TAG}_c2_pmcF" "$OUT/${TAG}_c2_pmcW"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_c2_stats" -o s -- $B2 > "$OUT/${TAG}_c2_stats.log" 2>&1
 DB=$(find "$OUT/${TAG}_c2_stats" -name '*.db' | head -1)
@@ -40,9 +40,16 @@ timeout 900 $B2 > "$OUT/${TAG}_bench_b4096_config2_bp30.json" 2>> "$OUT/${TAG}_b
 # size (8192 frames per GPU) and config 4 (low SNR, few signals, truth-based decode probability)
 timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b4096_ref_knobs.json" 2> "$OUT/${TAG}_big.err"
 timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline --bp-iters 30 --osd 40 4 > "$OUT/${TAG}_bench_b4096_ext_knobs.json" 2>> "$OUT/${TAG}_big.err"
-timeout 900 python3 bench.py --frames 8192 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b8192.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py --config 3 --no-cpu-baseline > "$OUT/${TAG}_bench_config3_shard_b8192.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py --config 4 --no-cpu-baseline > "$OUT/${TAG}_bench_config4_b2048_order3_gate.json" 2>> "$OUT/${TAG}_big.err"
 timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline --signals 8 --snr -24 -14 > "$OUT/${TAG}_bench_b4096_lowsnr.json" 2>> "$OUT/${TAG}_big.err"
+# two ranks on this one GPU over gloo: the N > 1 flow of bench.py (sharding, barriers, gather) -- not a scaling number
+timeout 900 python3 bench.py --gpus 2 --backend gloo --no-host-entry > "$OUT/${TAG}_bench_2ranks_1gpu_gloo.json" 2>> "$OUT/${TAG}_big.err"
+# SQ counters per kernel (three --pmc passes)
+timeout 1500 tools/pmc_sq.sh "${TAG}" > /dev/null 2>&1
+timeout 1500 python3 tools/sensitivity.py 2048 -24 -20 > "$OUT/${TAG}_config4_sensitivity.txt" 2>> "$OUT/${TAG}_big.err"
+timeout 300 tools/ubench/valu_rate > "$OUT/${TAG}_valu_rate.txt" 2>&1
 timeout 300 python3 tools/latency.py > "$OUT/${TAG}_latency.txt" 2>> "$OUT/${TAG}_big.err"
 timeout 600 python3 tools/two_pass_yield.py 256 50 2>&1 | tail -7 > "$OUT/${TAG}_multi_pass_yield.txt"
-timeout 1200 python3 tools/sensitivity.py 4096 > "$OUT/${TAG}_sensitivity_gpu.txt" 2>> "$OUT/${TAG}_big.err"
+timeout 1200 python3 tools/sensitivity.py 2048 > "$OUT/${TAG}_sensitivity_wide.txt" 2>> "$OUT/${TAG}_big.err"
 ls -la "$OUT" | grep "${TAG}_" | head -40
