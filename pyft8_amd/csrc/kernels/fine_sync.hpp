@@ -271,8 +271,12 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
     const cpx* __restrict__ S = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
 #endif
     FT_DECL
+#ifndef FINE_NO_WQ_HOIST
     cpx wq[8];
     sym32_twiddles(w32, tid & 3, wq);                             // every symbol DFT of this thread uses n2 = tid & 3
+#else
+    const cpx* wq = w32 + 0;                                      // (experiment) twiddles re-read from LDS by every symbol DFT
+#endif
     const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
     // Score of one Costas block (contract): per symbol a the quad leader forms on_a = |tone costas[a]| and off_a = sum of
     // the other six tones (b ascending) in fp64 from its registers; after ONE barrier every thread combines

@@ -26,10 +26,12 @@ FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __r
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int m = pc + 240 * j, i0 = base + 2 * m;
-                const short2 sm = *reinterpret_cast<const short2*>(a + (i0 >= 0 ? i0 : 0));
+                // samples before the frame start are zeros (the ring starts zeroed, receiver.py:248): masked with integer ALU ops --
+                // a select here is turned back into a branch around the load, i.e. one memory round trip per basic block
+                uint32_t raw = *reinterpret_cast<const uint32_t*>(a + (i0 & ~(i0 >> 31)));
+                raw &= ~(uint32_t)(i0 >> 31);
                 const float2 wn = *reinterpret_cast<const float2*>(T.win + 2 * m);
-                const float x0 = (float)sm.x * wn.x, x1 = (float)sm.y * wn.y;
-                v[i][j] = (i0 >= 0) ? make_float2(x0, x1) : make_float2(0.0f, 0.0f);
+                v[i][j] = make_float2((float)(int16_t)(raw & 0xFFFFu) * wn.x, (float)(int16_t)(raw >> 16) * wn.y);
             }
 #pragma unroll
             for (int j = 1; j < 8; j++) w[i][j] = W[j * pc];
