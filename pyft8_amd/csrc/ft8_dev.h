@@ -127,7 +127,7 @@ FT8_DEV void fft_pass(const cpx* __restrict__ src, cpx* __restrict__ dst, const 
 #pragma unroll
         for (int j = 1; j < R; j++) {
             cpx v = a[j];
-            if (m > 1 && p != 0) v = cmul(v, W[j * p * s]);
+            if (m > 1) v = cmul(v, W[j * p * s]);            // unconditional (p = 0: W^0 = (1, -0) is an exact identity): no divergent branch around the twiddle load
             y[q + s * (R * p + j)] = v;
         }
     }

@@ -8,7 +8,7 @@
 //   k_grid_llr     (candidate)          payload gather -> max-log LLRs -> sigma normalisation
 //   k_bp           (candidate, AP)      one wavefront: GOOD91 + flooding BP, ballot parity, LDS exchange
 //   k_select0      (candidate)          first success in ladder order
-//   k_cyc_a/b/c    (tile, frame)        192000-pt real FFT as 300x320 four-step + real split
+//   k_cyc_a/bc     (tile, frame)        192000-pt real FFT as 300x320 four-step; row pass fused with the real split
 //   k_fine         (candidate)          9x(slice/taper/3200-pt IFFT) + 32-pt DFT scoring, Costas gate, LLRs
 //   k_bp           (candidate, AP)      GOOD91 + BP(90,20) with saved outputs
 //   k_select1, k_osd (candidate, slot) one wavefront: rank sort, register-resident GF(2) Gauss-Jordan
@@ -89,7 +89,7 @@ struct ft8rx_handle {
     ft8rx_record* d_rec; int32_t* d_ncand;
     float* d_llr0; float* d_saved;
     Att *d_att0, *d_attG, *d_attB, *d_attO;
-    cpx *d_A, *d_Z, *d_spec;
+    cpx *d_A, *d_spec;
     ft8rx_event* d_ev; int32_t* d_evcount;
     const uint32_t* d_trials; int n_trials;      // OSD trial list of this configuration
     // Result slots.  A batch writes its records/events into slot k % 2 (slot 0 = d_rec/d_ncand/d_ev/d_evcount above) and, when its
@@ -236,7 +236,6 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     rc |= dalloc(h, &h->d_attB, B * MAXC * 5);
     rc |= dalloc(h, &h->d_attO, B * MAXC * 10);
     rc |= dalloc(h, &h->d_A, B * 96000);
-    rc |= dalloc(h, &h->d_Z, B * 96000);
     rc |= dalloc(h, &h->d_spec, B * FT8RX_SPEC_BINS);
     rc |= dalloc(h, &h->d_ev, B * FT8RX_EVENT_CAP);
     rc |= dalloc(h, &h->d_evcount, B);
@@ -354,7 +353,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     ft8rx_record* rec = h->s_rec[slot] + F * MAXC; int32_t* ncand = h->s_ncand[slot] + F;
     float* llr0 = h->d_llr0 + F * MAXC * 174; float* saved = h->d_saved + F * MAXC * 5 * 174;
     Att* att0 = h->d_att0 + F * MAXC * 5; Att* attG = h->d_attG + F * MAXC * 2; Att* attB = h->d_attB + F * MAXC * 5; Att* attO = h->d_attO + F * MAXC * 10;
-    cpx* A = h->d_A + F * 96000; cpx* Z = h->d_Z + F * 96000; cpx* spec = h->d_spec + F * FT8RX_SPEC_BINS;
+    cpx* A = h->d_A + F * 96000; cpx* spec = h->d_spec + F * FT8RX_SPEC_BINS;
     ft8rx_event* ev = h->s_ev[slot] + F * FT8RX_EVENT_CAP; int32_t* evc = h->s_evcount[slot] + F;
 #define STAGE(name) do { if (prof) { hipEventRecord(h->pev[h->pnames.size()], s); h->pnames.push_back(name); } } while (0)
     hipMemsetAsync(evc, 0, sizeof(int32_t) * B, s);
@@ -373,8 +372,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     k_select0<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B);
     STAGE("cycle_fft");
     k_cyc_a<<<dim3(40, B), 256, 0, s>>>(audio, A, h->T);
-    k_cyc_b<<<dim3(75, B), 256, 0, s>>>(A, Z, h->T);
-    k_cyc_c<<<dim3(FT8RX_SPEC_BINS / 256, B), 256, 0, s>>>(Z, spec, h->T);
+    k_cyc_bc<<<dim3(CYC_BC_BLOCKS, B), 256, 0, s>>>(A, spec, h->T);
     STAGE("fine");
     k_fine<<<B * MAXC, FINE_NT, 0, s>>>(spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr);
     STAGE("bp_fine");
@@ -612,8 +610,7 @@ int ft8rx_cycle_spectrum(ft8rx_handle* h, const int16_t* audio, int B, float* sp
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
     k_cyc_a<<<dim3(40, B), 256, 0, h->stream>>>(h->d_audio, h->d_A, h->T);
-    k_cyc_b<<<dim3(75, B), 256, 0, h->stream>>>(h->d_A, h->d_Z, h->T);
-    k_cyc_c<<<dim3(FT8RX_SPEC_BINS / 256, B), 256, 0, h->stream>>>(h->d_Z, h->d_spec, h->T);
+    k_cyc_bc<<<dim3(CYC_BC_BLOCKS, B), 256, 0, h->stream>>>(h->d_A, h->d_spec, h->T);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(spec, h->d_spec, sizeof(cpx) * (size_t)B * FT8RX_SPEC_BINS, hipMemcpyDeviceToHost));
     return 0;

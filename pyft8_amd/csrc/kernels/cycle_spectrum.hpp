@@ -17,9 +17,12 @@ __global__ __launch_bounds__(256) void k_cyc_a(const int16_t* __restrict__ audio
     for (int i = tid; i < 2400; i += 256) {
         int c = i & 7, n1 = i >> 3;
         int m = 320 * n1 + n2b + c;
-        float re = 0.0f, im = 0.0f;
-        if (2 * m < FT8RX_NSAMP) { short2 v = *reinterpret_cast<const short2*>(a + 2 * m); re = (float)v.x; im = (float)v.y; }
-        bufA[c * 300 + n1] = make_float2(re, im);
+        // zero padding beyond the 180000 samples (receiver.py:283: a 192000-sample buffer) by integer masking of a clamped load -- a
+        // select would be turned back into a branch around the load (one memory round trip per basic block)
+        const int inb = (2 * m < FT8RX_NSAMP) ? -1 : 0;
+        uint32_t raw = *reinterpret_cast<const uint32_t*>(a + ((2 * m) & inb));
+        raw &= (uint32_t)inb;
+        bufA[c * 300 + n1] = make_float2((float)(int16_t)(raw & 0xFFFFu), (float)(int16_t)(raw >> 16));
     }
     __syncthreads();
     cpx* r = lds_fft<300, 5, 5, 4, 3>(bufA, bufB, T.W300, 8, tid, 256);
@@ -32,29 +35,54 @@ __global__ __launch_bounds__(256) void k_cyc_a(const int16_t* __restrict__ audio
     }
 }
 
-__global__ __launch_bounds__(256) void k_cyc_b(const cpx* __restrict__ A, cpx* __restrict__ Z, Tables T) {
-    __shared__ cpx bufA[4 * 320];
-    __shared__ cpx bufB[4 * 320];
-    const int f = blockIdx.y, tid = threadIdx.x, k1b = 4 * blockIdx.x;
-    const cpx* in = A + (size_t)f * 96000 + (size_t)k1b * 320;
-    for (int i = tid; i < 1280; i += 256) bufA[i] = in[i];
-    __syncthreads();
-    cpx* r = lds_fft<320, 8, 8, 5>(bufA, bufB, T.W320, 4, tid, 256);
-    cpx* out = Z + (size_t)f * 96000;
-    for (int i = tid; i < 1280; i += 256) {
-        int rr = i & 3, k2 = i >> 2;
-        out[(k1b + rr) + 300 * k2] = r[rr * 320 + k2];
+// Row FFTs (320-point, over n2) fused with the real-FFT split.  Z[k1 + 300 k2] = FFT320 of row k1 of A; the split of bin k needs
+// Z[k] and Z[96000 - k], and 96000 - (k1 + 300 k2) = (300 - k1) + 300 (319 - k2): the partner of row k1 is row 300 - k1.  A block
+// therefore transforms 4 adjacent rows k1 .. k1+3 TOGETHER WITH their partner rows 297-k1 .. 300-k1 and forms the spectrum bins of
+// all eight rows from LDS -- the 96000-point intermediate Z never goes to HBM (r01: 197 MB written + 201 MB read per 256 frames).
+// Blocks 0..37: k1 = 1 + 4 b (rows 1..152 and 148..299; the rows 148..152 are produced twice, identically); block 38: the
+// self-paired rows 0 (partner bin 300 (320 - k2)) and 150.  Only bins < 49152 are kept (k2 < 164).
+#define CYC_BC_BLOCKS 39
+__global__ __launch_bounds__(256) void k_cyc_bc(const cpx* __restrict__ A, cpx* __restrict__ spec, Tables T) {
+    __shared__ cpx bufA[8 * 320];
+    __shared__ cpx bufB[8 * 320];
+    const int f = blockIdx.y, tid = threadIdx.x, b = blockIdx.x;
+    const cpx* in = A + (size_t)f * 96000;
+    // row index of slot r (0..7): slots 0..3 = the low rows, 4..7 = their partners (slot 4 + j is the partner of slot j)
+    const bool special = (b == CYC_BC_BLOCKS - 1);
+    const int k1a = 1 + 4 * b;
+    for (int i = tid; i < 8 * 320; i += 256) {
+        const int r = i / 320, c = i - 320 * r;
+        int row;
+        if (special) row = (r == 0) ? 0 : 150;                                // slot 0 = row 0, every other slot = row 150 (only slot 1 is used)
+        else row = (r < 4) ? k1a + r : 300 - (k1a + (r - 4));
+        bufA[i] = in[(size_t)row * 320 + c];
     }
-}
-
-__global__ __launch_bounds__(256) void k_cyc_c(const cpx* __restrict__ Z, cpx* __restrict__ spec, Tables T) {
-    const int f = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-    const cpx* z = Z + (size_t)f * 96000;
-    cpx p = z[k], q = z[(96000 - k) % 96000];
-    float er = 0.5f * (p.x + q.x), ei = 0.5f * (p.y - q.y);
-    float orr = 0.5f * (p.y + q.y), oi = 0.5f * (q.x - p.x);
-    cpx w = T.WR192k[k];
-    spec[(size_t)f * FT8RX_SPEC_BINS + k] = make_float2(er + (w.x * orr - w.y * oi), ei + (w.x * oi + w.y * orr));
+    __syncthreads();
+    cpx* z = lds_fft<320, 8, 8, 5>(bufA, bufB, T.W320, 8, tid, 256);
+    cpx* out = spec + (size_t)f * FT8RX_SPEC_BINS;
+    // outputs: slot r, k2 < 164 -> bin k = row + 300 k2; adjacent threads take adjacent rows (32-byte runs in memory)
+    for (int i = tid; i < 8 * 164; i += 256) {
+        const int half = i / (4 * 164), j = i - half * (4 * 164), rr = j & 3, k2 = j >> 2;
+        const int r = 4 * half + rr;
+        int row, pr, pk2;                                                       // this row, partner slot, partner k2
+        if (special) {
+            if (r >= 2) continue;
+            row = (r == 0) ? 0 : 150;
+            pr = r;                                                             // self-paired
+            pk2 = (r == 0) ? ((320 - k2) % 320) : 319 - k2;
+        } else {
+            row = (r < 4) ? k1a + r : 300 - (k1a + (r - 4));
+            pr = (r < 4) ? r + 4 : r - 4;
+            pk2 = 319 - k2;
+        }
+        const int k = row + 300 * k2;
+        if (k >= FT8RX_SPEC_BINS) continue;
+        const cpx p = z[r * 320 + k2], q = z[pr * 320 + pk2];
+        const float er = 0.5f * (p.x + q.x), ei = 0.5f * (p.y - q.y);
+        const float orr = 0.5f * (p.y + q.y), oi = 0.5f * (q.x - p.x);
+        const cpx w = T.WR192k[k];
+        out[k] = make_float2(er + (w.x * orr - w.y * oi), ei + (w.x * oi + w.y * orr));
+    }
 }
 
 #endif
