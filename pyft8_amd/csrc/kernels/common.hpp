@@ -48,10 +48,14 @@ struct Att {               // one decode attempt's outcome
 #define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */
 
 // grid row accessor with the reference's modulo-750 wrap (receiver.py:240,347,360)
+// (branch-free: an always-valid clamped load, then an integer mask selects the grid's initial 1.0 -- a branch or select around
+// the load would serialise the loads of a gather loop, one memory round trip per basic block)
 FT8_DEV float grid_at(const float* __restrict__ g, int row, int col) {
     row %= 750; if (row < 0) row += 750;
-    if (row >= 1 && row <= 375) return g[row * FT8RX_GRID_COLS + col];
-    return 1.0f;
+    const bool in = row >= 1 && row <= 375;
+    const uint32_t raw = __float_as_uint(g[(in ? row : 1) * FT8RX_GRID_COLS + col]);
+    const uint32_t m = in ? 0xFFFFFFFFu : 0u;
+    return __uint_as_float((raw & m) | (0x3F800000u & ~m));
 }
 
 FT8_DEV void log_event(ft8rx_event* ev, int32_t* evcount, int frame, int cand, int ipass, int slot, int seq,

@@ -18,10 +18,14 @@ __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, fl
     const int f0base = cfg.f0_lo + 16 * blockIdx.x;
     const int rlo = cfg.h0_lo + 148;
     const float* g = grid + (size_t)f * FT8RX_GRID_ROWS * FT8RX_GRID_COLS;
+    // tile load: rows outside 1..375 read the grid's initial 1.0 (receiver.py:240), columns beyond the grid 0 -- resolved by integer
+    // masks on an always-valid (clamped) load, so the loop body is straight-line and the loads of successive iterations overlap
     for (int i = tid; i < nrows * 29; i += 256) {
-        int r = i / 29, c = i - r * 29;
-        int col = f0base + c;
-        tile[i] = (col < FT8RX_GRID_COLS) ? grid_at(g, rlo + r, col) : 0.0f;
+        const int r = i / 29, c = i - r * 29;
+        const int col = f0base + c;
+        const bool incol = col < FT8RX_GRID_COLS;
+        const uint32_t raw = __float_as_uint(grid_at(g, rlo + r, incol ? col : 0));
+        tile[i] = __uint_as_float(raw & (incol ? 0xFFFFFFFFu : 0u));
     }
     __syncthreads();
     // T[r][f] = sum_{b<14} tile[r][f+b], accumulated in the contract's order (b ascending, fp64); every time offset that
