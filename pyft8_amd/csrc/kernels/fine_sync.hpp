@@ -81,14 +81,16 @@ FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W
     const bool has17 = tid >= 122;                    // p = tid + 128 >= 250
     const cpx a17r = s7[has17 ? 128 : 250];           // (250: any in-range address, p = tid + 250)
     const double t17 = taper[has17 ? tid - 122 : 0];
+    const uint32_t m02 = has02 ? 0xFFFFFFFFu : 0u, m17 = has17 ? 0xFFFFFFFFu : 0u;     // absent inputs: zeroed by masks, not by selects (r02_notes)
     const cpx a27r = s7[256];                          // p = tid + 256 >= 250 always
     const bool tap21 = tid >= 94;                      // p >= 350: bin p + 400 is tapered (index p - 350), else bin p + 2800 (index p - 250)
     const double t2 = taper[tap21 ? tid - 94 : tid + 6];
     const cpx a37r = s7[384 + t3 - tid];
     const double t31 = taper[34 + t3];                 // p + 400 - 750 = 34 + tid
     // ---- resolve
-    const cpx a02 = has02 ? fine_taper(a02r, t02) : zero;
-    const cpx a17 = has17 ? fine_taper(a17r, t17) : zero;
+    const cpx t02v = fine_taper(a02r, t02), t17v = fine_taper(a17r, t17);
+    const cpx a02 = make_float2(__uint_as_float(__float_as_uint(t02v.x) & m02), __uint_as_float(__float_as_uint(t02v.y) & m02));
+    const cpx a17 = make_float2(__uint_as_float(__float_as_uint(t17v.x) & m17), __uint_as_float(__float_as_uint(t17v.y) & m17));
     const cpx sel2 = fine_taper(tap21 ? a21 : a27r, t2);
     const cpx b21 = tap21 ? sel2 : a21, a27 = tap21 ? a27r : sel2;
     const cpx b31 = fine_taper(a31, t31);
