@@ -232,7 +232,7 @@ def main():
         uniq = B
         d_audio = torch.empty((B, _lib.NSAMP), dtype=torch.int16, device="cuda")
         h.synth_frames(d_audio.data_ptr(), rank * 1000000, B, n_signals=args.signals, snr_range=tuple(args.snr))
-        frames = d_audio[:64].cpu().numpy()           # CPU-baseline sample
+        frames = d_audio[:min(B, 192)].cpu().numpy()  # CPU-baseline sample (bounded by cpu_baseline's 15-s budget)
         data_desc = f"{B} distinct device-generated frames"
     torch.cuda.synchronize()
 
