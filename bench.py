@@ -163,15 +163,16 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="HIP streams a batch is cut across (1 = one chain of whole-batch launches)")
     ap.add_argument("--config", type=int, default=None, choices=(1, 2, 3, 4), help="BASELINE.json configuration preset (per GPU): 1 = 256 frames; "
                     "2 = 4096 frames, BP 30 iterations, OSD depth 2; 3 = 8192 frames per GPU (65 536 over 8 GPUs) + record gather; "
-                    "4 = 2048 frames per GPU (16 384 over 8), <= 10 signals at -24..-20 dB, OSD order 3")
+                    "4 = 2048 frames per GPU (16 384 over 8), <= 10 signals at -24..-20 dB, OSD order 3 over 30 positions with the distance gate at 32")
     ap.add_argument("--osd3", type=int, default=None, help="extension knob: OSD order-3 depth (triple flips over the first N basis positions; 0 = off)")
+    ap.add_argument("--osd-max-hd", type=int, default=None, help="extension knob: accept an OSD trial only within this Hamming distance of the hard decisions (0 = off)")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="after the K timed steps keep stepping (untimed for `value`, reported as "
                     "extra_steps) until the GPU has been busy this long, so that coarse GPU-activity samplers see the run")
     args = ap.parse_args()
     explicit = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
     if args.config is not None:
         preset = {1: dict(frames=256), 2: dict(frames=4096, bp_iters=30, osd=(30, 2)), 3: dict(frames=8192),
-                  4: dict(frames=2048, signals=10, snr=(-24.0, -20.0), osd3=30)}[args.config]
+                  4: dict(frames=2048, signals=10, snr=(-24.0, -20.0), osd3=30, osd_max_hd=32)}[args.config]
         for k, v in preset.items():
             if "--" + k.replace("_", "-") not in explicit:
                 setattr(args, k, v)
@@ -217,8 +218,11 @@ def main():
         cfg.osd_single, cfg.osd_double = args.osd
     if args.osd3 is not None:
         cfg.osd_triple = args.osd3
-    knobs = f"BP {cfg.bp_iters_a}/{cfg.bp_iters_b} iters, OSD {cfg.osd_single}/{cfg.osd_double}" + (f"/order-3 over {cfg.osd_triple}" if cfg.osd_triple else "")
-    reference_knobs = (cfg.bp_iters_b, cfg.osd_single, cfg.osd_double, cfg.osd_triple) == (20, 30, 2, 0)
+    if args.osd_max_hd is not None:
+        cfg.osd_max_hd = args.osd_max_hd
+    knobs = (f"BP {cfg.bp_iters_a}/{cfg.bp_iters_b} iters, OSD {cfg.osd_single}/{cfg.osd_double}" + (f"/order-3 over {cfg.osd_triple}" if cfg.osd_triple else "")
+             + (f", distance gate {cfg.osd_max_hd}" if cfg.osd_max_hd else ""))
+    reference_knobs = (cfg.bp_iters_b, cfg.osd_single, cfg.osd_double, cfg.osd_triple, cfg.osd_max_hd) == (20, 30, 2, 0, 0)
     h = _lib.Handle(cfg=cfg, device=local, max_frames=B)
     h.set_streams(args.streams)
     if args.host_synth:

@@ -39,8 +39,15 @@ def main():
             h.close()
             h = _lib.Handle(max_frames=48)
         h.set_streams(ns)
-        mode = int(rng.integers(0, 3))
-        if mode == 0:                                   # synchronous host-pointer entry
+        mode = int(rng.integers(0, 4))
+        if mode == 3:                                   # pipelined host entry: two batches in flight from host memory (pageable here)
+            s2 = int(rng.integers(0, 48 - B + 1))
+            a1, a2 = np.ascontiguousarray(frames[start:start + B]), np.ascontiguousarray(frames[s2:s2 + B])
+            h.enqueue_host(a1)
+            h.enqueue_host(a2)
+            assert digest(h.fetch(B)) == ref[start:start + B], ("host pipelined", B, ns, start)
+            assert digest(h.fetch(B)) == ref[s2:s2 + B], ("host pipelined 2", B, ns, s2)
+        elif mode == 0:                                 # synchronous host-pointer entry
             got = digest(h.decode_batch(frames[start:start + B]))
             assert got == ref[start:start + B], (B, ns, start)
         else:                                           # device-resident, pipelined: two batches in flight, fetched oldest first
