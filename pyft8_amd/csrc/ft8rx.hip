@@ -92,6 +92,8 @@ struct ft8rx_handle {
     cpx *d_A, *d_spec;
     ft8rx_event* d_ev; int32_t* d_evcount;
     const uint32_t* d_trials; int n_trials;      // OSD trial list of this configuration
+    int32_t* d_work[WL_N];                       // ladder work lists (kernels/common.hpp: WorkList), [B][MAXC] candidate ids each
+    int32_t* d_wcount;                           // [16 chunks][WL_N] list lengths, zeroed at the head of every chunk's chain
     // Result slots.  A batch writes its records/events into slot k % 2 (slot 0 = d_rec/d_ncand/d_ev/d_evcount above) and, when its
     // kernels are done, the copy stream moves them into page-locked host buffers while the next batch computes into the other
     // slot; ft8rx_fetch_results hands out the oldest unfetched batch.  At most two batches' results are retained.
@@ -237,6 +239,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     rc |= dalloc(h, &h->d_attO, B * MAXC * 10);
     rc |= dalloc(h, &h->d_A, B * 96000);
     rc |= dalloc(h, &h->d_spec, B * FT8RX_SPEC_BINS);
+    for (int i = 0; i < WL_N; i++) rc |= dalloc(h, &h->d_work[i], B * MAXC);
+    rc |= dalloc(h, &h->d_wcount, (size_t)16 * WL_N);
     rc |= dalloc(h, &h->d_ev, B * FT8RX_EVENT_CAP);
     rc |= dalloc(h, &h->d_evcount, B);
     h->s_rec[0] = h->d_rec; h->s_ncand[0] = h->d_ncand; h->s_ev[0] = h->d_ev; h->s_evcount[0] = h->d_evcount;
@@ -344,7 +348,14 @@ int ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms
 
 
 // the kernel chain for frames [f0, f0+B) on stream s (all buffers are frame-major, so a chunk is a pointer offset)
-static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B, hipStream_t s, bool prof, int slot) {
+#ifndef LADDER_GRID_CAP
+#define LADDER_GRID_CAP (4 * 256 * 32)
+#endif
+// ladder kernels launch a bounded grid that strides over their work list (a few items per block at most): enough blocks to fill the
+// chip four times over, never more than there can be items
+static int ladder_grid(int max_items) { const int cap = LADDER_GRID_CAP; return max_items < cap ? max_items : cap; }
+
+static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B, hipStream_t s, bool prof, int slot, int chunk) {
     const ft8rx_config& c = h->cfg;
     const size_t F = (size_t)f0;
     const int16_t* audio = d_audio + F * FT8RX_NSAMP;
@@ -357,6 +368,10 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     ft8rx_event* ev = h->s_ev[slot] + F * FT8RX_EVENT_CAP; int32_t* evc = h->s_evcount[slot] + F;
 #define STAGE(name) do { if (prof) { hipEventRecord(h->pev[h->pnames.size()], s); h->pnames.push_back(name); } } while (0)
     hipMemsetAsync(evc, 0, sizeof(int32_t) * B, s);
+    int32_t* wc = h->d_wcount + WL_N * chunk;
+    hipMemsetAsync(wc, 0, sizeof(int32_t) * WL_N, s);
+    WorkList wl[WL_N];
+    for (int i = 0; i < WL_N; i++) { wl[i].items = h->d_work[i] + F * MAXC; wl[i].count = wc + i; }
     STAGE("spectrogram");
     k_spectrogram<<<dim3(376, B), SPEC_NT, 0, s>>>(audio, grid, h->T);
     STAGE("sync");
@@ -366,22 +381,24 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c);
     STAGE("grid_llr");
     k_grid_llr<<<B * MAXC, 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr);
+    k_worklist<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, B, wl[WL_BP0]);
     STAGE("bp_grid");
-    k_bp<<<B * MAXC * 5, 64, 0, s>>>(0, llr0, rec, ncand, nullptr, att0, nullptr, ev, evc, c, c.bp_nc0_a, c.bp_iters_a);
+    k_bp<<<B * MAXC * 5, 64, 0, s>>>(0, llr0, rec, ncand, nullptr, att0, nullptr, ev, evc, c, c.bp_nc0_a, c.bp_iters_a, wl[WL_BP0]);
     STAGE("select0");
-    k_select0<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B);
+    k_select0<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_FINE]);
     STAGE("cycle_fft");
     k_cyc_a<<<dim3(40, B), 256, 0, s>>>(audio, A, h->T);
     k_cyc_bc<<<dim3(CYC_BC_BLOCKS, B), 256, 0, s>>>(A, spec, h->T);
     STAGE("fine");
-    k_fine<<<B * MAXC, FINE_NT, 0, s>>>(spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr);
+    k_fine<<<ladder_grid(B * MAXC), FINE_NT, 0, s>>>(spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
+    k_worklist<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, B, wl[WL_BP1]);
     STAGE("bp_fine");
-    k_bp<<<B * MAXC * 5, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b);
+    k_bp<<<B * MAXC * 5, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1]);
     STAGE("select1");
-    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attG, attB, B, c);
+    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attG, attB, B, c, wl[WL_OSD]);
     STAGE("osd");
-    k_osd<<<B * MAXC * 10, 64, 0, s>>>(0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials,
-                                       osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd);
+    k_osd<<<ladder_grid(B * MAXC * 10), 64, 0, s>>>(0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials,
+                                                    osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd, wl[WL_OSD]);
     STAGE("select2");
     k_select2<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attO, B);
     if (prof) hipEventRecord(h->pev[h->pnames.size()], s);
@@ -417,7 +434,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     if (nc > B / 8) nc = B / 8;
     if (nc <= 1) {
         if (host_audio) HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
-        enqueue_chain(h, d_audio, 0, B, h->stream, h->profiling, slot);
+        enqueue_chain(h, d_audio, 0, B, h->stream, h->profiling, slot, 0);
     } else {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         if (host_audio && !pipelined) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_fork, 0));
@@ -433,7 +450,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
                 HIPCHK(h, hipEventRecord(h->ev_chunk[k], cs));
                 HIPCHK(h, hipStreamWaitEvent(s, h->ev_chunk[k], 0));
             }
-            enqueue_chain(h, d_audio, f0, n, s, false, slot);
+            enqueue_chain(h, d_audio, f0, n, s, false, slot, k);
         }
         for (int i = 0; i < h->n_streams; i++) {
             HIPCHK(h, hipEventRecord(h->ev_join[i], h->sub[i]));
@@ -630,7 +647,7 @@ int ft8rx_fine(ft8rx_handle* h, const float* spec, int B, int n, const int32_t* 
     float* d_sd = S.get<float>(n); NEED(d_sd);
     int32_t* d_out = S.get<int32_t>((size_t)n * 5); NEED(d_out);
     float* d_sg = sgrid ? S.get<float>((size_t)n * 632) : nullptr; if (sgrid) NEED(d_sg);
-    k_fine<<<n, FINE_NT, 0, h->stream>>>(h->d_spec, nullptr, nullptr, d_llr, h->T, h->cfg, d_trip, d_out, d_sd, d_sg);
+    k_fine<<<n, FINE_NT, 0, h->stream>>>(h->d_spec, nullptr, nullptr, d_llr, h->T, h->cfg, d_trip, d_out, d_sd, d_sg, WorkList{nullptr, nullptr});
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<int32_t> o((size_t)n * 5);
     HIPCHK(h, hipMemcpy(o.data(), d_out, sizeof(int32_t) * o.size(), hipMemcpyDeviceToHost));
@@ -650,7 +667,7 @@ int ft8rx_ldpc(ft8rx_handle* h, const float* llr, int n, int max_ncheck0, int ma
     float* d_out = S.get<float>((size_t)n * 174); NEED(d_out);
     HIPCHK(h, hipMemset(d_out, 0, sizeof(float) * (size_t)n * 174));
     Att* d_att = S.get<Att>(n); NEED(d_att);
-    k_bp<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, d_att, d_out, nullptr, nullptr, h->cfg, max_ncheck0, max_iters);
+    k_bp<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, d_att, d_out, nullptr, nullptr, h->cfg, max_ncheck0, max_iters, WorkList{nullptr, nullptr});
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<Att> a(n);
     HIPCHK(h, hipMemcpy(a.data(), d_att, sizeof(Att) * n, hipMemcpyDeviceToHost));
@@ -672,7 +689,7 @@ int ft8rx_osd_ext(ft8rx_handle* h, const float* llr, int n, int singleflips, int
     uint32_t* d_tr = S.put(tr.data(), tr.size()); NEED(d_tr);
     Att* d_att = S.get<Att>(n); NEED(d_att);
     k_osd<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, nullptr, d_att, nullptr, nullptr, d_tr, (int)tr.size(),
-                                   osd_nflip(singleflips, tripleflips), max_hd);
+                                   osd_nflip(singleflips, tripleflips), max_hd, WorkList{nullptr, nullptr});
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<Att> a(n);
     HIPCHK(h, hipMemcpy(a.data(), d_att, sizeof(Att) * n, hipMemcpyDeviceToHost));

@@ -12,19 +12,18 @@
 #ifndef BP_WV
 #define BP_WV 7          /* <= 72 VGPRs: 7 waves per SIMD; measured 1.76 -> 1.68 ms for both BP launches (profiles/r02_notes.md) */
 #endif
-__global__ __launch_bounds__(64, BP_WV) void k_bp(int mode, const float* __restrict__ llr_in, ft8rx_record* __restrict__ rec,
-                                           const int32_t* __restrict__ ncand, Att* __restrict__ attG, Att* __restrict__ attB,
-                                           float* __restrict__ saved, ft8rx_event* ev, int32_t* evcount, ft8rx_config cfg,
-                                           int max_nc0, int max_iters) {
+FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ llr_in, ft8rx_record* __restrict__ rec,
+                        const int32_t* __restrict__ ncand, Att* __restrict__ attG, Att* __restrict__ attB,
+                        float* __restrict__ saved, ft8rx_event* ev, int32_t* evcount, const ft8rx_config& cfg,
+                        int max_nc0, int max_iters) {
     __shared__ float llr[176];
     __shared__ float tl[576];        // 9 x 64 edge slots: slots >= 522 are dummy edges (variable 174, check 83) so that the
     __shared__ float dl[576];        // per-edge code below is straight-line for all nine slots of a lane
     __shared__ float P[84];
-    const int lane = threadIdx.x;
     int frame = 0, ci = 0, ap = 0; size_t vec;
-    if (mode == 2) vec = blockIdx.x;
+    if (mode == 2) vec = bid;
     else {
-        ap = blockIdx.x % 5; int c = blockIdx.x / 5; frame = c / MAXC; ci = c % MAXC;
+        ap = bid % 5; int c = bid / 5; frame = c / MAXC; ci = c % MAXC;
         if (ci >= ncand[frame]) return;
         if (rec[(size_t)frame * MAXC + ci].status != FT8RX_ST_ACTIVE) return;
         vec = (size_t)c;
@@ -141,41 +140,65 @@ __global__ __launch_bounds__(64, BP_WV) void k_bp(int mode, const float* __restr
 #endif
 }
 
+// mode 2 (test entry): one block per vector.  Pipeline modes: blocks stride over work list x 5 AP attempts.
+__global__ __launch_bounds__(64, BP_WV) void k_bp(int mode, const float* __restrict__ llr_in, ft8rx_record* __restrict__ rec,
+                                           const int32_t* __restrict__ ncand, Att* __restrict__ attG, Att* __restrict__ attB,
+                                           float* __restrict__ saved, ft8rx_event* ev, int32_t* evcount, ft8rx_config cfg,
+                                           int max_nc0, int max_iters, WorkList work) {
+    if (mode == 2) { bp_attempt(threadIdx.x, 2, blockIdx.x, llr_in, rec, ncand, attG, attB, saved, ev, evcount, cfg, max_nc0, max_iters); return; }
+    // one attempt per block (BP attempts are short and very uneven: the hardware's block dispatcher balances them better than a
+    // strided loop, and the straight-line kernel allocates registers better); blocks beyond the list exit after one load
+    const int item = blockIdx.x;
+    if (item >= *work.count * 5) return;
+    bp_attempt(threadIdx.x, mode, work.items[item / 5] * 5 + item % 5, llr_in, rec, ncand, attG, attB, saved, ev, evcount, cfg, max_nc0, max_iters);
+}
+
 // first success in ladder order after ipass 0 (receiver.py:72-78)
-__global__ void k_select0(ft8rx_record* rec, const int32_t* ncand, const Att* att0, int B) {
+__global__ void k_select0(ft8rx_record* rec, const int32_t* ncand, const Att* att0, int B, WorkList next) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= B * MAXC) return;
-    int frame = c / MAXC, ci = c % MAXC;
-    if (ci >= ncand[frame]) return;
-    ft8rx_record& r = rec[c];
-    if (r.status != FT8RX_ST_ACTIVE) return;
-    for (int ap = 0; ap < 5; ap++) {
-        const Att& a = att0[(size_t)c * 5 + ap];
-        if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 0; r.ap = (uint8_t)ap; r.method = a.method; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    bool go_on = false;
+    if (c < B * MAXC && (c % MAXC) < ncand[c / MAXC]) {
+        ft8rx_record& r = rec[c];
+        if (r.status == FT8RX_ST_ACTIVE) {
+            go_on = true;
+            for (int ap = 0; ap < 5; ap++) {
+                const Att& a = att0[(size_t)c * 5 + ap];
+                if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 0; r.ap = (uint8_t)ap; r.method = a.method; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; go_on = false; break; }
+            }
+        }
     }
+    work_push_block(next, go_on, c);                                // still undecoded: goes on to the fine sync
+}
+
+// work list of a ladder step = every candidate that is ACTIVE now (thread per candidate, one atomic per block)
+__global__ void k_worklist(const ft8rx_record* rec, const int32_t* ncand, int B, WorkList next) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = c < B * MAXC && (c % MAXC) < ncand[c / MAXC] && rec[c].status == FT8RX_ST_ACTIVE;
+    work_push_block(next, on, c);
 }
 
 // first success among ipass 2 (GOOD91 ap0,1), 3 (BP_A ap0,1 derived from the BP_B run), 4 (BP_B ap0..4)
-__global__ void k_select1(ft8rx_record* rec, const int32_t* ncand, const Att* attG, const Att* attB, int B, ft8rx_config cfg) {
+__global__ void k_select1(ft8rx_record* rec, const int32_t* ncand, const Att* attG, const Att* attB, int B, ft8rx_config cfg, WorkList next) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= B * MAXC) return;
-    int frame = c / MAXC, ci = c % MAXC;
-    if (ci >= ncand[frame]) return;
-    ft8rx_record& r = rec[c];
-    if (r.status != FT8RX_ST_ACTIVE) return;
-    for (int ap = 0; ap < 2; ap++) {
-        const Att& a = attG[(size_t)c * 2 + ap];
-        if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 2; r.ap = (uint8_t)ap; r.method = FT8RX_M_GOOD91; r.n_its = 0; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
+    bool go_on = false;
+    if (c < B * MAXC && (c % MAXC) < ncand[c / MAXC] && rec[c].status == FT8RX_ST_ACTIVE) {
+        ft8rx_record& r = rec[c];
+        go_on = true;
+        for (int ap = 0; ap < 2 && go_on; ap++) {
+            const Att& a = attG[(size_t)c * 2 + ap];
+            if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 2; r.ap = (uint8_t)ap; r.method = FT8RX_M_GOOD91; r.n_its = 0; r.msg_lo = a.lo; r.msg_hi = a.hi; go_on = false; }
+        }
+        for (int ap = 0; ap < 2 && go_on; ap++) {
+            const Att& a = attB[(size_t)c * 5 + ap];
+            if (a.ok && a.nc0 <= cfg.bp_nc0_a && a.n_its < cfg.bp_iters_a) {
+                r.status = FT8RX_ST_DECODED; r.ipass = 3; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_A; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; go_on = false; }
+        }
+        for (int ap = 0; ap < 5 && go_on; ap++) {
+            const Att& a = attB[(size_t)c * 5 + ap];
+            if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 4; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_B; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; go_on = false; }
+        }
     }
-    for (int ap = 0; ap < 2; ap++) {
-        const Att& a = attB[(size_t)c * 5 + ap];
-        if (a.ok && a.nc0 <= cfg.bp_nc0_a && a.n_its < cfg.bp_iters_a) {
-            r.status = FT8RX_ST_DECODED; r.ipass = 3; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_A; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
-    }
-    for (int ap = 0; ap < 5; ap++) {
-        const Att& a = attB[(size_t)c * 5 + ap];
-        if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 4; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_B; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; return; }
-    }
+    work_push_block(next, go_on, c);                                // still undecoded: goes on to OSD
 }
 
 // ipass 5 (OSD on llr0+AP, slots 0..4) then ipass 6 (OSD on the saved BP outputs, slots 5..9)

@@ -45,6 +45,37 @@ struct Att {               // one decode attempt's outcome
     uint8_t pad[2];
 };
 
+// Work lists of the decode ladder.  Each ladder kernel only has work for the candidates that are still ACTIVE (39 % of the 256 slots
+// per frame for the second BP, 27 % for OSD, a few per cent in sparse low-SNR frames), so instead of one mostly-empty block per slot
+// a thread-per-candidate kernel (k_worklist, k_select0, k_select1) appends the candidates that go on to a compact list and the
+// consumer indexes list x attempts: k_fine and k_osd with a bounded grid whose blocks stride over the items, k_bp with one
+// attempt per block (its attempts are short and very uneven).  Entries are chunk-relative candidate ids (frame * MAXC + ci); the
+// order is whatever the atomics give -- every attempt writes its own result slot and the host sorts the event log, so results do
+// not depend on it.
+struct WorkList { int32_t* items; int32_t* count; };
+FT8_DEV void work_push(const WorkList& w, int cand) { if (w.items) w.items[atomicAdd(w.count, 1)] = cand; }
+// Block-aggregated push for thread-per-candidate kernels (256-thread blocks): ONE atomic per block reserves a range -- tens of
+// thousands of atomics on a single counter serialise in L2 (measured: k_grid_llr 0.09 -> 0.61 ms with one atomic per candidate).
+// Every thread of the block must call this (it contains block barriers).
+FT8_DEV void work_push_block(const WorkList& w, bool want, int cand) {
+    __shared__ int s_wave[4], s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t m = __ballot(want);
+    if (lane == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = tot ? atomicAdd(w.count, tot) : 0;
+    }
+    __syncthreads();
+    if (want) {
+        int off = s_base + __popcll(m & ((1ull << lane) - 1));
+        for (int i = 0; i < wv; i++) off += s_wave[i];
+        w.items[off] = cand;
+    }
+}
+enum { WL_BP0 = 0, WL_FINE = 1, WL_BP1 = 2, WL_OSD = 3, WL_N = 4 };
+
 #define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */
 
 // grid row accessor with the reference's modulo-750 wrap (receiver.py:240,347,360)

@@ -225,10 +225,10 @@ FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, const cpx* wq, float* m
     sym32_quad<NT>(x, n2, wq, mag);
 }
 
-__global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
-                                                  const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
-                                                  const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
-                                                  float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
+FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
+                            const int32_t* __restrict__ ncand, float* __restrict__ llr0, const Tables& T, const ft8rx_config& cfg,
+                            const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
+                            float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
     __shared__ cpx z[3200];
 #ifndef FINE_NO_SLICE
     __shared__ cpx slice[FINE_SLICE];  // the candidate's 1064 spectrum bins, read by the first stage of all ten IFFTs
@@ -247,11 +247,11 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
     __shared__ float sc[16];
     __shared__ int ish[4];
     __shared__ cpx w32[32];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     int frame, ci = 0, f0, h0;
-    if (trip) { frame = trip[3 * blockIdx.x]; f0 = trip[3 * blockIdx.x + 1]; h0 = trip[3 * blockIdx.x + 2]; }
+    if (trip) { frame = trip[3 * bid]; f0 = trip[3 * bid + 1]; h0 = trip[3 * bid + 2]; }
     else {
-        frame = blockIdx.x / MAXC; ci = blockIdx.x % MAXC;
+        frame = bid / MAXC; ci = bid % MAXC;
         if (ci >= ncand[frame]) return;
         const ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
         if (r.status != FT8RX_ST_ACTIVE) return;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
     if (tid < 64) { int nm = __popcll(__ballot(match)); if (tid == 0) ish[1] = nm; }
     __syncthreads();
     const int nsync = ish[1];
-    if (trip && t_sgrid) for (int i = tid; i < 632; i += FINE_NT) t_sgrid[(size_t)blockIdx.x * 632 + i] = mg[i];
+    if (trip && t_sgrid) for (int i = tid; i < 632; i += FINE_NT) t_sgrid[(size_t)bid * 632 + i] = mg[i];
     int ret = 1; float sd = 0.0f; int snr = 0;
     if (nsync <= 6) ret = 0;           // block-uniform
     else {
@@ -377,19 +377,36 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         __syncthreads();
         sd = sc[10]; snr = ish[2];
         if (sd <= cfg.llr_sd_min) ret = -1;
-        float* out = llr0 + (size_t)blockIdx.x * 174;
+        float* out = llr0 + (size_t)bid * 174;
         for (int i = tid; i < 174; i += FINE_NT) out[i] = llr[i];
     }
     FT(13);
     FT_FLUSH;
     if (tid == 0) {
-        if (trip) { int32_t* o = t_out + 5 * (size_t)blockIdx.x; o[0] = ret; o[1] = tt; o[2] = ft; o[3] = nsync; o[4] = snr; t_sd[blockIdx.x] = sd; }
+        if (trip) { int32_t* o = t_out + 5 * (size_t)bid; o[0] = ret; o[1] = tt; o[2] = ft; o[3] = nsync; o[4] = snr; t_sd[bid] = sd; }
         else {
             ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
             r.ttweak = (int8_t)tt; r.ftweak = (int8_t)ft; r.nsync = (uint8_t)nsync;
             if (ret == 0) r.status = FT8RX_ST_STOP_COSTAS;
             else { r.fine_sd = sd; r.snr_fine = (int8_t)snr; if (ret < 0) r.status = FT8RX_ST_STOP_FINE_SD; }
         }
+    }
+}
+
+
+// test entry (trip != nullptr): one block per (frame, f0, h0) triple.  Pipeline: blocks stride over the fine-sync work list.
+__global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
+                                                  const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
+                                                  const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
+                                                  float* __restrict__ t_sd, float* __restrict__ t_sgrid, WorkList work) {
+    if (trip) { fine_candidate(threadIdx.x, blockIdx.x, spec, rec, ncand, llr0, T, cfg, trip, t_out, t_sd, t_sgrid); return; }
+    const int n = *work.count;
+#pragma unroll 1
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                               // opaque per item: nothing thread-specific is hoisted across candidates (register pressure)
+        fine_candidate(tid, work.items[item], spec, rec, ncand, llr0, T, cfg, nullptr, nullptr, nullptr, nullptr);
+        __syncthreads();                                            // the LDS images are reused by the next candidate
     }
 }
 

@@ -29,21 +29,20 @@ __device__ uint32_t d_G0T[192][3];       // column v of G0 = [I | A^T]: row bits
 FT8_DEV unsigned osd_syndrome(uint64_t w0, uint64_t w1) { return ft8_crc_syndrome(w0, w1); }     // table d_CRC_T: ft8_dev.h
 
 // mode 0: pipeline (work = (candidate, slot 0..9)); mode 2: raw vectors
-__global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,
-                                            const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,
-                                            const int32_t* __restrict__ ncand, Att* __restrict__ attO,
-                                            ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,
-                                            int nflip, int max_hd) {
+FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ llr_in, const float* __restrict__ saved,
+                         const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,
+                         const int32_t* __restrict__ ncand, Att* __restrict__ attO,
+                         ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,
+                         int nflip, int max_hd) {
     __shared__ float llr[176];
     __shared__ uint64_t skey[256];
     __shared__ uint64_t ftab[192];                         // per column (natural order): bit i = flip i covers it, bit 63 = order-0 codeword bit
     __shared__ uint32_t frow[3 * (OSD_MAXFLIP + 1)];       // unit vectors of the flip columns (their pivot rows)
     __shared__ uint32_t hmw[3];
     __shared__ uint16_t fsyn[OSD_MAXFLIP + 2];             // [i] flip i, [OSD_MAXFLIP] = 0 ("no flip"), [OSD_MAXFLIP + 1] order-0 codeword
-    const int lane = threadIdx.x;
-    int frame = 0, ci = 0, slot = 0; size_t vec = blockIdx.x;
+    int frame = 0, ci = 0, slot = 0; size_t vec = bid;
     if (mode == 0) {
-        slot = blockIdx.x % 10; int c = blockIdx.x / 10; frame = c / MAXC; ci = c % MAXC;
+        slot = bid % 10; int c = bid / 10; frame = c / MAXC; ci = c % MAXC;
         if (ci >= ncand[frame]) return;
         if (rec[(size_t)frame * MAXC + ci].status != FT8RX_ST_ACTIVE) return;
         if (slot < 5) { for (int i = lane; i < 174; i += 64) llr[i] = ap_value(slot, i, llr_in[(size_t)c * 174 + i]); }
@@ -234,6 +233,25 @@ __global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ 
         if (done) break;
     }
     if (lane == 0) attO[vec] = res;
+}
+
+
+// mode 2 (test entry): one block per vector.  Pipeline: blocks stride over OSD work list x 10 attempts (5 AP variants of the fine
+// LLRs, then the 5 saved BP outputs).
+__global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,
+                                            const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,
+                                            const int32_t* __restrict__ ncand, Att* __restrict__ attO,
+                                            ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,
+                                            int nflip, int max_hd, WorkList work) {
+    if (mode == 2) { osd_attempt(threadIdx.x, 2, blockIdx.x, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd); return; }
+    const int n = *work.count * 10;
+#pragma unroll 1
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));                              // opaque per item: nothing lane-specific is hoisted across attempts (register pressure)
+        osd_attempt(lane, 0, work.items[item / 10] * 10 + item % 10, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd);
+        __syncthreads();                                            // the LDS arrays are reused by the next attempt
+    }
 }
 
 #endif
