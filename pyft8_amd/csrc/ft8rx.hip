@@ -430,7 +430,9 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
         HIPCHK(h, hipStreamWaitEvent(cs, h->ev_comp[slot], 0));             // the kernels that last read this staging buffer are done
     }
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));          // the slot's previous results have left the device
-    int nc = h->profiling ? 1 : (host_audio ? 2 * h->n_streams : h->n_streams);
+    // synchronous host entry: twice as many chunks, so that the first kernels start after 1/8 of the copy; the pipelined entry's copies
+    // already overlap the previous batch, so it keeps the 4 larger chunks of the device-resident path
+    int nc = h->profiling ? 1 : ((host_audio && !pipelined) ? 2 * h->n_streams : h->n_streams);
     if (nc > B / 8) nc = B / 8;
     if (nc <= 1) {
         if (host_audio) HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
