@@ -347,9 +347,40 @@ FT8_DEV unsigned ft8_crc_syndrome(uint64_t b0, uint64_t b1) {
     return s;
 }
 
+// Wave-cooperative forms for wave-uniform words (call with all 64 lanes active).  A uniform-index lookup in a 16-bit table compiles
+// to a broadcast *vector* load (gfx950 has no sub-dword scalar loads): 12 of them per word kept the texture-address unit busy
+// longer than everything else the callers do.  Here lane b of every 16-lane row fetches byte b's entry -- one load instruction --
+// and the rows are XOR-reduced with DPP (quad_perm, quad_perm, row_half_mirror, row_mirror).
+FT8_DEV unsigned ft8_xor_row16(unsigned t) {
+    t ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xB1, 0xf, 0xf, false);      // quad_perm:[1,0,3,2]
+    t ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x4E, 0xf, 0xf, false);      // quad_perm:[2,3,0,1]
+    t ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x141, 0xf, 0xf, false);     // row_half_mirror (quads hold equal values)
+    t ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x140, 0xf, 0xf, false);     // row_mirror (halves hold equal values)
+    return t;
+}
+// this lane's table entry for the word (b0, b1): byte (lane & 15) of the 12; 0 for lanes 12..15 of a row
+FT8_DEV unsigned ft8_crc_entry(uint64_t b0, uint64_t b1, int lane) {
+    const int b = lane & 15;
+    const uint64_t w = (b < 8) ? b0 : b1;
+    const unsigned byte = (unsigned)(w >> (8 * (b & 7))) & 0xFFu;
+    const unsigned t = d_CRC_T[b < 12 ? b : 0][byte];                  // always a valid address; masked below (no branch around the load)
+    return t & (unsigned)((b - 12) >> 31);
+}
+FT8_DEV unsigned ft8_crc_syndrome_wave(uint64_t b0, uint64_t b1, int lane) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)ft8_xor_row16(ft8_crc_entry(b0, b1 & ((1ull << 27) - 1), lane)));
+}
+
 // 0 = no CRC match (or all-zero message), 1 = CRC ok but unpack() -> None, 2 = accepted
 FT8_DEV int ft8_crc_check(uint64_t b0, uint64_t b1, uint64_t* lo, uint64_t* hi) {
     if (ft8_crc_syndrome(b0, b1 & ((1ull << 27) - 1)) != 0) return 0;        // 12 table lookups instead of a 77-step bit loop
+    unsigned crc;
+    ft8_cw_to_msg(b0, b1, lo, hi, &crc);
+    if (*lo == 0 && *hi == 0) return 0;
+    return ft8_valid77(*lo, *hi) ? 2 : 1;
+}
+// the same for a wave-uniform word, all 64 lanes active
+FT8_DEV int ft8_crc_check_wave(uint64_t b0, uint64_t b1, int lane, uint64_t* lo, uint64_t* hi) {
+    if (ft8_crc_syndrome_wave(b0, b1, lane) != 0) return 0;
     unsigned crc;
     ft8_cw_to_msg(b0, b1, lo, hi, &crc);
     if (*lo == 0 && *hi == 0) return 0;

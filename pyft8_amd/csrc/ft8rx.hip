@@ -239,7 +239,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     rc |= dalloc(h, &h->d_attO, B * MAXC * 10);
     rc |= dalloc(h, &h->d_A, B * 96000);
     rc |= dalloc(h, &h->d_spec, B * FT8RX_SPEC_BINS);
-    for (int i = 0; i < WL_N; i++) rc |= dalloc(h, &h->d_work[i], B * MAXC);
+    for (int i = 0; i < WL_N; i++) rc |= dalloc(h, &h->d_work[i], B * MAXC * (i == WL_BP0 ? 5 : 1));      // WL_BP0 lists attempts
     rc |= dalloc(h, &h->d_wcount, (size_t)16 * WL_N);
     rc |= dalloc(h, &h->d_ev, B * FT8RX_EVENT_CAP);
     rc |= dalloc(h, &h->d_evcount, B);
@@ -371,7 +371,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     int32_t* wc = h->d_wcount + WL_N * chunk;
     hipMemsetAsync(wc, 0, sizeof(int32_t) * WL_N, s);
     WorkList wl[WL_N];
-    for (int i = 0; i < WL_N; i++) { wl[i].items = h->d_work[i] + F * MAXC; wl[i].count = wc + i; }
+    for (int i = 0; i < WL_N; i++) { wl[i].items = h->d_work[i] + F * MAXC * (i == WL_BP0 ? 5 : 1); wl[i].count = wc + i; }
     STAGE("spectrogram");
     k_spectrogram<<<dim3(376, B), SPEC_NT, 0, s>>>(audio, grid, h->T);
     STAGE("sync");
@@ -380,8 +380,8 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     STAGE("topk");
     k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c);
     STAGE("grid_llr");
-    k_grid_llr<<<B * MAXC, 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr);
-    k_worklist<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, B, wl[WL_BP0]);
+    k_grid_llr<<<B * MAXC, 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr, att0, ev, evc);
+    k_worklist_att<<<(B * MAXC * 5 + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_BP0]);
     STAGE("bp_grid");
     k_bp<<<B * MAXC * 5, 64, 0, s>>>(0, llr0, rec, ncand, nullptr, att0, nullptr, ev, evc, c, c.bp_nc0_a, c.bp_iters_a, wl[WL_BP0]);
     STAGE("select0");
@@ -616,7 +616,7 @@ int ft8rx_llr_grid(ft8rx_handle* h, const float* grid, int B, int n, const int32
     float* d_llr = S.get<float>((size_t)n * 174); NEED(d_llr);
     float* d_sd = S.get<float>(n); NEED(d_sd);
     int32_t* d_snr = S.get<int32_t>(n); NEED(d_snr);
-    k_grid_llr<<<n, 64, 0, h->stream>>>(h->d_grid, nullptr, nullptr, d_llr, h->cfg, d_trip, d_sd, d_snr);
+    k_grid_llr<<<n, 64, 0, h->stream>>>(h->d_grid, nullptr, nullptr, d_llr, h->cfg, d_trip, d_sd, d_snr, nullptr, nullptr, nullptr);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(llr, d_llr, sizeof(float) * (size_t)n * 174, hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(sd, d_sd, sizeof(float) * n, hipMemcpyDeviceToHost));

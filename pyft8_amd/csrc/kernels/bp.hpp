@@ -7,8 +7,9 @@
 // One wavefront per (candidate, AP) -- or per test vector.  Edge-parallel tanh / message update
 // (lane l owns edges l, l+64, ...), check-parallel products, variable-parallel accumulation in the
 // reference's np.add.at order; everything exchanged through LDS; parity via __ballot.
-// mode 0: pipeline ipass 0 (GOOD91 then BP(nc0_a, iters_a)), mode 1: pipeline fine stage
-// (GOOD91 for ap<2, BP(nc0_b, iters_b), save output llr), mode 2: raw vectors (tests).
+// mode 0: pipeline ipass 0, BP(nc0_a, iters_a) of the attempts that bp0_precheck (llr.hpp: GOOD91 + initial check count, done
+// where the grid LLRs are produced) left pending; mode 1: pipeline fine stage (GOOD91 for ap<2, BP(nc0_b, iters_b), save
+// output llr); mode 2: raw vectors (tests).
 #ifndef BP_WV
 #define BP_WV 7          /* <= 72 VGPRs: 7 waves per SIMD; measured 1.76 -> 1.68 ms for both BP launches (profiles/r02_notes.md) */
 #endif
@@ -34,16 +35,14 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
     __syncthreads();
     Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
     Att resG; memset(&resG, 0, sizeof(resG)); resG.n_its = -1;
-    const int ipG = (mode == 0) ? 0 : 2;
-    // ---- GOOD91: CRC on the hard decisions of llr[:91] (receiver.py:119-122)
-    bool doneG = false;
-    if (mode == 0 || (mode == 1 && ap < 2)) {
+    // ---- GOOD91 of the fine stage (ipass 2): CRC on the hard decisions of llr[:91] (receiver.py:119-122)
+    if (mode == 1 && ap < 2) {                 // (ipass 0's GOOD91 is done by bp0_precheck in k_grid_llr)
         uint64_t b0 = __ballot(llr[lane] > 0.0f);
         uint64_t b1 = __ballot(lane < 27 && llr[64 + (lane < 27 ? lane : 0)] > 0.0f);
         uint64_t lo, hi;
-        int r = ft8_crc_check(b0, b1, &lo, &hi);
-        if (r) { if (lane == 0) log_event(ev, evcount, frame, ci, ipG, ap, 0, lo, hi, r == 2); }
-        if (r == 2) { resG.ok = 1; resG.lo = lo; resG.hi = hi; resG.n_its = 0; resG.method = FT8RX_M_GOOD91; doneG = true; }
+        int r = ft8_crc_check_wave(b0, b1, lane, &lo, &hi);
+        if (r) { if (lane == 0) log_event(ev, evcount, frame, ci, 2, ap, 0, lo, hi, r == 2); }
+        if (r == 2) { resG.ok = 1; resG.lo = lo; resG.hi = hi; resG.n_its = 0; resG.method = FT8RX_M_GOOD91; }
     }
     // membership masks of this lane's two checks (c0 = lane, c1 = 64 + lane) over the 174 variables
     const int c0 = lane, c1 = lane + 64;
@@ -57,9 +56,8 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
     float mc[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) mc[i] = 0.0f;
-    bool run_bp = !(mode == 0 && doneG);       // ipass 0: the BP of this AP is only reached if GOOD91 failed
     res.has_out = 1;
-    if (run_bp) for (int it = 0; it < max_iters; it++) {
+    for (int it = 0; it < max_iters; it++) {
         // parity of every check from the hard decisions
         const uint64_t h0 = __ballot(llr[lane] > 0.0f), h1 = __ballot(llr[64 + lane] > 0.0f),
                        h2 = __ballot(lane < 46 && llr[128 + (lane < 46 ? lane : 0)] > 0.0f);
@@ -71,7 +69,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
             uint64_t b0 = h0;
             uint64_t b1 = h1 & ((1ull << 27) - 1);
             uint64_t lo, hi;
-            int r = ft8_crc_check(b0, b1, &lo, &hi);
+            int r = ft8_crc_check_wave(b0, b1, lane, &lo, &hi);
             if (r) {
                 int ipass = (mode == 0) ? 0 : ((ap < 2 && res.nc0 <= cfg.bp_nc0_a && it < cfg.bp_iters_a) ? 3 : 4);
                 if (lane == 0) log_event(ev, evcount, frame, ci, ipass, ap, it + 1, lo, hi, r == 2);
@@ -126,14 +124,13 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
         }
         __syncthreads();
     }
-    else res.has_out = 0;
     if (res.ok) res.method = (mode == 0) ? FT8RX_M_LDPC_A : FT8RX_M_LDPC_B;
     if (mode == 2) {
         if (lane == 0) attB[vec] = res;
         if (res.has_out) for (int i = lane; i < 174; i += 64) saved[vec * 174 + i] = llr[i];
         return;
     }
-    if (mode == 0) { if (lane == 0) attB[vec * 5 + ap] = doneG ? resG : res; return; }
+    if (mode == 0) { if (lane == 0) attB[vec * 5 + ap] = res; return; }
     if (lane == 0) { attB[vec * 5 + ap] = res; if (ap < 2) attG[vec * 2 + ap] = resG; }
 #ifndef BP_TIMING_NO_SAVED
     if (res.has_out) for (int i = lane; i < 174; i += 64) saved[(vec * 5 + ap) * 174 + i] = llr[i];
@@ -148,7 +145,13 @@ __global__ __launch_bounds__(64, BP_WV) void k_bp(int mode, const float* __restr
     if (mode == 2) { bp_attempt(threadIdx.x, 2, blockIdx.x, llr_in, rec, ncand, attG, attB, saved, ev, evcount, cfg, max_nc0, max_iters); return; }
     // one attempt per block (BP attempts are short and very uneven: the hardware's block dispatcher balances them better than a
     // strided loop, and the straight-line kernel allocates registers better); blocks beyond the list exit after one load
+    // mode 0: the list holds attempts (candidate * 5 + ap) that survived bp0_precheck; mode 1: candidates, five attempts each
     const int item = blockIdx.x;
+    if (mode == 0) {
+        if (item >= *work.count) return;
+        bp_attempt(threadIdx.x, 0, work.items[item], llr_in, rec, ncand, attG, attB, saved, ev, evcount, cfg, max_nc0, max_iters);
+        return;
+    }
     if (item >= *work.count * 5) return;
     bp_attempt(threadIdx.x, mode, work.items[item / 5] * 5 + item % 5, llr_in, rec, ncand, attG, attB, saved, ev, evcount, cfg, max_nc0, max_iters);
 }
@@ -175,6 +178,13 @@ __global__ void k_worklist(const ft8rx_record* rec, const int32_t* ncand, int B,
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     const bool on = c < B * MAXC && (c % MAXC) < ncand[c / MAXC] && rec[c].status == FT8RX_ST_ACTIVE;
     work_push_block(next, on, c);
+}
+
+// attempt list of the first BP: thread per (candidate, ap); pending = left open by bp0_precheck
+__global__ void k_worklist_att(const ft8rx_record* rec, const int32_t* ncand, const Att* att0, int B, WorkList next) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, c = i / 5;
+    const bool on = c < B * MAXC && (c % MAXC) < ncand[c / MAXC] && rec[c].status == FT8RX_ST_ACTIVE && att0[i].pad[1] != 0;
+    work_push_block(next, on, i);
 }
 
 // first success among ipass 2 (GOOD91 ap0,1), 3 (BP_A ap0,1 derived from the BP_B run), 4 (BP_B ap0..4)

@@ -55,11 +55,78 @@ FT8_DEV void llr_from_p(const float* p, float* llr, float* sq, int lane, bool ac
     *sd_out = sd; *snr_out = snr;
 }
 
-// block of 64 = one candidate (or one test triple when `trip` is given)
+// ------------------------------------------------------------------------------------ AP masks (receiver.py:109-117)
+FT8_DEV float ap_value(int ap, int i, float v) {
+    if (ap == 1) {
+        if (i < 29) return d_AP_CQ[i] ? 5.0f : -5.0f;
+        if (i == 74 || i == 75 || i == 57 || i == 58) return -5.0f;
+        if (i == 76) return 5.0f;
+    } else if (ap >= 2) {
+        if (i >= 58 && i < 77) return d_AP_END[ap - 2][i - 58] ? 5.0f : -5.0f;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------ ipass-0 pre-check
+// What every ipass-0 attempt starts with, for the five AP variants of one candidate, while its LLRs are still in LDS:
+// GOOD91 (receiver.py:119-122: CRC + unpack on the hard decisions of llr[:91]) and BP's initial unsatisfied-check count
+// (decoders.py:157-159).  Most attempts end right there (count > bp_nc0_a), and a wavefront of its own per attempt cost ~12 us of
+// dependent loads for that -- 78 % of the first BP launch.  Resolved attempts get their final Att record here; the others are
+// marked pending (pad[1] = 1) and k_worklist_att puts them on k_bp's attempt list.
+struct ChkMasks { uint64_t m[6]; };          // this lane's two checks (lane, lane + 64) as membership masks over the 174 variables
+FT8_DEV ChkMasks chk_masks(int lane) {
+    ChkMasks c;
+    c.m[0] = d_CHK_MASK[lane][0]; c.m[1] = d_CHK_MASK[lane][1]; c.m[2] = d_CHK_MASK[lane][2];
+    c.m[3] = d_CHK_MASK[lane + 64][0]; c.m[4] = d_CHK_MASK[lane + 64][1]; c.m[5] = d_CHK_MASK[lane + 64][2];
+    return c;
+}
+FT8_DEV void bp0_precheck(int lane, const float* llr /*LDS [174]*/, const ChkMasks& cm, int frame, int ci,
+                          Att* __restrict__ att /*this candidate's [5]*/, ft8rx_event* ev, int32_t* evcount, int max_nc0, int max_iters) {
+    const float v0 = llr[lane], v1 = llr[64 + lane], v2 = llr[128 + (lane < 46 ? lane : 0)];
+    const uint64_t m27 = (1ull << 27) - 1;
+    uint64_t h0[5], h1[5];
+    int nchk[5];
+#pragma unroll
+    for (int ap = 0; ap < 5; ap++) {
+        h0[ap] = __ballot(ap_value(ap, lane, v0) > 0.0f); h1[ap] = __ballot(ap_value(ap, 64 + lane, v1) > 0.0f);
+        const uint64_t h2 = __ballot(lane < 46 && ap_value(ap, 128 + lane, v2) > 0.0f);
+        const int par0 = (__popcll(h0[ap] & cm.m[0]) + __popcll(h1[ap] & cm.m[1]) + __popcll(h2 & cm.m[2])) & 1;
+        const int par1 = (__popcll(h0[ap] & cm.m[3]) + __popcll(h1[ap] & cm.m[4]) + __popcll(h2 & cm.m[5])) & 1;
+        nchk[ap] = __popcll(__ballot(par0)) + __popcll(__ballot(par1));
+    }
+    // CRC syndromes of the five words with two load instructions: row g of the wavefront (16 lanes) takes variant g, variant 4
+    // rides in the upper half of row 0's registers
+    const int g = lane >> 4;
+    const uint64_t w0 = g == 0 ? h0[0] : g == 1 ? h0[1] : g == 2 ? h0[2] : h0[3];
+    const uint64_t w1 = g == 0 ? h1[0] : g == 1 ? h1[1] : g == 2 ? h1[2] : h1[3];
+    const unsigned t = ft8_xor_row16(ft8_crc_entry(w0, w1 & m27, lane) | (ft8_crc_entry(h0[4], h1[4] & m27, lane) << 16));
+    // lanes 0..4 finish one variant each (the slow path -- CRC match: unpack + validity, event -- is ordinary per-lane code)
+    const unsigned syn_lo = (unsigned)__builtin_amdgcn_ds_bpermute((lane & 3) << 6, (int)t) & 0xFFFFu;     // lane l < 4 <- row l
+    const unsigned syn4 = (unsigned)__builtin_amdgcn_readfirstlane((int)t) >> 16;
+    if (lane < 5) {
+        const unsigned syn = lane < 4 ? syn_lo : syn4;
+        const uint64_t my0 = lane == 0 ? h0[0] : lane == 1 ? h0[1] : lane == 2 ? h0[2] : lane == 3 ? h0[3] : h0[4];
+        const uint64_t my1 = lane == 0 ? h1[0] : lane == 1 ? h1[1] : lane == 2 ? h1[2] : lane == 3 ? h1[3] : h1[4];
+        const int myn = lane == 0 ? nchk[0] : lane == 1 ? nchk[1] : lane == 2 ? nchk[2] : lane == 3 ? nchk[3] : nchk[4];
+        Att a; memset(&a, 0, sizeof(a)); a.n_its = -1;
+        int r = 0;
+        uint64_t lo = 0, hi = 0;
+        if (syn == 0) {
+            r = ft8_crc_check(my0, my1 & m27, &lo, &hi);
+            if (r) log_event(ev, evcount, frame, ci, 0, lane, 0, lo, hi, r == 2);
+        }
+        if (r == 2) { a.ok = 1; a.lo = lo; a.hi = hi; a.n_its = 0; a.method = FT8RX_M_GOOD91; }
+        else if (max_iters > 0 && myn > max_nc0) a.nc0 = (uint8_t)myn;           // BP gives up before its first iteration
+        else a.pad[1] = 1;                                                        // pending: k_bp runs it
+        att[lane] = a;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid, ft8rx_record* __restrict__ rec,
                                                  const int32_t* __restrict__ ncand, float* __restrict__ llr0,
                                                  ft8rx_config cfg, const int32_t* __restrict__ trip, float* __restrict__ t_sd,
-                                                 int32_t* __restrict__ t_snr) {
+                                                 int32_t* __restrict__ t_snr, Att* __restrict__ att0, ft8rx_event* ev,
+                                                 int32_t* evcount) {
     __shared__ float p[464];
     __shared__ float llr[174];
     __shared__ float sq[174];
@@ -72,6 +139,8 @@ __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid,
         const ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
         f0 = r.f0_idx; h0 = r.h0_idx;
     }
+    ChkMasks cm;
+    if (att0) cm = chk_masks(lane);              // issued with the gather below
     const float* g = grid + (size_t)frame * FT8RX_GRID_ROWS * FT8RX_GRID_COLS;
     for (int i = lane; i < 464; i += 64) {
         int s = i >> 3, t = i & 7;
@@ -90,18 +159,8 @@ __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid,
             if (sd <= cfg.llr_sd_min) r.status = FT8RX_ST_STOP_GRID_SD;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------ AP masks (receiver.py:109-117)
-FT8_DEV float ap_value(int ap, int i, float v) {
-    if (ap == 1) {
-        if (i < 29) return d_AP_CQ[i] ? 5.0f : -5.0f;
-        if (i == 74 || i == 75 || i == 57 || i == 58) return -5.0f;
-        if (i == 76) return 5.0f;
-    } else if (ap >= 2) {
-        if (i >= 58 && i < 77) return d_AP_END[ap - 2][i - 58] ? 5.0f : -5.0f;
-    }
-    return v;
+    if (att0 && !(sd <= cfg.llr_sd_min))        // pipeline: the candidate stays ACTIVE -> pre-check its five ipass-0 attempts
+        bp0_precheck(lane, llr, cm, frame, ci, att0 + (size_t)blockIdx.x * 5, ev, evcount, cfg.bp_nc0_a, cfg.bp_iters_a);
 }
 
 #endif
