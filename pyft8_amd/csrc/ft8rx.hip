@@ -303,7 +303,9 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
             if (v < 77) { const int pos = 76 - v; syn91[v] = (uint16_t)hostmsg::crc14_serial(pos < 64 ? (1ull << pos) : 0ull, pos >= 64 ? (1ull << (pos - 64)) : 0ull); }
             else syn91[v] = (uint16_t)(1u << (13 - (v - 77)));
         }
-        ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_SYN91), syn91, sizeof(syn91)) == hipSuccess;
+        uint32_t synm[14][3]; memset(synm, 0, sizeof(synm));
+        for (int v = 0; v < 91; v++) for (int k = 0; k < 14; k++) if ((syn91[v] >> k) & 1) synm[k][v >> 5] |= 1u << (v & 31);
+        ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_SYNM), synm, sizeof(synm)) == hipSuccess;
         static uint16_t ct[12][256];
         for (int b = 0; b < 12; b++) for (int x = 0; x < 256; x++) { uint16_t a = 0; for (int t = 0; t < 8; t++) if ((x >> t) & 1) a ^= syn91[8 * b + t]; ct[b][x] = a; }
         ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CRC_T), ct, sizeof(ct)) == hipSuccess;

@@ -24,7 +24,10 @@ FT8_DEV uint64_t shfl64(uint64_t v, int src) {
 #define OSD_MAXTRIALS 16384       /* trial index must fit the 16-bit seq of the event log */
 #define OSD_NONE 0xFFu            /* "no flip" in a packed trial entry (i | j << 8 | k << 16) */
 
-__device__ uint16_t d_SYN91[96];         // CRC syndrome of codeword bit v alone (v < 77: message bit, 77..90: the CRC field bit itself)
+// CRC syndrome of codeword bit v alone (v < 77: message bit, 77..90: the CRC field bit itself), bit-sliced: d_SYNM[k][w] bit b = bit k
+// of the syndrome of codeword bit 32 w + b.  Constant address space: wave-uniform reads become scalar loads (a uniform lookup in a
+// 16-bit __device__ table is a broadcast vector load -- 91 of them per attempt kept the texture-address path busy, profiles/r02_notes.md)
+__device__ __constant__ uint32_t d_SYNM[14][3];
 __device__ uint32_t d_G0T[192][3];       // column v of G0 = [I | A^T]: row bits 0..31, 32..63, 64..90 (columns >= 174 are zero)
 FT8_DEV unsigned osd_syndrome(uint64_t w0, uint64_t w1) { return ft8_crc_syndrome(w0, w1); }     // table d_CRC_T: ft8_dev.h
 
@@ -174,13 +177,25 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     // back to natural column order: ftab[column]
     ftab[ord0] = f0; ftab[ord1] = f1; if (has2) ftab[ord2] = f2;
     __syncthreads();
-    // CRC syndromes (the CRC is linear): lane i < nflip takes flip i, lane 63 the order-0 codeword; the per-bit syndromes of the
-    // 91-bit word are constants of the CRC polynomial (d_SYN91, filled at create time)
+    // CRC syndromes (the CRC is linear): lane i < nflip takes flip i, lane 63 the order-0 codeword.  The lane gathers its word as a
+    // 91-bit column set (bit `bitsel` of every ftab entry), then each of the 14 syndrome bits is a masked parity (d_SYNM)
     {
         const int bitsel = (lane < nflip) ? lane : 63;
+        const bool up = bitsel >= 32;
+        const int sh = bitsel & 31;
+        uint32_t ra = 0, rb = 0, rc = 0;
+#pragma unroll 8
+        for (int v = 0; v < 32; v++) {
+            const uint64_t a = ftab[v], b = ftab[32 + v], c = ftab[64 + (v < 27 ? v : 0)];
+            ra |= (((up ? (uint32_t)(a >> 32) : (uint32_t)a) >> sh) & 1u) << v;
+            rb |= (((up ? (uint32_t)(b >> 32) : (uint32_t)b) >> sh) & 1u) << v;
+            rc |= (((up ? (uint32_t)(c >> 32) : (uint32_t)c) >> sh) & 1u) << v;
+        }
+        rc &= (1u << 27) - 1;
         unsigned sy = 0;
-#pragma unroll 7
-        for (int v = 0; v < 91; v++) sy ^= ((ftab[v] >> bitsel) & 1ull) ? (unsigned)d_SYN91[v] : 0u;
+#pragma unroll
+        for (int k = 0; k < 14; k++)
+            sy |= (unsigned)((__popc(ra & d_SYNM[k][0]) + __popc(rb & d_SYNM[k][1]) + __popc(rc & d_SYNM[k][2])) & 1) << k;
         if (lane < nflip) fsyn[lane] = (uint16_t)sy;
         if (lane == 63) fsyn[OSD_MAXFLIP + 1] = (uint16_t)sy;
         if (lane == 0) fsyn[OSD_MAXFLIP] = 0;
