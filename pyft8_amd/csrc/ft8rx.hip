@@ -390,7 +390,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     k_select0<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_FINE]);
     STAGE("cycle_fft");
     k_cyc_a<<<dim3(40, B), 256, 0, s>>>(audio, A, h->T);
-    k_cyc_bc<<<dim3(CYC_BC_BLOCKS, B), 256, 0, s>>>(A, spec, h->T);
+    k_cyc_bc<<<dim3(CYC_BC_GRID, B), 256, 0, s>>>(A, spec, h->T);
     STAGE("fine");
     k_fine<<<ladder_grid(B * MAXC), FINE_NT, 0, s>>>(spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
     k_worklist<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, B, wl[WL_BP1]);
@@ -631,7 +631,7 @@ int ft8rx_cycle_spectrum(ft8rx_handle* h, const int16_t* audio, int B, float* sp
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
     k_cyc_a<<<dim3(40, B), 256, 0, h->stream>>>(h->d_audio, h->d_A, h->T);
-    k_cyc_bc<<<dim3(CYC_BC_BLOCKS, B), 256, 0, h->stream>>>(h->d_A, h->d_spec, h->T);
+    k_cyc_bc<<<dim3(CYC_BC_GRID, B), 256, 0, h->stream>>>(h->d_A, h->d_spec, h->T);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(spec, h->d_spec, sizeof(cpx) * (size_t)B * FT8RX_SPEC_BINS, hipMemcpyDeviceToHost));
     return 0;

@@ -84,13 +84,11 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
             n0 = d_CHK_N[c0]; e00 = d_CHK_E0[c0];
             n1 = (c1 < 83) ? d_CHK_N[c1] : 0; e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
         }
-        float tt[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const int e = lane + 64 * i;
             const float v2c = llr[ev_[i]] - mc[i];
-            tt[i] = ft8_tanhf(-v2c);
-            tl[e] = tt[i];
+            tl[e] = ft8_tanhf(-v2c);
         }
         __syncthreads();
         {
@@ -111,8 +109,9 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const int e = lane + 64 * i;
-            const float Pc = P[ec_[i]], u = 1.18f * tt[i];
-            const float nm = (Pc * tt[i]) / ((Pc - u) * (u + Pc));     // = e/((e-1.18)(1.18+e)), e = P/t, in one division
+            const float tti = tl[e];          // own slot, re-read: keeping tt[] in registers across the barriers spilled 24 B per thread at 72 VGPRs
+            const float Pc = P[ec_[i]], u = 1.18f * tti;
+            const float nm = (Pc * tti) / ((Pc - u) * (u + Pc));     // = e/((e-1.18)(1.18+e)), e = P/t, in one division
             dl[e] = nm - mc[i];
             mc[i] = nm;
         }

@@ -29,9 +29,7 @@ __global__ __launch_bounds__(256) void k_cyc_a(const int16_t* __restrict__ audio
     cpx* out = A + (size_t)f * 96000;
     for (int i = tid; i < 2400; i += 256) {
         int c = i & 7, k1 = i >> 3, n2 = n2b + c;
-        cpx v = r[c * 300 + k1];
-        if (n2 * k1 != 0) v = cmul(v, T.W96000[n2 * k1]);
-        out[k1 * 320 + n2] = v;
+        out[k1 * 320 + n2] = cmul(r[c * 300 + k1], T.W96000[n2 * k1]);      // unconditional: W^0 = (1, -0) is an exact identity
     }
 }
 
@@ -41,11 +39,17 @@ __global__ __launch_bounds__(256) void k_cyc_a(const int16_t* __restrict__ audio
 // all eight rows from LDS -- the 96000-point intermediate Z never goes to HBM (r01: 197 MB written + 201 MB read per 256 frames).
 // Blocks 0..37: k1 = 1 + 4 b (rows 1..152 and 148..299; the rows 148..152 are produced twice, identically); block 38: the
 // self-paired rows 0 (partner bin 300 (320 - k2)) and 150.  Only bins < 49152 are kept (k2 < 164).
+// XCD-aware tile map as in k_cyc_a (gridDim.x = 40 = 8 XCDs x 5, workgroup id % 8 = XCD): one XCD takes five adjacent row
+// blocks = 20 adjacent rows, so the 32-byte output runs of neighbouring blocks (bin k = row + 300 k2) meet in ONE L2 and leave it
+// as whole lines; with the plain map the partial lines went out from four L2s (WRITE_SIZE 156 MB for 101 MB of spectrum).
 #define CYC_BC_BLOCKS 39
+#define CYC_BC_GRID 40
 __global__ __launch_bounds__(256) void k_cyc_bc(const cpx* __restrict__ A, cpx* __restrict__ spec, Tables T) {
     __shared__ cpx bufA[8 * 320];
     __shared__ cpx bufB[8 * 320];
-    const int f = blockIdx.y, tid = threadIdx.x, b = blockIdx.x;
+    static_assert(CYC_BC_GRID == 8 * 5 && CYC_BC_BLOCKS <= CYC_BC_GRID, "tile map: 40 slots = 8 XCDs x 5");
+    const int f = blockIdx.y, tid = threadIdx.x, b = (blockIdx.x & 7) * 5 + (blockIdx.x >> 3);
+    if (b >= CYC_BC_BLOCKS) return;
     const cpx* in = A + (size_t)f * 96000;
     // row index of slot r (0..7): slots 0..3 = the low rows, 4..7 = their partners (slot 4 + j is the partner of slot j)
     const bool special = (b == CYC_BC_BLOCKS - 1);
