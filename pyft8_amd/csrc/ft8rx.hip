@@ -385,7 +385,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     k_grid_llr<<<B * MAXC, 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr, att0, ev, evc);
     k_worklist_att<<<(B * MAXC * 5 + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_BP0]);
     STAGE("bp_grid");
-    k_bp<<<B * MAXC * 5, 64, 0, s>>>(0, llr0, rec, ncand, nullptr, att0, nullptr, ev, evc, c, c.bp_nc0_a, c.bp_iters_a, wl[WL_BP0]);
+    k_bp<<<B * MAXC * 5, 64, 0, s>>>(0, llr0, rec, ncand, nullptr, att0, nullptr, ev, evc, c, c.bp_nc0_a, c.bp_iters_a, wl[WL_BP0], 0, 5);
     STAGE("select0");
     k_select0<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_FINE]);
     STAGE("cycle_fft");
@@ -395,9 +395,13 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     k_fine<<<ladder_grid(B * MAXC), FINE_NT, 0, s>>>(spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
     k_worklist<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, B, wl[WL_BP1]);
     STAGE("bp_fine");
-    k_bp<<<B * MAXC * 5, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1]);
+    k_bp<<<B * MAXC, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1], 0, 1);
+    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(0, rec, ncand, attG, attB, B, c, wl[WL_BP1B]);
+    k_bp<<<B * MAXC, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1B], 1, 1);
+    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(1, rec, ncand, attG, attB, B, c, wl[WL_BP1C]);
+    k_bp<<<B * MAXC * 3, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1C], 2, 3);
     STAGE("select1");
-    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attG, attB, B, c, wl[WL_OSD]);
+    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(2, rec, ncand, attG, attB, B, c, wl[WL_OSD]);
     STAGE("osd");
     k_osd<<<ladder_grid(B * MAXC * 10), 64, 0, s>>>(0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials,
                                                     osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd, wl[WL_OSD]);
@@ -671,7 +675,7 @@ int ft8rx_ldpc(ft8rx_handle* h, const float* llr, int n, int max_ncheck0, int ma
     float* d_out = S.get<float>((size_t)n * 174); NEED(d_out);
     HIPCHK(h, hipMemset(d_out, 0, sizeof(float) * (size_t)n * 174));
     Att* d_att = S.get<Att>(n); NEED(d_att);
-    k_bp<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, d_att, d_out, nullptr, nullptr, h->cfg, max_ncheck0, max_iters, WorkList{nullptr, nullptr});
+    k_bp<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, d_att, d_out, nullptr, nullptr, h->cfg, max_ncheck0, max_iters, WorkList{nullptr, nullptr}, 0, 1);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<Att> a(n);
     HIPCHK(h, hipMemcpy(a.data(), d_att, sizeof(Att) * n, hipMemcpyDeviceToHost));

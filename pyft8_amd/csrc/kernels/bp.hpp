@@ -8,8 +8,13 @@
 // (lane l owns edges l, l+64, ...), check-parallel products, variable-parallel accumulation in the
 // reference's np.add.at order; everything exchanged through LDS; parity via __ballot.
 // mode 0: pipeline ipass 0, BP(nc0_a, iters_a) of the attempts that bp0_precheck (llr.hpp: GOOD91 + initial check count, done
-// where the grid LLRs are produced) left pending; mode 1: pipeline fine stage (GOOD91 for ap<2, BP(nc0_b, iters_b), save
-// output llr); mode 2: raw vectors (tests).
+// where the grid LLRs are produced) left pending; mode 1: pipeline fine stage, BP(nc0_b, iters_b) of one AP variant with its
+// output llr saved -- the ap 0 attempt first evaluates GOOD91 for ap 0 and ap 1 (ipass 2) and skips its BP if either succeeds;
+// mode 2: raw vectors (tests).
+// The fine-stage attempts run in ladder order in three launches (receiver.py:84-98: GOOD91 ap 0,1; BP_A ap 0,1; BP_B ap 0..4, first
+// success wins): {GOOD91 x 2, BP ap 0} -> k_select1(0) -> {BP ap 1} -> k_select1(1) -> {BP ap 2,3,4} -> k_select1(2).  A candidate
+// that is decided leaves the lists; with all five variants in one launch 42 % of the candidates (the ones that decode here) ran
+// four BPs nobody reads, most of them 20 iterations on wrongly forced bits (profiles/r02_notes.md).
 #ifndef BP_WV
 #define BP_WV 7          /* <= 72 VGPRs: 7 waves per SIMD; measured 1.76 -> 1.68 ms for both BP launches (profiles/r02_notes.md) */
 #endif
@@ -34,15 +39,22 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
     if (lane == 0) P[83] = 1.0f;
     __syncthreads();
     Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
-    Att resG; memset(&resG, 0, sizeof(resG)); resG.n_its = -1;
-    // ---- GOOD91 of the fine stage (ipass 2): CRC on the hard decisions of llr[:91] (receiver.py:119-122)
-    if (mode == 1 && ap < 2) {                 // (ipass 0's GOOD91 is done by bp0_precheck in k_grid_llr)
-        uint64_t b0 = __ballot(llr[lane] > 0.0f);
-        uint64_t b1 = __ballot(lane < 27 && llr[64 + (lane < 27 ? lane : 0)] > 0.0f);
-        uint64_t lo, hi;
-        int r = ft8_crc_check_wave(b0, b1, lane, &lo, &hi);
-        if (r) { if (lane == 0) log_event(ev, evcount, frame, ci, 2, ap, 0, lo, hi, r == 2); }
-        if (r == 2) { resG.ok = 1; resG.lo = lo; resG.hi = hi; resG.n_its = 0; resG.method = FT8RX_M_GOOD91; }
+    // ---- GOOD91 of the fine stage (ipass 2, ap 0 then ap 1): CRC on the hard decisions of llr[:91] (receiver.py:119-122)
+    // (ipass 0's GOOD91 is done by bp0_precheck in k_grid_llr)
+    if (mode == 1 && ap == 0) {
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            Att resG; memset(&resG, 0, sizeof(resG)); resG.n_its = -1;
+            const uint64_t b0 = __ballot(ap_value(g, lane, llr[lane]) > 0.0f);
+            const uint64_t b1 = __ballot(lane < 27 && ap_value(g, 64 + lane, llr[64 + (lane < 27 ? lane : 0)]) > 0.0f);
+            uint64_t lo, hi;
+            const int r = ft8_crc_check_wave(b0, b1, lane, &lo, &hi);
+            if (r) { if (lane == 0) log_event(ev, evcount, frame, ci, 2, g, 0, lo, hi, r == 2); }
+            if (r == 2) { resG.ok = 1; resG.lo = lo; resG.hi = hi; resG.n_its = 0; resG.method = FT8RX_M_GOOD91; any = true; }
+            if (lane == 0) attG[vec * 2 + g] = resG;
+        }
+        if (any) return;                       // decided at ipass 2: k_select1(0) never looks at this candidate's BP records
     }
     // membership masks of this lane's two checks (c0 = lane, c1 = 64 + lane) over the 174 variables
     const int c0 = lane, c1 = lane + 64;
@@ -130,29 +142,29 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
         return;
     }
     if (mode == 0) { if (lane == 0) attB[vec * 5 + ap] = res; return; }
-    if (lane == 0) { attB[vec * 5 + ap] = res; if (ap < 2) attG[vec * 2 + ap] = resG; }
+    if (lane == 0) attB[vec * 5 + ap] = res;
 #ifndef BP_TIMING_NO_SAVED
     if (res.has_out) for (int i = lane; i < 174; i += 64) saved[(vec * 5 + ap) * 174 + i] = llr[i];
 #endif
 }
 
-// mode 2 (test entry): one block per vector.  Pipeline modes: blocks stride over work list x 5 AP attempts.
+// mode 2 (test entry): one block per vector.  Pipeline modes: one attempt per block from the work list (BP attempts are short and
+// very uneven: the hardware's block dispatcher balances them better than a strided loop, and the straight-line kernel allocates
+// registers better); blocks beyond the list exit after one load.
+// mode 0: the list holds attempts (candidate * 5 + ap) that survived bp0_precheck; mode 1: candidates, AP variants ap_lo .. ap_lo + ap_n - 1
 __global__ __launch_bounds__(64, BP_WV) void k_bp(int mode, const float* __restrict__ llr_in, ft8rx_record* __restrict__ rec,
                                            const int32_t* __restrict__ ncand, Att* __restrict__ attG, Att* __restrict__ attB,
                                            float* __restrict__ saved, ft8rx_event* ev, int32_t* evcount, ft8rx_config cfg,
-                                           int max_nc0, int max_iters, WorkList work) {
+                                           int max_nc0, int max_iters, WorkList work, int ap_lo, int ap_n) {
     if (mode == 2) { bp_attempt(threadIdx.x, 2, blockIdx.x, llr_in, rec, ncand, attG, attB, saved, ev, evcount, cfg, max_nc0, max_iters); return; }
-    // one attempt per block (BP attempts are short and very uneven: the hardware's block dispatcher balances them better than a
-    // strided loop, and the straight-line kernel allocates registers better); blocks beyond the list exit after one load
-    // mode 0: the list holds attempts (candidate * 5 + ap) that survived bp0_precheck; mode 1: candidates, five attempts each
     const int item = blockIdx.x;
     if (mode == 0) {
         if (item >= *work.count) return;
         bp_attempt(threadIdx.x, 0, work.items[item], llr_in, rec, ncand, attG, attB, saved, ev, evcount, cfg, max_nc0, max_iters);
         return;
     }
-    if (item >= *work.count * 5) return;
-    bp_attempt(threadIdx.x, mode, work.items[item / 5] * 5 + item % 5, llr_in, rec, ncand, attG, attB, saved, ev, evcount, cfg, max_nc0, max_iters);
+    if (item >= *work.count * ap_n) return;
+    bp_attempt(threadIdx.x, mode, work.items[item / ap_n] * 5 + ap_lo + item % ap_n, llr_in, rec, ncand, attG, attB, saved, ev, evcount, cfg, max_nc0, max_iters);
 }
 
 // first success in ladder order after ipass 0 (receiver.py:72-78)
@@ -186,28 +198,36 @@ __global__ void k_worklist_att(const ft8rx_record* rec, const int32_t* ncand, co
     work_push_block(next, on, i);
 }
 
-// first success among ipass 2 (GOOD91 ap0,1), 3 (BP_A ap0,1 derived from the BP_B run), 4 (BP_B ap0..4)
-__global__ void k_select1(ft8rx_record* rec, const int32_t* ncand, const Att* attG, const Att* attB, int B, ft8rx_config cfg, WorkList next) {
+// Fine-stage ladder (receiver.py:84-98), order: GOOD91 ap 0, ap 1 (ipass 2); BP_A ap 0, ap 1 (ipass 3: the BP_B run of that variant
+// if it would also have succeeded under BP_A's limits); BP_B ap 0..4 (ipass 4).  step 0 runs after {GOOD91 x 2, BP ap 0}, step 1
+// after {BP ap 1}, step 2 after {BP ap 2,3,4}; a step decides what the attempts so far can decide and passes the rest on.
+FT8_DEV bool sel_take(ft8rx_record& r, const Att& a, int ipass, int ap, int method) {
+    r.status = FT8RX_ST_DECODED; r.ipass = (uint8_t)ipass; r.ap = (uint8_t)ap; r.method = (uint8_t)method; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi;
+    return false;
+}
+__global__ void k_select1(int step, ft8rx_record* rec, const int32_t* ncand, const Att* attG, const Att* attB, int B, ft8rx_config cfg, WorkList next) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     bool go_on = false;
     if (c < B * MAXC && (c % MAXC) < ncand[c / MAXC] && rec[c].status == FT8RX_ST_ACTIVE) {
         ft8rx_record& r = rec[c];
         go_on = true;
-        for (int ap = 0; ap < 2 && go_on; ap++) {
-            const Att& a = attG[(size_t)c * 2 + ap];
-            if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 2; r.ap = (uint8_t)ap; r.method = FT8RX_M_GOOD91; r.n_its = 0; r.msg_lo = a.lo; r.msg_hi = a.hi; go_on = false; }
+        const Att* b = attB + (size_t)c * 5;
+#define IS_A(a) ((a).ok && (a).nc0 <= cfg.bp_nc0_a && (a).n_its < cfg.bp_iters_a)
+        if (step == 0) {
+            const Att& g0 = attG[(size_t)c * 2], & g1 = attG[(size_t)c * 2 + 1];
+            if (g0.ok) { Att a = g0; a.n_its = 0; go_on = sel_take(r, a, 2, 0, FT8RX_M_GOOD91); }
+            else if (g1.ok) { Att a = g1; a.n_its = 0; go_on = sel_take(r, a, 2, 1, FT8RX_M_GOOD91); }
+            else if (IS_A(b[0])) go_on = sel_take(r, b[0], 3, 0, FT8RX_M_LDPC_A);
+        } else if (step == 1) {
+            if (IS_A(b[1])) go_on = sel_take(r, b[1], 3, 1, FT8RX_M_LDPC_A);
+            else if (b[0].ok) go_on = sel_take(r, b[0], 4, 0, FT8RX_M_LDPC_B);
+            else if (b[1].ok) go_on = sel_take(r, b[1], 4, 1, FT8RX_M_LDPC_B);
+        } else {
+            for (int ap = 2; ap < 5 && go_on; ap++) if (b[ap].ok) go_on = sel_take(r, b[ap], 4, ap, FT8RX_M_LDPC_B);
         }
-        for (int ap = 0; ap < 2 && go_on; ap++) {
-            const Att& a = attB[(size_t)c * 5 + ap];
-            if (a.ok && a.nc0 <= cfg.bp_nc0_a && a.n_its < cfg.bp_iters_a) {
-                r.status = FT8RX_ST_DECODED; r.ipass = 3; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_A; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; go_on = false; }
-        }
-        for (int ap = 0; ap < 5 && go_on; ap++) {
-            const Att& a = attB[(size_t)c * 5 + ap];
-            if (a.ok) { r.status = FT8RX_ST_DECODED; r.ipass = 4; r.ap = (uint8_t)ap; r.method = FT8RX_M_LDPC_B; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi; go_on = false; }
-        }
+#undef IS_A
     }
-    work_push_block(next, go_on, c);                                // still undecoded: goes on to OSD
+    work_push_block(next, go_on, c);                                // still undecoded: next BP step, or OSD after step 2
 }
 
 // ipass 5 (OSD on llr0+AP, slots 0..4) then ipass 6 (OSD on the saved BP outputs, slots 5..9)

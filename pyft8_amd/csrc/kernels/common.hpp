@@ -74,7 +74,7 @@ FT8_DEV void work_push_block(const WorkList& w, bool want, int cand) {
         w.items[off] = cand;
     }
 }
-enum { WL_BP0 = 0, WL_FINE = 1, WL_BP1 = 2, WL_OSD = 3, WL_N = 4 };
+enum { WL_BP0 = 0, WL_FINE = 1, WL_BP1 = 2, WL_BP1B = 3, WL_BP1C = 4, WL_OSD = 5, WL_N = 6 };
 
 #define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */
 

@@ -103,25 +103,33 @@ FT8_DEV void bp0_precheck(int lane, const float* llr /*LDS [174]*/, const ChkMas
     // lanes 0..4 finish one variant each (the slow path -- CRC match: unpack + validity, event -- is ordinary per-lane code)
     const unsigned syn_lo = (unsigned)__builtin_amdgcn_ds_bpermute((lane & 3) << 6, (int)t) & 0xFFFFu;     // lane l < 4 <- row l
     const unsigned syn4 = (unsigned)__builtin_amdgcn_readfirstlane((int)t) >> 16;
+    // (the ladder takes the variants in order and stops at the first success, receiver.py:72-78: a GOOD91 success at variant g
+    // means the variants after g are never tried -- no event, not pending)
+    int r = 0;
+    uint64_t lo = 0, hi = 0;
+    int myn = 0;
     if (lane < 5) {
         const unsigned syn = lane < 4 ? syn_lo : syn4;
         const uint64_t my0 = lane == 0 ? h0[0] : lane == 1 ? h0[1] : lane == 2 ? h0[2] : lane == 3 ? h0[3] : h0[4];
         const uint64_t my1 = lane == 0 ? h1[0] : lane == 1 ? h1[1] : lane == 2 ? h1[2] : lane == 3 ? h1[3] : h1[4];
-        const int myn = lane == 0 ? nchk[0] : lane == 1 ? nchk[1] : lane == 2 ? nchk[2] : lane == 3 ? nchk[3] : nchk[4];
+        myn = lane == 0 ? nchk[0] : lane == 1 ? nchk[1] : lane == 2 ? nchk[2] : lane == 3 ? nchk[3] : nchk[4];
+        if (syn == 0) r = ft8_crc_check(my0, my1 & m27, &lo, &hi);
+    }
+    const uint64_t okm = __ballot(r == 2);
+    const int first = okm ? __builtin_ctzll(okm) : 5;
+    if (lane < 5) {
         Att a; memset(&a, 0, sizeof(a)); a.n_its = -1;
-        int r = 0;
-        uint64_t lo = 0, hi = 0;
-        if (syn == 0) {
-            r = ft8_crc_check(my0, my1 & m27, &lo, &hi);
+        if (lane <= first) {
             if (r) log_event(ev, evcount, frame, ci, 0, lane, 0, lo, hi, r == 2);
+            if (r == 2) { a.ok = 1; a.lo = lo; a.hi = hi; a.n_its = 0; a.method = FT8RX_M_GOOD91; }
+            else if (max_iters > 0 && myn > max_nc0) a.nc0 = (uint8_t)myn;        // BP gives up before its first iteration
+            else a.pad[1] = 1;                                                    // pending: k_bp runs it
         }
-        if (r == 2) { a.ok = 1; a.lo = lo; a.hi = hi; a.n_its = 0; a.method = FT8RX_M_GOOD91; }
-        else if (max_iters > 0 && myn > max_nc0) a.nc0 = (uint8_t)myn;           // BP gives up before its first iteration
-        else a.pad[1] = 1;                                                        // pending: k_bp runs it
         att[lane] = a;
     }
 }
 
+// block of 64 = one candidate (or one test triple when `trip` is given)
 __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid, ft8rx_record* __restrict__ rec,
                                                  const int32_t* __restrict__ ncand, float* __restrict__ llr0,
                                                  ft8rx_config cfg, const int32_t* __restrict__ trip, float* __restrict__ t_sd,
