@@ -130,6 +130,13 @@ int  ft8rx_results_to_device(ft8rx_handle* h, int n_frames, ft8rx_record* d_reco
 /* per-kernel HIP-event timing of the most recent enqueue (enable before enqueue). names/ms: up to 16 */
 /* number of HIP streams a batch is cut across (1..8, default 4); profiling mode always uses one */
 int  ft8rx_set_streams(ft8rx_handle* h, int n);
+/* how the fine-stage BP attempts of a batch are launched; records and messages are identical either way:
+ * 0 (default) = in the reference's ladder order (receiver.py:84-98) as three launches, candidates that are decided dropping out in
+ *     between -- least work, highest throughput;
+ * 1 = all five AP variants in one launch -- one dependent BP instead of three: lower latency for batches too small to fill the GPU
+ *     (one frame: 0.41 vs 0.52 ms host to host).  The event log then also holds CRC-passing words of attempts the ladder would not
+ *     have reached; ft8rx_package_batch skips them. */
+int  ft8rx_set_ladder_mode(ft8rx_handle* h, int mode);
 int  ft8rx_set_profiling(ft8rx_handle* h, int on);
 int  ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms);
 

@@ -205,6 +205,10 @@ class Handle:
     def set_streams(self, n):
         self._chk(lib().ft8rx_set_streams(self._h, int(n)), "ft8rx_set_streams")
 
+    def set_ladder_mode(self, mode):
+        """0 (default) = fine-stage BP in ladder order, three launches (throughput); 1 = one launch for the five AP variants (latency)."""
+        self._chk(lib().ft8rx_set_ladder_mode(self._h, int(mode)), "ft8rx_set_ladder_mode")
+
     def set_profiling(self, on):
         lib().ft8rx_set_profiling(self._h, int(bool(on)))
 

@@ -73,6 +73,7 @@ struct ft8rx_handle {
     int device, max_frames;
     hipStream_t stream;
     int n_streams;                       // chunks of a batch run their kernel chains on separate streams
+    int ladder_mode;                     // fine-stage BP launches: 0 = ladder order (three launches), 1 = one launch (ft8rx_set_ladder_mode)
     hipStream_t sub[8];
     hipEvent_t ev_fork, ev_join[8];
     hipStream_t copy_s;              // host-to-device chunk copies of ft8rx_decode_batch, in order, never queued behind kernels
@@ -217,7 +218,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     if (device < 0 || device >= ndev) { set_err(nullptr, "ft8rx_create: device %d out of range (%d devices)", device, ndev); return -1; }
     ft8rx_handle* h = new ft8rx_handle();
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
-    h->n_streams = 4; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
+    h->n_streams = 4; h->ladder_mode = 0; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
     h->copy_s = nullptr; h->h2d_s = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
     for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
@@ -395,13 +396,22 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     k_fine<<<ladder_grid(B * MAXC), FINE_NT, 0, s>>>(spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
     k_worklist<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, B, wl[WL_BP1]);
     STAGE("bp_fine");
-    k_bp<<<B * MAXC, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1], 0, 1);
-    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(0, rec, ncand, attG, attB, B, c, wl[WL_BP1B]);
-    k_bp<<<B * MAXC, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1B], 1, 1);
-    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(1, rec, ncand, attG, attB, B, c, wl[WL_BP1C]);
-    k_bp<<<B * MAXC * 3, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1C], 2, 3);
-    STAGE("select1");
-    k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(2, rec, ncand, attG, attB, B, c, wl[WL_OSD]);
+    // fine-stage BP: in ladder order (three launches; decided candidates drop out), or -- ft8rx_set_ladder_mode(h, 1), for small
+    // batches where latency matters more than work -- all five variants in one launch: one dependent BP instead of three, same
+    // records and messages (the event log then also holds entries of attempts the ladder would not have reached)
+    if (h->ladder_mode == 0) {
+        k_bp<<<B * MAXC, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1], 0, 1);
+        k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(0, rec, ncand, attG, attB, B, c, wl[WL_BP1B]);
+        k_bp<<<B * MAXC, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1B], 1, 1);
+        k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(1, rec, ncand, attG, attB, B, c, wl[WL_BP1C]);
+        k_bp<<<B * MAXC * 3, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1C], 2, 3);
+        STAGE("select1");
+        k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(2, rec, ncand, attG, attB, B, c, wl[WL_OSD]);
+    } else {
+        k_bp<<<B * MAXC * 5, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1], 0, 5);
+        STAGE("select1");
+        k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(3, rec, ncand, attG, attB, B, c, wl[WL_OSD]);
+    }
     STAGE("osd");
     k_osd<<<ladder_grid(B * MAXC * 10), 64, 0, s>>>(0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials,
                                                     osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd, wl[WL_OSD]);
@@ -493,6 +503,7 @@ int ft8rx_enqueue_batch_host(ft8rx_handle* h, const int16_t* audio, int B) {
 }
 
 int ft8rx_set_streams(ft8rx_handle* h, int n) { if (!h || n < 1 || n > 8) return -1; h->n_streams = n; return 0; }
+int ft8rx_set_ladder_mode(ft8rx_handle* h, int mode) { if (!h || mode < 0 || mode > 1) return -1; h->ladder_mode = mode; return 0; }
 
 int ft8rx_sync(ft8rx_handle* h) {
     if (!h) return -1;

@@ -201,6 +201,8 @@ __global__ void k_worklist_att(const ft8rx_record* rec, const int32_t* ncand, co
 // Fine-stage ladder (receiver.py:84-98), order: GOOD91 ap 0, ap 1 (ipass 2); BP_A ap 0, ap 1 (ipass 3: the BP_B run of that variant
 // if it would also have succeeded under BP_A's limits); BP_B ap 0..4 (ipass 4).  step 0 runs after {GOOD91 x 2, BP ap 0}, step 1
 // after {BP ap 1}, step 2 after {BP ap 2,3,4}; a step decides what the attempts so far can decide and passes the rest on.
+// step 3 = the whole ladder at once, after a single launch of all five variants (small batches: three dependent launches of up
+// to 20 iterations each triple the latency of this stage when there are too few attempts to fill the GPU anyway).
 FT8_DEV bool sel_take(ft8rx_record& r, const Att& a, int ipass, int ap, int method) {
     r.status = FT8RX_ST_DECODED; r.ipass = (uint8_t)ipass; r.ap = (uint8_t)ap; r.method = (uint8_t)method; r.n_its = a.n_its; r.msg_lo = a.lo; r.msg_hi = a.hi;
     return false;
@@ -215,15 +217,22 @@ __global__ void k_select1(int step, ft8rx_record* rec, const int32_t* ncand, con
 #define IS_A(a) ((a).ok && (a).nc0 <= cfg.bp_nc0_a && (a).n_its < cfg.bp_iters_a)
         if (step == 0) {
             const Att& g0 = attG[(size_t)c * 2], & g1 = attG[(size_t)c * 2 + 1];
-            if (g0.ok) { Att a = g0; a.n_its = 0; go_on = sel_take(r, a, 2, 0, FT8RX_M_GOOD91); }
-            else if (g1.ok) { Att a = g1; a.n_its = 0; go_on = sel_take(r, a, 2, 1, FT8RX_M_GOOD91); }
+            if (g0.ok) go_on = sel_take(r, g0, 2, 0, FT8RX_M_GOOD91);
+            else if (g1.ok) go_on = sel_take(r, g1, 2, 1, FT8RX_M_GOOD91);
             else if (IS_A(b[0])) go_on = sel_take(r, b[0], 3, 0, FT8RX_M_LDPC_A);
         } else if (step == 1) {
             if (IS_A(b[1])) go_on = sel_take(r, b[1], 3, 1, FT8RX_M_LDPC_A);
             else if (b[0].ok) go_on = sel_take(r, b[0], 4, 0, FT8RX_M_LDPC_B);
             else if (b[1].ok) go_on = sel_take(r, b[1], 4, 1, FT8RX_M_LDPC_B);
-        } else {
+        } else if (step == 2) {
             for (int ap = 2; ap < 5 && go_on; ap++) if (b[ap].ok) go_on = sel_take(r, b[ap], 4, ap, FT8RX_M_LDPC_B);
+        } else {                                                    // step 3: all five variants ran in one launch (small batches)
+            const Att& g0 = attG[(size_t)c * 2], & g1 = attG[(size_t)c * 2 + 1];
+            if (g0.ok) go_on = sel_take(r, g0, 2, 0, FT8RX_M_GOOD91);
+            else if (g1.ok) go_on = sel_take(r, g1, 2, 1, FT8RX_M_GOOD91);
+            else if (IS_A(b[0])) go_on = sel_take(r, b[0], 3, 0, FT8RX_M_LDPC_A);
+            else if (IS_A(b[1])) go_on = sel_take(r, b[1], 3, 1, FT8RX_M_LDPC_A);
+            else for (int ap = 0; ap < 5 && go_on; ap++) if (b[ap].ok) go_on = sel_take(r, b[ap], 4, ap, FT8RX_M_LDPC_B);
         }
 #undef IS_A
     }

@@ -869,6 +869,38 @@ def test_repeatable_across_runs_and_stream_counts(ocfg):
             assert rec[f][:cnt[f]].tobytes() == outs[0][0][f][:cnt[f]].tobytes()
 
 
+def test_ladder_modes_give_the_same_records_and_messages():
+    """ft8rx_set_ladder_mode: fine-stage BP in ladder order (three launches, default) vs all five AP variants in one launch --
+    identical records and rendered messages; the one-launch event log is a superset (attempts the ladder would not have reached)."""
+    from pyft8_amd import _lib, synth, messages as M
+    audio = synth.make_batch(515000, 24)
+    res = []
+    for mode in (0, 1):
+        h = _lib.Handle(max_frames=24)
+        h.set_ladder_mode(mode)
+        rec, cnt, ev, evc = h.decode_batch(audio)
+        msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc)
+        py = [[" ".join(m["msg_tuple"]) for m in M.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]))] for f in range(4)]
+        res.append((rec.copy(), cnt.copy(), msgs.copy(), mcnt.copy(), py,
+                    [set(map(tuple, ev[f, :min(int(evc[f]), _lib.EVENT_CAP)].tolist())) for f in range(24)]))
+        h.close()
+    a, b = res
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and a[4] == b[4]
+    n_extra = 0
+    for f in range(24):
+        assert a[0][f][:a[1][f]].tobytes() == b[0][f][:b[1][f]].tobytes()
+        assert a[2][f][:a[3][f]].tobytes() == b[2][f][:b[3][f]].tobytes()
+        assert a[5][f] <= b[5][f]
+        n_extra += len(b[5][f] - a[5][f])
+    assert int(a[3].sum()) > 100
+    with pytest.raises(_lib.Ft8rxError):
+        h2 = _lib.Handle(max_frames=1)
+        try:
+            h2.set_ladder_mode(2)
+        finally:
+            h2.close()
+
+
 def test_full_size_batch_properties():
     """BASELINE config-2 size (4096 frames in one batch), checked through size-independent properties:
     batch-size independence (a frame decodes the same inside a 4096-frame batch as in a 64-frame one), independence of the
