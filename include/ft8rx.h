@@ -21,8 +21,20 @@ extern "C" {
 
 #define FT8RX_NSAMP      180000   /* 15 s @ 12 kHz, int16 mono (receiver.py:9-12,241) */
 #define FT8RX_GRID_ROWS  376      /* row 0 = never-written 1.0 row, rows 1..375 = hops (receiver.py:237-240) */
-#define FT8RX_GRID_COLS  976      /* receiver.py:240 */
+/* The spectrogram and cycle-spectrum layouts are compile-time widths.  The library is built twice from the same source:
+ *   libft8rx.so       search_freq_range up to 3000 Hz, the reference's default (receiver.py:312): f0_hi <= 960
+ *   libft8rx_wide.so  (-DFT8RX_WIDE) search_freq_range up to 5900 Hz: f0_hi <= 1888 -- twice the grid / spectrum memory per frame
+ * Same ABI; ft8rx_build_info() tells which one is loaded.  (The reference allocates f0_hi + 16 grid columns, receiver.py:240, and
+ * fails beyond ~5940 Hz, where the fine-sync slice runs off the 96001-bin cycle spectrum, receiver.py:181-182.) */
+#ifdef FT8RX_WIDE
+#define FT8RX_GRID_COLS  1920     /* bins 0..1919 of the 3840-point real FFT */
+#define FT8RX_SPEC_BINS  96000    /* bins 0..95999 of the 192000-point real FFT */
+#define FT8RX_MAX_F0     1888
+#else
+#define FT8RX_GRID_COLS  976      /* receiver.py:240 at the default range: 960 + 16 */
 #define FT8RX_SPEC_BINS  49152    /* kept bins of the 192000-point cycle spectrum (receiver.py:280-286) */
+#define FT8RX_MAX_F0     960
+#endif
 #define FT8RX_MAX_CANDS  256      /* upper bound for config.max_cands */
 #define FT8RX_EVENT_CAP  512      /* per-frame capacity of the CRC-pass event log */
 
@@ -92,6 +104,9 @@ int  ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_han
 void ft8rx_destroy(ft8rx_handle* h);
 const char* ft8rx_last_error(ft8rx_handle* h);                      /* h may be NULL: last create error */
 int  ft8rx_device_count(void);
+/* the compile-time widths of the loaded library (FT8RX_GRID_COLS, FT8RX_SPEC_BINS, FT8RX_MAX_F0): 976 / 49152 / 960, or
+ * 1920 / 96000 / 1888 for the wide build */
+int  ft8rx_build_info(int32_t* grid_cols, int32_t* spec_bins, int32_t* max_f0);
 /* FFT radix plans the kernels use (0-terminated, <= 8 entries each): 1920, 3200, 300, 320 point */
 int  ft8rx_get_fft_plans(int32_t* p1920, int32_t* p3200, int32_t* p300, int32_t* p320);
 
@@ -141,17 +156,17 @@ int  ft8rx_set_profiling(ft8rx_handle* h, int on);
 int  ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms);
 
 /* ---- stage entry points (parity tests; each mirrors one reference function) ---------------- */
-/* AudioIn.get_hop_spectrum x375 (receiver.py:288-293): grid [n][376][976] */
+/* AudioIn.get_hop_spectrum x375 (receiver.py:288-293): grid [n][376][FT8RX_GRID_COLS] */
 int  ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int n_frames, float* grid);
-/* streaming mode: ONE call of AudioIn.get_hop_spectrum (receiver.py:288-293): the last 3840 int16 samples -> 976 dB values */
-int  ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row976);
+/* streaming mode: ONE call of AudioIn.get_hop_spectrum (receiver.py:288-293): the last 3840 int16 samples -> FT8RX_GRID_COLS dB values */
+int  ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row);
 /* Receiver.search (receiver.py:338-367): per frame <= max_cands (f0,h0,score), sorted */
 int  ft8rx_sync_search(ft8rx_handle* h, const float* grid, int n_frames,
                        int32_t* f0_idx, int32_t* h0_idx, float* score, int32_t* counts);
 /* Candidate._get_llr_grid/_dB_to_llr (receiver.py:136-138, 208-222) for n (frame,f0,h0) triples */
 int  ft8rx_llr_grid(ft8rx_handle* h, const float* grid, int n_frames, int n, const int32_t* frame,
                     const int32_t* f0_idx, const int32_t* h0_idx, float* llr /*[n][174]*/, float* sd, int32_t* snr);
-/* AudioIn.get_cycle_spectrum (receiver.py:280-286): spec [n][49152] complex64 (bins 0..49151) */
+/* AudioIn.get_cycle_spectrum (receiver.py:280-286): spec [n][FT8RX_SPEC_BINS] complex64 */
 int  ft8rx_cycle_spectrum(ft8rx_handle* h, const int16_t* audio, int n_frames, float* spec);
 /* Candidate._get_llr_fine (receiver.py:140-206) for n (frame,f0,h0) triples; sgrid [n][79][8] may be NULL.
  * ret[i]: 1 continue, 0 Costas gate failed, -1 sd gate failed */

@@ -9,9 +9,16 @@ extern "C" {
 
 #define FT8O_NSAMP      180000
 #define FT8O_GRID_ROWS  376      /* row 0 is the never-written 1.0 row; rows 1..375 are hops */
+/* compile-time widths, as in include/ft8rx.h: the default build (search_freq_range up to 3000 Hz) and -DFT8O_WIDE (up to 5900 Hz) */
+#ifdef FT8O_WIDE
+#define FT8O_GRID_COLS  1920
+#define FT8O_SPEC_BINS  96000
+#define FT8O_MAX_F0     1888
+#else
 #define FT8O_GRID_COLS  976
 #define FT8O_SPEC_BINS  49152    /* cycle-spectrum bins kept (0.0625 Hz each) */
 #define FT8O_MAX_F0     960
+#endif
 
 /* Mirrors Receiver.__init__ kwargs (reference receiver.py:311-313) + decoder constants
  * (receiver.py:30,78,91,95; decoders.py:223).  Extension knobs are the same fields with

@@ -9,8 +9,10 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "libft8oracle.so")
+LIB_PATH_WIDE = os.path.join(HERE, "_build", "libft8oracle_wide.so")   # -DFT8O_WIDE: search_freq_range up to 5900 Hz (ft8_oracle.h)
 
 NSAMP, GRID_ROWS, GRID_COLS, SPEC_BINS = 180000, 376, 976, 49152
+GRID_COLS_WIDE, SPEC_BINS_WIDE, MAX_F0 = 1920, 96000, 960
 
 
 class Config(C.Structure):
@@ -42,30 +44,36 @@ class Msg(C.Structure):
 
 
 AP_NAMES = ["NoAP", "CQ", "RR73", "73", "RRR"]
-_lib = None
+_libs = {}
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB_PATH) or \
-            os.path.getmtime(LIB_PATH) < max(os.path.getmtime(os.path.join(HERE, f)) for f in ("ft8_oracle.c", "ft8_oracle.h", "ft8_tables.h")):
+    src = max(os.path.getmtime(os.path.join(HERE, f)) for f in ("ft8_oracle.c", "ft8_oracle.h", "ft8_tables.h"))
+    if force or any(not os.path.exists(p) or os.path.getmtime(p) < src for p in (LIB_PATH, LIB_PATH_WIDE)):
         subprocess.check_call(["make", "-s", "-C", HERE])
     return LIB_PATH
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(wide=False):
+    """The oracle library; wide=True -> the build with the wide layouts (same source, -DFT8O_WIDE).  The wrappers below pick the
+    variant from their arguments: a config with f0_hi > 960, a 1920-column grid or a 96000-bin spectrum mean the wide one."""
+    wide = bool(wide)
+    if wide not in _libs:
         build()
-        L = C.CDLL(LIB_PATH)
-        fp, ip, u64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)
+        L = C.CDLL(LIB_PATH_WIDE if wide else LIB_PATH)
         L.ft8o_log10f.restype = C.c_float; L.ft8o_log10f.argtypes = [C.c_float]
         L.ft8o_tanhf.restype = C.c_float; L.ft8o_tanhf.argtypes = [C.c_float]
         L.ft8o_unpack77.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         L.ft8o_valid77.argtypes = [C.c_uint64, C.c_uint64]
         L.ft8o_hash_new.restype = C.c_void_p
         L.ft8o_hash_free.argtypes = [C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[wide] = L
+    return _libs[wide]
+
+
+def _wide(cfg=None, grid=None, spec=None):
+    return (cfg is not None and cfg.f0_hi > MAX_F0) or (grid is not None and grid.shape[-1] == GRID_COLS_WIDE) or \
+        (spec is not None and spec.shape[-1] == SPEC_BINS_WIDE)
 
 
 def default_config(**kw):
@@ -108,21 +116,23 @@ def fft(x, plan):
 def spectrogram(audio, cfg=None):
     cfg = cfg or default_config()
     audio = np.ascontiguousarray(audio, np.int16)
-    g = np.empty((GRID_ROWS, GRID_COLS), np.float32)
-    lib().ft8o_spectrogram(_p(audio, C.c_int16), C.byref(cfg), _p(g))
+    g = np.empty((GRID_ROWS, GRID_COLS_WIDE if _wide(cfg) else GRID_COLS), np.float32)
+    lib(_wide(cfg)).ft8o_spectrogram(_p(audio, C.c_int16), C.byref(cfg), _p(g))
     return g
 
 
 def sync_search(grid, cfg=None):
     cfg = cfg or default_config()
-    out = (Cand * 1024)()
-    n = lib().ft8o_sync_search(_p(grid), C.byref(cfg), out)
+    grid = np.ascontiguousarray(grid, np.float32)
+    out = (Cand * 2048)()
+    n = lib(_wide(cfg, grid)).ft8o_sync_search(_p(grid), C.byref(cfg), out)
     return [out[i] for i in range(n)]
 
 
 def payload(grid, f0, h0):
+    grid = np.ascontiguousarray(grid, np.float32)
     p = np.empty((58, 8), np.float32)
-    lib().ft8o_payload(_p(grid), int(f0), int(h0), _p(p))
+    lib(_wide(grid=grid)).ft8o_payload(_p(grid), int(f0), int(h0), _p(p))
     return p
 
 
@@ -137,8 +147,8 @@ def db_to_llr(p):
 def cycle_spectrum(audio, cfg=None):
     cfg = cfg or default_config()
     audio = np.ascontiguousarray(audio, np.int16)
-    s = np.empty(SPEC_BINS, np.complex64)
-    lib().ft8o_cycle_spectrum(_p(audio, C.c_int16), C.byref(cfg), _p(s.view(np.float32)))
+    s = np.empty(SPEC_BINS_WIDE if _wide(cfg) else SPEC_BINS, np.complex64)
+    lib(_wide(cfg)).ft8o_cycle_spectrum(_p(audio, C.c_int16), C.byref(cfg), _p(s.view(np.float32)))
     return s
 
 
@@ -149,7 +159,7 @@ def fine(spec, f0, h0, cfg=None):
     sd = C.c_float()
     llr = np.zeros(174, np.float32)
     sg = np.zeros((79, 8), np.float32)
-    r = lib().ft8o_fine(_p(spec.view(np.float32)), C.byref(cfg), int(f0), int(h0), C.byref(tt), C.byref(ft), C.byref(ns),
+    r = lib(_wide(cfg, spec=spec)).ft8o_fine(_p(spec.view(np.float32)), C.byref(cfg), int(f0), int(h0), C.byref(tt), C.byref(ft), C.byref(ns),
                         _p(llr), C.byref(sd), C.byref(snr), _p(sg))
     return dict(ret=r, ttweak=tt.value, ftweak=ft.value, nsync=ns.value, llr=llr, sd=sd.value, snr=snr.value, sgrid=sg)
 
@@ -232,7 +242,7 @@ def decode_frame(audio, cfg=None):
     log = (Event * 4096)()
     msgs = (Msg * 256)()
     nc, nl, nm = C.c_int32(), C.c_int32(), C.c_int32()
-    lib().ft8o_decode_frame(_p(audio, C.c_int16), C.byref(cfg), cands, C.byref(nc), log, 4096, C.byref(nl), msgs, 256, C.byref(nm))
+    lib(_wide(cfg)).ft8o_decode_frame(_p(audio, C.c_int16), C.byref(cfg), cands, C.byref(nc), log, 4096, C.byref(nl), msgs, 256, C.byref(nm))
     out_msgs = []
     for i in range(min(nm.value, 256)):
         m = msgs[i]

@@ -9,6 +9,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FT8RX_LIB", os.path.join(HERE, "libft8rx.so"))   # FT8RX_LIB: A/B builds of the same ABI
+# the same source with the wide layouts (-DFT8RX_WIDE, include/ft8rx.h): search_freq_range up to 5900 Hz; loaded only when a config asks for it
+LIB_PATH_WIDE = os.environ.get("FT8RX_LIB_WIDE", os.path.join(HERE, "libft8rx_wide.so"))
 SRC = os.path.join(HERE, "csrc", "ft8rx.hip")
 # -fno-slp-vectorize: on gfx950 a v_pk_add/mul_f32 issues at exactly the cost of the two scalar ops it replaces (tools/ubench/valu_rate.hip,
 # profiles/r02_valu_rate.txt) while the packing costs ~1000 extra v_mov in k_fine: scalar code is 7 % faster there, bit-identical.
@@ -16,6 +18,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-Wno-unused-value", "-fPIC", "-shared"]
 
 NSAMP, GRID_ROWS, GRID_COLS, SPEC_BINS, MAX_CANDS, EVENT_CAP = 180000, 376, 976, 49152, 256, 512
+MAX_F0, GRID_COLS_WIDE, SPEC_BINS_WIDE, MAX_F0_WIDE = 960, 1920, 96000, 1888      # Handle.grid_cols / .spec_bins hold the loaded variant's
 
 
 class Config(C.Structure):
@@ -41,7 +44,7 @@ assert RECORD_DTYPE.itemsize == 48 and EVENT_DTYPE.itemsize == 24 and MESSAGE_DT
 ST_ACTIVE, ST_DECODED, ST_STOP_GRID_SD, ST_STOP_COSTAS, ST_STOP_FINE_SD, ST_EXHAUSTED = range(6)
 M_GOOD91, M_LDPC_A, M_LDPC_B, M_OSD, M_LDPC_B_OSD = range(5)
 
-_lib = None
+_libs = {}
 
 
 class Ft8rxError(RuntimeError):
@@ -49,23 +52,32 @@ class Ft8rxError(RuntimeError):
 
 
 def build(force=False, verbose=False):
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): libft8rx.so and libft8rx_wide.so."""
     deps = [os.path.join(os.path.dirname(HERE), "include", "ft8rx.h")]
     for d, _, files in os.walk(os.path.join(HERE, "csrc")):            # ft8rx.hip + ft8_dev.h, ft8_tables.h, kernels/*.hpp, host_messages.hpp
         deps += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".hpp"))]
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(d) for d in deps):
-        cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    newest = max(os.path.getmtime(d) for d in deps)
+    jobs = []
+    for path, extra in ((LIB_PATH, []), (LIB_PATH_WIDE, ["-DFT8RX_WIDE"])):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < newest:
+            cmd = ["hipcc"] + HIPCC_FLAGS + extra + ["-o", path, SRC]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, j in jobs:
+        if j.wait() != 0:
+            raise subprocess.CalledProcessError(j.returncode, cmd)
     return LIB_PATH
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise Ft8rxError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+def lib(wide=False):
+    """The loaded library; wide=True -> the build with the wide layouts (Handle picks it when cfg.f0_hi > 960).  The host-only entry
+    points (message layer, tone encoder, hash tables, defaults) are the same code in both and are always taken from the default one."""
+    wide = bool(wide)
+    if wide not in _libs:
+        path = LIB_PATH_WIDE if wide else LIB_PATH
+        if not os.path.exists(path):
+            raise Ft8rxError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(pyft8_amd has no CPU fallback)")
         # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; libft8rx.so links the system one (/opt/rocm, same soname).  The
         # copy loaded first serves both: this library runs on either, torch only on its own -- so if torch is already imported,
@@ -76,7 +88,7 @@ def lib():
                 sys.modules["torch"].cuda.is_available()
             except Exception:
                 pass
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         L.ft8rx_last_error.restype = C.c_char_p
         L.ft8rx_last_error.argtypes = [C.c_void_p]
         L.ft8rx_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -84,8 +96,13 @@ def lib():
         L.ft8rx_destroy.restype = None
         L.ft8rx_staging_audio.restype = C.c_void_p
         L.ft8rx_staging_audio.argtypes = [C.c_void_p]
-        _lib = L
-    return _lib
+        gc, sb, mf = C.c_int32(), C.c_int32(), C.c_int32()
+        L.ft8rx_build_info(C.byref(gc), C.byref(sb), C.byref(mf))
+        want = (GRID_COLS_WIDE, SPEC_BINS_WIDE, MAX_F0_WIDE) if wide else (GRID_COLS, SPEC_BINS, MAX_F0)
+        if (gc.value, sb.value, mf.value) != want:
+            raise Ft8rxError(f"{path} was built with layouts {(gc.value, sb.value, mf.value)}, expected {want}")
+        _libs[wide] = L
+    return _libs[wide]
 
 
 def default_config(**kw):
@@ -111,8 +128,10 @@ class Handle:
     """One HIP device + stream + preallocated workspaces for up to max_frames frames."""
 
     def __init__(self, cfg=None, device=0, max_frames=1):
-        L = lib()
         self.cfg = cfg or default_config()
+        self.wide = self.cfg.f0_hi > MAX_F0                 # search range beyond 3000 Hz: the wide build (include/ft8rx.h)
+        L = self._L = lib(self.wide)
+        self.grid_cols, self.spec_bins = (GRID_COLS_WIDE, SPEC_BINS_WIDE) if self.wide else (GRID_COLS, SPEC_BINS)
         self.max_frames = int(max_frames)
         self.device = int(device)
         self._h = C.c_void_p()
@@ -122,7 +141,7 @@ class Handle:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            lib().ft8rx_destroy(self._h)
+            self._L.ft8rx_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -133,7 +152,7 @@ class Handle:
 
     def _chk(self, rc, what):
         if rc != 0:
-            raise Ft8rxError(f"{what} failed ({rc}): {lib().ft8rx_last_error(self._h).decode()}")
+            raise Ft8rxError(f"{what} failed ({rc}): {self._L.ft8rx_last_error(self._h).decode()}")
 
     # ---- whole path
     def decode_batch(self, audio):
@@ -153,29 +172,29 @@ class Handle:
 
     def _run(self, audio, B):
         rec, cnt, ev, evc = self._alloc_out(B)
-        rc = lib().ft8rx_decode_batch(self._h, _ptr(audio, C.c_int16), B, rec.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32),
+        rc = self._L.ft8rx_decode_batch(self._h, _ptr(audio, C.c_int16), B, rec.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32),
                                       ev.ctypes.data_as(C.c_void_p), _ptr(evc, C.c_int32))
         self._chk(rc, "ft8rx_decode_batch")
         return rec, cnt, ev, evc
 
     def enqueue(self, d_audio_ptr, B):
-        self._chk(lib().ft8rx_enqueue_batch(self._h, C.c_void_p(d_audio_ptr), int(B)), "ft8rx_enqueue_batch")
+        self._chk(self._L.ft8rx_enqueue_batch(self._h, C.c_void_p(d_audio_ptr), int(B)), "ft8rx_enqueue_batch")
 
     def enqueue_host(self, audio):
         """Asynchronous decode of host audio (int16 [B, 180000], ideally from pinned_audio()): ft8rx_enqueue_batch_host.  The array
         must stay alive and unchanged until the batch has been fetched."""
         if audio.dtype != np.int16 or audio.ndim != 2 or audio.shape[1] != NSAMP or not audio.flags["C_CONTIGUOUS"]:
             raise Ft8rxError(f"enqueue_host: audio must be a C-contiguous int16 [n_frames, {NSAMP}] array")
-        L = lib()
+        L = self._L
         L.ft8rx_enqueue_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         self._chk(L.ft8rx_enqueue_batch_host(self._h, audio.ctypes.data_as(C.c_void_p), int(audio.shape[0])), "ft8rx_enqueue_batch_host")
 
     def sync(self):
-        self._chk(lib().ft8rx_sync(self._h), "ft8rx_sync")
+        self._chk(self._L.ft8rx_sync(self._h), "ft8rx_sync")
 
     def fetch(self, B):
         rec, cnt, ev, evc = self._alloc_out(B)
-        rc = lib().ft8rx_fetch_results(self._h, int(B), rec.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32),
+        rc = self._L.ft8rx_fetch_results(self._h, int(B), rec.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32),
                                        ev.ctypes.data_as(C.c_void_p), _ptr(evc, C.c_int32))
         self._chk(rc, "ft8rx_fetch_results")
         return rec, cnt, ev, evc
@@ -185,7 +204,7 @@ class Handle:
         Valid until two more batches have been enqueued."""
         B = int(B)
         p = [C.c_void_p() for _ in range(4)]
-        L = lib()
+        L = self._L
         L.ft8rx_fetch_results_view.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4
         self._chk(L.ft8rx_fetch_results_view(self._h, B, *[C.byref(x) for x in p]), "ft8rx_fetch_results_view")
         mc = self.cfg.max_cands
@@ -197,26 +216,26 @@ class Handle:
 
     def results_to_device(self, B, d_rec, d_cnt, d_ev, d_evc):
         """Latest batch's results -> caller-owned device buffers (raw device pointers; ft8rx_results_to_device)."""
-        L = lib()
+        L = self._L
         L.ft8rx_results_to_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
         self._chk(L.ft8rx_results_to_device(self._h, int(B), C.c_void_p(d_rec), C.c_void_p(d_cnt), C.c_void_p(d_ev), C.c_void_p(d_evc)),
                   "ft8rx_results_to_device")
 
     def set_streams(self, n):
-        self._chk(lib().ft8rx_set_streams(self._h, int(n)), "ft8rx_set_streams")
+        self._chk(self._L.ft8rx_set_streams(self._h, int(n)), "ft8rx_set_streams")
 
     def set_ladder_mode(self, mode):
         """0 (default) = fine-stage BP in ladder order, three launches (throughput); 1 = one launch for the five AP variants (latency)."""
-        self._chk(lib().ft8rx_set_ladder_mode(self._h, int(mode)), "ft8rx_set_ladder_mode")
+        self._chk(self._L.ft8rx_set_ladder_mode(self._h, int(mode)), "ft8rx_set_ladder_mode")
 
     def set_profiling(self, on):
-        lib().ft8rx_set_profiling(self._h, int(bool(on)))
+        self._L.ft8rx_set_profiling(self._h, int(bool(on)))
 
     def stage_times(self):
         n = C.c_int()
         names = (C.c_char_p * 24)()
         ms = (C.c_float * 24)()
-        lib().ft8rx_get_stage_times(self._h, C.byref(n), names, ms)
+        self._L.ft8rx_get_stage_times(self._h, C.byref(n), names, ms)
         return {names[i].decode(): ms[i] for i in range(n.value)}
 
     # ---- stage entry points
@@ -225,36 +244,40 @@ class Handle:
         if audio.ndim == 1:
             audio = audio[None]
         B = audio.shape[0]
-        g = np.empty((B, GRID_ROWS, GRID_COLS), np.float32)
-        self._chk(lib().ft8rx_spectrogram(self._h, _ptr(audio, C.c_int16), B, _ptr(g, C.c_float)), "ft8rx_spectrogram")
+        g = np.empty((B, GRID_ROWS, self.grid_cols), np.float32)
+        self._chk(self._L.ft8rx_spectrogram(self._h, _ptr(audio, C.c_int16), B, _ptr(g, C.c_float)), "ft8rx_spectrogram")
         return g
 
     def hop_spectrum(self, window3840):
         w = np.ascontiguousarray(window3840, np.int16)
         if w.shape != (3840,):
             raise Ft8rxError(f"hop_spectrum needs the last 3840 samples, got shape {w.shape}")
-        row = np.empty(GRID_COLS, np.float32)
-        self._chk(lib().ft8rx_hop_spectrum(self._h, _ptr(w, C.c_int16), _ptr(row, C.c_float)), "ft8rx_hop_spectrum")
+        row = np.empty(self.grid_cols, np.float32)
+        self._chk(self._L.ft8rx_hop_spectrum(self._h, _ptr(w, C.c_int16), _ptr(row, C.c_float)), "ft8rx_hop_spectrum")
         return row
 
-    def sync_search(self, grid):
+    def _grid(self, grid):
         grid = np.ascontiguousarray(grid, np.float32)
         if grid.ndim == 2:
             grid = grid[None]
+        if grid.shape[1:] != (GRID_ROWS, self.grid_cols):
+            raise Ft8rxError(f"grid must be [n][{GRID_ROWS}][{self.grid_cols}] for this handle, got {grid.shape}")
+        return grid
+
+    def sync_search(self, grid):
+        grid = self._grid(grid)
         B, mc = grid.shape[0], self.cfg.max_cands
         f0 = np.zeros((B, mc), np.int32); h0 = np.zeros((B, mc), np.int32); sc = np.zeros((B, mc), np.float32); cnt = np.zeros(B, np.int32)
-        self._chk(lib().ft8rx_sync_search(self._h, _ptr(grid, C.c_float), B, _ptr(f0, C.c_int32), _ptr(h0, C.c_int32),
+        self._chk(self._L.ft8rx_sync_search(self._h, _ptr(grid, C.c_float), B, _ptr(f0, C.c_int32), _ptr(h0, C.c_int32),
                                           _ptr(sc, C.c_float), _ptr(cnt, C.c_int32)), "ft8rx_sync_search")
         return f0, h0, sc, cnt
 
     def llr_grid(self, grid, frame, f0, h0):
-        grid = np.ascontiguousarray(grid, np.float32)
-        if grid.ndim == 2:
-            grid = grid[None]
+        grid = self._grid(grid)
         frame, f0, h0 = (np.ascontiguousarray(x, np.int32) for x in (frame, f0, h0))
         n = len(f0)
         llr = np.zeros((n, 174), np.float32); sd = np.zeros(n, np.float32); snr = np.zeros(n, np.int32)
-        self._chk(lib().ft8rx_llr_grid(self._h, _ptr(grid, C.c_float), grid.shape[0], n, _ptr(frame, C.c_int32), _ptr(f0, C.c_int32),
+        self._chk(self._L.ft8rx_llr_grid(self._h, _ptr(grid, C.c_float), grid.shape[0], n, _ptr(frame, C.c_int32), _ptr(f0, C.c_int32),
                                        _ptr(h0, C.c_int32), _ptr(llr, C.c_float), _ptr(sd, C.c_float), _ptr(snr, C.c_int32)), "ft8rx_llr_grid")
         return llr, sd, snr
 
@@ -263,20 +286,22 @@ class Handle:
         if audio.ndim == 1:
             audio = audio[None]
         B = audio.shape[0]
-        s = np.empty((B, SPEC_BINS), np.complex64)
-        self._chk(lib().ft8rx_cycle_spectrum(self._h, _ptr(audio, C.c_int16), B, s.ctypes.data_as(C.POINTER(C.c_float))), "ft8rx_cycle_spectrum")
+        s = np.empty((B, self.spec_bins), np.complex64)
+        self._chk(self._L.ft8rx_cycle_spectrum(self._h, _ptr(audio, C.c_int16), B, s.ctypes.data_as(C.POINTER(C.c_float))), "ft8rx_cycle_spectrum")
         return s
 
     def fine(self, spec, frame, f0, h0, want_sgrid=False):
         spec = np.ascontiguousarray(spec, np.complex64)
         if spec.ndim == 1:
             spec = spec[None]
+        if spec.shape[1] != self.spec_bins:
+            raise Ft8rxError(f"spectrum must be [n][{self.spec_bins}] for this handle, got {spec.shape}")
         frame, f0, h0 = (np.ascontiguousarray(x, np.int32) for x in (frame, f0, h0))
         n = len(f0)
         ret, tt, ft, ns, snr = (np.zeros(n, np.int32) for _ in range(5))
         llr = np.zeros((n, 174), np.float32); sd = np.zeros(n, np.float32)
         sg = np.zeros((n, 79, 8), np.float32) if want_sgrid else None
-        self._chk(lib().ft8rx_fine(self._h, spec.ctypes.data_as(C.POINTER(C.c_float)), spec.shape[0], n, _ptr(frame, C.c_int32),
+        self._chk(self._L.ft8rx_fine(self._h, spec.ctypes.data_as(C.POINTER(C.c_float)), spec.shape[0], n, _ptr(frame, C.c_int32),
                                    _ptr(f0, C.c_int32), _ptr(h0, C.c_int32), _ptr(ret, C.c_int32), _ptr(tt, C.c_int32), _ptr(ft, C.c_int32),
                                    _ptr(ns, C.c_int32), _ptr(llr, C.c_float), _ptr(sd, C.c_float), _ptr(snr, C.c_int32),
                                    _ptr(sg, C.c_float) if want_sgrid else None), "ft8rx_fine")
@@ -288,7 +313,7 @@ class Handle:
         ok, nits, has = (np.zeros(n, np.int32) for _ in range(3))
         lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
         out = np.zeros((n, 174), np.float32)
-        self._chk(lib().ft8rx_ldpc(self._h, _ptr(llr, C.c_float), n, int(max_ncheck0), int(max_iters), _ptr(ok, C.c_int32),
+        self._chk(self._L.ft8rx_ldpc(self._h, _ptr(llr, C.c_float), n, int(max_ncheck0), int(max_iters), _ptr(ok, C.c_int32),
                                    _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), _ptr(nits, C.c_int32), _ptr(has, C.c_int32),
                                    _ptr(out, C.c_float)), "ft8rx_ldpc")
         return ok, lo, hi, nits, has, out
@@ -298,7 +323,7 @@ class Handle:
         n = len(llr)
         ok, trial, hd = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
         lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
-        self._chk(lib().ft8rx_osd_ext(self._h, _ptr(llr, C.c_float), n, int(singleflips), int(doubleflips), int(tripleflips), int(max_hd),
+        self._chk(self._L.ft8rx_osd_ext(self._h, _ptr(llr, C.c_float), n, int(singleflips), int(doubleflips), int(tripleflips), int(max_hd),
                                       _ptr(ok, C.c_int32), _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), _ptr(trial, C.c_int32),
                                       _ptr(hd, C.c_int32)), "ft8rx_osd_ext")
         return (ok, lo, hi, trial, hd) if want_hd else (ok, lo, hi, trial)
@@ -307,14 +332,14 @@ class Handle:
         cw91 = np.ascontiguousarray(cw91, np.float32).reshape(-1, 91)
         n = len(cw91)
         res = np.zeros(n, np.int32); lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
-        self._chk(lib().ft8rx_crc_valid(self._h, _ptr(cw91, C.c_float), n, _ptr(res, C.c_int32), _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64)), "ft8rx_crc_valid")
+        self._chk(self._L.ft8rx_crc_valid(self._h, _ptr(cw91, C.c_float), n, _ptr(res, C.c_int32), _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64)), "ft8rx_crc_valid")
         return res, lo, hi
 
     def valid77(self, bits):
         lo = np.array([b & (2 ** 64 - 1) for b in bits], np.uint64)
         hi = np.array([b >> 64 for b in bits], np.uint64)
         out = np.zeros(len(lo), np.int32)
-        self._chk(lib().ft8rx_valid77(self._h, _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), len(lo), _ptr(out, C.c_int32)), "ft8rx_valid77")
+        self._chk(self._L.ft8rx_valid77(self._h, _ptr(lo, C.c_uint64), _ptr(hi, C.c_uint64), len(lo), _ptr(out, C.c_int32)), "ft8rx_valid77")
         return out
 
     def subtract(self, d_audio_ptr, n_frames, signals, return_float=False, refine=False, return_origins=False):
@@ -336,7 +361,7 @@ class Handle:
                     arr[f, i]["tones"] = np.asarray(tones, np.uint8)
                     arr[f, i]["fHz"], arr[f, i]["tsec"] = fHz, tsec
         out = np.empty((B, NSAMP), np.float32) if return_float else None
-        L = lib()
+        L = self._L
         L.ft8rx_subtract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         self._chk(L.ft8rx_subtract(self._h, C.c_void_p(d_audio_ptr), B, arr.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32), ms,
                                    int(bool(refine)), out.ctypes.data_as(C.c_void_p) if return_float else None), "ft8rx_subtract")
@@ -347,7 +372,7 @@ class Handle:
     def pinned_audio(self, n_frames):
         """int16 [n_frames, 180000] array in page-locked host memory (ft8rx_alloc_host): fill it and pass it to decode_batch for
         overlapped DMA.  The memory is released when the array (and every view of it) is garbage collected."""
-        L = lib()
+        L = self._L
         L.ft8rx_alloc_host.restype = C.c_void_p
         L.ft8rx_alloc_host.argtypes = [C.c_void_p, C.c_uint64]
         L.ft8rx_free_host.argtypes = [C.c_void_p, C.c_void_p]
@@ -361,11 +386,11 @@ class Handle:
         return arr
 
     def staging_ptr(self):
-        return int(lib().ft8rx_staging_audio(self._h))
+        return int(self._L.ft8rx_staging_audio(self._h))
 
     def download_audio(self, d_ptr, n_frames):
         out = np.empty((n_frames, NSAMP), np.int16)
-        self._chk(lib().ft8rx_copy_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr), C.c_uint64(out.nbytes)), "ft8rx_copy_to_host")
+        self._chk(self._L.ft8rx_copy_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr), C.c_uint64(out.nbytes)), "ft8rx_copy_to_host")
         return out
 
     def synth_frames(self, d_audio_ptr, start, count, n_signals=50, snr_range=(-10.0, 10.0), seed=0x4654385F53594E54, noise=True,
@@ -376,7 +401,7 @@ class Handle:
         recs, truth = synth.device_signal_table(start, count, n_signals, snr_range)
         assert recs.dtype.itemsize == synth.SIGNAL_DTYPE.itemsize
         q = np.ascontiguousarray(synth.pulse_cumsum(), np.float64)
-        self._chk(lib().ft8rx_synth_frames_ex(self._h, C.c_uint64(seed), int(start), int(count), int(n_signals),
+        self._chk(self._L.ft8rx_synth_frames_ex(self._h, C.c_uint64(seed), int(start), int(count), int(n_signals),
                                               recs.ctypes.data_as(C.c_void_p), int(recs.dtype.itemsize), _ptr(q, C.c_double),
                                               C.c_void_p(d_audio_ptr), int(not noise)), "ft8rx_synth_frames")
         return (truth, recs) if return_table else truth
@@ -385,11 +410,11 @@ class Handle:
         if which == 2:
             x = np.ascontiguousarray(x, np.complex64)
             y = np.empty_like(x)
-            self._chk(lib().ft8rx_math_probe(self._h, 2, x.ctypes.data_as(C.POINTER(C.c_float)), len(x), y.ctypes.data_as(C.POINTER(C.c_float))), "ft8rx_math_probe")
+            self._chk(self._L.ft8rx_math_probe(self._h, 2, x.ctypes.data_as(C.POINTER(C.c_float)), len(x), y.ctypes.data_as(C.POINTER(C.c_float))), "ft8rx_math_probe")
             return y
         x = np.ascontiguousarray(x, np.float32)
         y = np.empty_like(x)
-        self._chk(lib().ft8rx_math_probe(self._h, int(which), _ptr(x, C.c_float), x.size, _ptr(y, C.c_float)), "ft8rx_math_probe")
+        self._chk(self._L.ft8rx_math_probe(self._h, int(which), _ptr(x, C.c_float), x.size, _ptr(y, C.c_float)), "ft8rx_math_probe")
         return y
 
 

@@ -30,7 +30,7 @@
 #include "ft8_dev.h"
 
 #define MAXC FT8RX_MAX_CANDS
-#define NF0MAX 1024
+#define NF0MAX (FT8RX_MAX_F0 > 1024 ? 2048 : 1024)     /* per-frame stride of the per-f0 sync results; k_topk sorts this many keys */
 
 // The kernels live in one file per stage; this file is the C ABI, the handle and the launch chains.
 #include "kernels/common.hpp"
@@ -170,6 +170,13 @@ int ft8rx_default_config(ft8rx_config* c) {
 }
 
 int ft8rx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int ft8rx_build_info(int32_t* grid_cols, int32_t* spec_bins, int32_t* max_f0) {
+    static_assert(NF0MAX >= FT8RX_GRID_COLS && NF0MAX >= FT8RX_MAX_F0, "per-f0 scratch stride");
+    if (grid_cols) *grid_cols = FT8RX_GRID_COLS;
+    if (spec_bins) *spec_bins = FT8RX_SPEC_BINS;
+    if (max_f0) *max_f0 = FT8RX_MAX_F0;
+    return 0;
+}
 
 int ft8rx_get_fft_plans(int32_t* p1920, int32_t* p3200, int32_t* p300, int32_t* p320) {
     const int32_t a[8] = {8, 4, 4, 5, 3, 0, 0, 0}, b[8] = {8, 4, 4, 5, 5, 0, 0, 0}, c[8] = {5, 5, 4, 3, 0, 0, 0, 0}, d[8] = {8, 8, 5, 0, 0, 0, 0, 0};
@@ -207,7 +214,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
 
 int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_handle** out) {
     if (!cfg || !out || max_frames < 1) { set_err(nullptr, "ft8rx_create: bad arguments"); return -1; }
-    if (cfg->max_cands < 1 || cfg->max_cands > MAXC || cfg->f0_lo < 4 || cfg->f0_hi > 960 || cfg->f0_lo >= cfg->f0_hi ||
+    if (cfg->max_cands < 1 || cfg->max_cands > MAXC || cfg->f0_lo < 4 || cfg->f0_hi > FT8RX_MAX_F0 || cfg->f0_lo >= cfg->f0_hi ||
         cfg->h0_hi <= cfg->h0_lo || cfg->h0_hi - cfg->h0_lo > 352 || cfg->bp_nc0_a > cfg->bp_nc0_b || cfg->bp_iters_a > cfg->bp_iters_b ||
         cfg->osd_single < 0 || cfg->osd_single > OSD_MAXFLIP || cfg->osd_double < 0 || cfg->osd_double > OSD_MAXFLIP ||
         cfg->osd_triple < 0 || cfg->osd_triple > 40 || cfg->osd_max_hd < 0 || cfg->osd_max_hd > 174 ||
@@ -266,7 +273,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     rc |= upload(h, &h->T.win, win);
     rc |= upload(h, &h->T.taper, taper);
     host_twiddle(1920, 1920, w);   rc |= upload(h, &h->T.W1920, w);
-    host_twiddle(3840, 976, w);    rc |= upload(h, &h->T.WR3840, w);
+    host_twiddle(3840, FT8RX_GRID_COLS, w);    rc |= upload(h, &h->T.WR3840, w);
     host_twiddle(3200, 3200, w);   rc |= upload(h, &h->T.W3200, w);
     host_twiddle(96000, 96000, w); rc |= upload(h, &h->T.W96000, w);
     host_twiddle(300, 300, w);     rc |= upload(h, &h->T.W300, w);
@@ -589,13 +596,13 @@ int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid)
     return 0;
 }
 
-int ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row976) {
-    if (!h || !window3840 || !row976) return -1;
+int ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row) {
+    if (!h || !window3840 || !row) return -1;
     HIPCHK(h, hipSetDevice(h->device));
-    float* d_row = h->d_best_score;                      // any 976-float scratch: not in use between batches
+    float* d_row = h->d_best_score;                      // any scratch of FT8RX_GRID_COLS floats (NF0MAX >= that): not in use between batches
     HIPCHK(h, hipMemcpyAsync(h->d_audio, window3840, sizeof(int16_t) * 3840, hipMemcpyHostToDevice, h->stream));
     k_hop_spectrum<<<1, SPEC_NT, 0, h->stream>>>(h->d_audio, d_row, h->T);
-    HIPCHK(h, hipMemcpyAsync(row976, d_row, sizeof(float) * FT8RX_GRID_COLS, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(row, d_row, sizeof(float) * FT8RX_GRID_COLS, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }

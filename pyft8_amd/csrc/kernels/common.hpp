@@ -7,12 +7,12 @@
 struct Tables {
     const float* win;        // [3840] Hann (np.hanning) as f32
     const cpx* W1920;        // twiddles
-    const cpx* WR3840;       // [976] real-split twiddles e^{-2 pi i k/3840}
+    const cpx* WR3840;       // [FT8RX_GRID_COLS] real-split twiddles e^{-2 pi i k/3840}
     const cpx* W3200;
     const cpx* W96000;
     const cpx* W300;
     const cpx* W320;
-    const cpx* WR192k;       // [49152]
+    const cpx* WR192k;       // [FT8RX_SPEC_BINS]
     const cpx* W32;
     const double* taper;     // [100]
 };

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_cyc_a(const int16_t* __restrict__ audio
 // therefore transforms 4 adjacent rows k1 .. k1+3 TOGETHER WITH their partner rows 297-k1 .. 300-k1 and forms the spectrum bins of
 // all eight rows from LDS -- the 96000-point intermediate Z never goes to HBM (r01: 197 MB written + 201 MB read per 256 frames).
 // Blocks 0..37: k1 = 1 + 4 b (rows 1..152 and 148..299; the rows 148..152 are produced twice, identically); block 38: the
-// self-paired rows 0 (partner bin 300 (320 - k2)) and 150.  Only bins < 49152 are kept (k2 < 164).
+// self-paired rows 0 (partner bin 300 (320 - k2)) and 150.  Only bins < FT8RX_SPEC_BINS are kept (k2 < 164; all 320 in the wide build).
 // XCD-aware tile map as in k_cyc_a (gridDim.x = 40 = 8 XCDs x 5, workgroup id % 8 = XCD): one XCD takes five adjacent row
 // blocks = 20 adjacent rows, so the 32-byte output runs of neighbouring blocks (bin k = row + 300 k2) meet in ONE L2 and leave it
 // as whole lines; with the plain map the partial lines went out from four L2s (WRITE_SIZE 156 MB for 101 MB of spectrum).
@@ -64,9 +64,11 @@ __global__ __launch_bounds__(256) void k_cyc_bc(const cpx* __restrict__ A, cpx* 
     __syncthreads();
     cpx* z = lds_fft<320, 8, 8, 5>(bufA, bufB, T.W320, 8, tid, 256);
     cpx* out = spec + (size_t)f * FT8RX_SPEC_BINS;
-    // outputs: slot r, k2 < 164 -> bin k = row + 300 k2; adjacent threads take adjacent rows (32-byte runs in memory)
-    for (int i = tid; i < 8 * 164; i += 256) {
-        const int half = i / (4 * 164), j = i - half * (4 * 164), rr = j & 3, k2 = j >> 2;
+    // outputs: slot r, k2 < NK2 -> bin k = row + 300 k2; adjacent threads take adjacent rows (32-byte runs in memory)
+    constexpr int NK2 = (FT8RX_SPEC_BINS + 299) / 300;                          // 164 (bins < 49152), 320 in the wide build
+    static_assert(NK2 <= 320, "k2 range of the 320-point row transforms");
+    for (int i = tid; i < 8 * NK2; i += 256) {
+        const int half = i / (4 * NK2), j = i - half * (4 * NK2), rr = j & 3, k2 = j >> 2;
         const int r = 4 * half + rr;
         int row, pr, pk2;                                                       // this row, partner slot, partner k2
         if (special) {

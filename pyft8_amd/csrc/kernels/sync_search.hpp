@@ -70,32 +70,49 @@ __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, fl
 }
 
 // ------------------------------------------------------------------------------------ K3 top-K
-// threshold, stable sort by score descending (ties: f0 ascending = original order), keep max_cands
+// threshold, stable sort by score descending (ties: f0 ascending = original order), keep max_cands.
+// NF0MAX keys (1024; 2048 in the wide build) on 1024 threads: bitonic network in LDS, KPT compare-exchanges per thread and step.
 __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ best_score, const int32_t* __restrict__ best_h0,
                                                ft8rx_record* __restrict__ rec, int32_t* __restrict__ ncand, ft8rx_config cfg) {
-    __shared__ uint64_t key[1024];
+    constexpr int KPT = NF0MAX / 1024;
+    __shared__ uint64_t key[NF0MAX];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int nf0 = cfg.f0_hi - cfg.f0_lo;
-    uint64_t k = ~0ull;
-    if (tid < nf0) {
-        float s = best_score[(size_t)f * NF0MAX + tid];
-        if (s > cfg.sync_score_min) k = ((uint64_t)(~__float_as_uint(s)) << 32) | (uint32_t)tid;   // s > 0: bit pattern is monotonic
+#pragma unroll
+    for (int q = 0; q < KPT; q++) {
+        const int i = tid + 1024 * q;
+        uint64_t k = ~0ull;
+        if (i < nf0) {
+            float s = best_score[(size_t)f * NF0MAX + i];
+            if (s > cfg.sync_score_min) k = ((uint64_t)(~__float_as_uint(s)) << 32) | (uint32_t)i;   // s > 0: bit pattern is monotonic
+        }
+        key[i] = k;
     }
-    key[tid] = k;
     __syncthreads();
-    for (int size = 2; size <= 1024; size <<= 1) {
+    for (int size = 2; size <= NF0MAX; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            int partner = tid ^ stride;
-            if (partner > tid) {
-                uint64_t a = key[tid], b = key[partner];
-                bool up = ((tid & size) == 0);
-                if ((a > b) == up) { key[tid] = b; key[partner] = a; }
+#pragma unroll
+            for (int q = 0; q < KPT; q++) {
+                const int i = tid + 1024 * q, partner = i ^ stride;
+                if (partner > i) {
+                    uint64_t a = key[i], b = key[partner];
+                    bool up = ((i & size) == 0);
+                    if ((a > b) == up) { key[i] = b; key[partner] = a; }
+                }
             }
             __syncthreads();
         }
     }
-    uint64_t kk = key[tid];
-    int cnt = __syncthreads_count(kk != ~0ull);
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < KPT; q++) mine += key[tid + 1024 * q] != ~0ull;
+    __shared__ int tot;
+    if (tid == 0) tot = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&tot, mine);
+    __syncthreads();
+    const int cnt = tot;
+    const uint64_t kk = key[tid];
     if (tid == 0) ncand[f] = cnt < cfg.max_cands ? cnt : cfg.max_cands;
     if (tid < cfg.max_cands) {
         ft8rx_record r; memset(&r, 0, sizeof(r));

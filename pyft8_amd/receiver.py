@@ -128,7 +128,8 @@ class AudioIn:
         self.search_hops_per_grid = 2 * self.search_hops_per_cycle
         self.dt = T_CYC / self.search_hops_per_cycle
         self.samples_per_cycle = SAMP_RATE * T_CYC
-        self.search_grid = np.ones((self.search_hops_per_grid, _lib.GRID_COLS), dtype=np.float32)
+        # reference receiver.py:240: f0_hi + 8 * bpt columns (976 at the default range)
+        self.search_grid = np.ones((self.search_hops_per_grid, self.search_f0_idx_range[1] + 8 * self.search_bpt), dtype=np.float32)
         self._rx = receiver
         self.search_grid_ptr = int(self._grid_time() * self.search_hops_per_grid / (2 * T_CYC))
         self.audio_buffer = np.zeros(self.samples_per_cycle, dtype=np.int16)    # reference: float32 copies of int16 samples
@@ -205,7 +206,7 @@ class AudioIn:
         self._audio = np.ascontiguousarray(audio_i16, np.int16).reshape(_lib.NSAMP)
         self.audio_buffer[:] = self._audio
         g = self._rx._handle(1).spectrogram(self._audio)[0]
-        self.search_grid[1:376] = g[1:376]          # in place: waterfall_data['data'] is a live view
+        self.search_grid[1:376] = g[1:376, :self.search_grid.shape[1]]          # in place: waterfall_data['data'] is a live view
         self.search_grid_ptr = 375
         self.cycle_spectrum = None
 
@@ -223,7 +224,7 @@ class AudioIn:
             if tg > 0.1:
                 self.search_grid_ptr = int(tg * self.search_hops_per_grid / (2 * T_CYC))
         with self._rx._hlock:
-            self.search_grid[self.search_grid_ptr, :] = self._rx._handle(1).hop_spectrum(self.audio_buffer[-self.search_fft_len:])
+            self.search_grid[self.search_grid_ptr, :] = self._rx._handle(1).hop_spectrum(self.audio_buffer[-self.search_fft_len:])[:self.search_grid.shape[1]]
         if cycle_done:                                                   # the last hop of a cycle just landed
             self._audio = self.audio_buffer.copy()
             self.cycle_spectrum = None
@@ -233,7 +234,7 @@ class AudioIn:
         return (None, 0)                 # (None, pyaudio.paContinue)
 
     def get_cycle_spectrum(self):
-        """First 49152 bins of the reference's 96001-bin spectrum (receiver.py:280-286): all the fine sync reads."""
+        """First 49152 (wide build: 96000) bins of the reference's 96001-bin spectrum (receiver.py:280-286): all the fine sync reads."""
         if self.cycle_spectrum is None:
             if self._audio is None:
                 raise _lib.Ft8rxError("no frame loaded")
@@ -245,10 +246,11 @@ class Receiver:
     def __init__(self, input_device_keywords, on_message, sync_score_min=85, max_cands=200,
                  search_freq_range=[100, 3000], search_time_range=[-2.5 + 0.5, 2.5 + 0.5], verbose=False,
                  device=0, max_frames=1, time_source=None, sleep=None, audio_source=None, autostart=None, **extension_knobs):
-        if search_freq_range[1] > 3000 or search_freq_range[0] < 12.5:
-            # the reference sizes its grid from search_freq_range (receiver.py:234-240); this build's spectrogram / cycle-spectrum
-            # layouts are fixed at the default 976 columns / 49152 bins (INTEGRATION.md "limits")
-            raise _lib.Ft8rxError(f"search_freq_range {list(search_freq_range)} outside the supported [12.5, 3000] Hz")
+        if search_freq_range[1] > 5900 or search_freq_range[0] < 12.5 or search_freq_range[0] >= search_freq_range[1]:
+            # the reference sizes its grid from search_freq_range (receiver.py:234-240) and itself fails beyond ~5940 Hz, where the
+            # fine-sync slice runs off the cycle spectrum (receiver.py:181-182).  Here the layouts are compile-time: up to 3000 Hz runs
+            # on libft8rx.so, beyond that on libft8rx_wide.so (include/ft8rx.h), chosen by _lib.Handle from cfg.f0_hi
+            raise _lib.Ft8rxError(f"search_freq_range {list(search_freq_range)} outside the supported [12.5, 5900] Hz")
         self.on_message = on_message
         self.time_source = time_source or _time.time          # the reference's time_utils seam (time_utils.py:7-8)
         self.sleep = sleep or _time.sleep                     # time_utils.py:13-14
@@ -264,7 +266,7 @@ class Receiver:
         self.search_start_hop = self.search_h0_range[1] + 43 * 4
         self.device = device
         self._h = None
-        self._sub = None                              # handle for search() over a sub-range of f0 indices
+        self._subs = {}                       # handles for search() over other f0 ranges, keyed by (lo, hi)
         self.call_hashes = _lib.CallHashTable()       # persistent across the cycles of the stream (poll); batches use fresh ones
         self._handle(max_frames)                      # fail loudly now if there is no GPU / library
         self.audio_in = AudioIn(search_freq_range, self, input_device_keywords)
@@ -321,40 +323,58 @@ class Receiver:
 
         odd_even selects the half of the 750-row grid (rows odd_even*375 + 1 ... + 375); hops before the cycle's
         first row read 1.0 (frame-complete semantics, DESIGN.md section 1 -- the live reference would see the
-        tail of the previous cycle there).  search_f_idxs must be a contiguous ascending range (the reference
-        only ever passes `range(a, b)`); a range other than the configured one runs on its own small handle."""
+        tail of the previous cycle there).  search_f_idxs: any sequence of f0 indices (the reference iterates over it, keeps
+        the f0 whose best score clears the threshold, sorts by score -- stably, so ties keep the iteration order -- and cuts
+        at max_cands).  Each run of consecutive ascending indices is one GPU search (the configured range on the receiver's
+        own handle, other runs on small cached handles); the runs are merged the same way."""
         if odd_even not in (0, 1):
             raise _lib.Ft8rxError("odd_even must be 0 or 1")
-        rng = list(self.audio_in.search_f0_idx_range)
-        if search_f_idxs is not None and len(search_f_idxs) > 0:
+        if search_f_idxs is None:
+            idx = list(range(*self.audio_in.search_f0_idx_range))
+        else:
             idx = [int(i) for i in search_f_idxs]
-            if idx != list(range(idx[0], idx[-1] + 1)):
-                raise _lib.Ft8rxError("search_f_idxs must be a contiguous ascending range")
-            rng = [idx[0], idx[-1] + 1]
-        elif search_f_idxs is not None:
+        if not idx:
             self.candidates = []
             return []
-        if rng == list(self.audio_in.search_f0_idx_range):
-            h = self._handle(1)
-        else:
-            if self._sub is None or (self._sub.cfg.f0_lo, self._sub.cfg.f0_hi) != tuple(rng):
-                if self._sub is not None:
-                    self._sub.close()
-                cfg = _lib.Config.from_buffer_copy(bytes(self.cfg))
-                cfg.f0_lo, cfg.f0_hi = rng
-                self._sub = _lib.Handle(cfg, device=self.device, max_frames=1)
-            h = self._sub
+        width = self.audio_in.search_grid.shape[1]
+        if min(idx) < 4 or max(idx) + 16 > width:
+            raise _lib.Ft8rxError(f"search_f_idxs must stay within [4, {width - 16}] (the grid has {width} columns, receiver.py:240)")
+        if len(set(idx)) != len(idx):
+            raise _lib.Ft8rxError("search_f_idxs holds an index twice")
+        runs, start = [], 0
+        for k in range(1, len(idx) + 1):
+            if k == len(idx) or idx[k] != idx[k - 1] + 1:
+                runs.append((idx[start], idx[k - 1] + 1))
+                start = k
         r0 = odd_even * self.audio_in.search_hops_per_cycle
-        grid = np.ones((1, _lib.GRID_ROWS, _lib.GRID_COLS), np.float32)
-        grid[0, 1:376] = self.audio_in.search_grid[r0 + 1:r0 + 376] if odd_even == 0 else \
+        rows = self.audio_in.search_grid[r0 + 1:r0 + 376] if odd_even == 0 else \
             np.concatenate([self.audio_in.search_grid[r0 + 1:], self.audio_in.search_grid[:1]])
-        f0, h0, sc, cnt = h.sync_search(grid)
+        found = []
+        for rng in runs:
+            if list(rng) == list(self.audio_in.search_f0_idx_range):
+                h = self._handle(1)
+            else:
+                h = self._subs.pop(rng, None)
+                if h is None:
+                    cfg = _lib.Config.from_buffer_copy(bytes(self.cfg))
+                    cfg.f0_lo, cfg.f0_hi = rng
+                    if len(self._subs) >= 8:                     # bounded cache of per-range handles, oldest out
+                        self._subs.pop(next(iter(self._subs))).close()
+                    h = _lib.Handle(cfg, device=self.device, max_frames=1)
+                self._subs[rng] = h
+            grid = np.ones((1, _lib.GRID_ROWS, h.grid_cols), np.float32)
+            grid[0, 1:376, :width] = rows
+            f0, h0, sc, cnt = h.sync_search(grid)
+            found += [(int(f0[0, i]), int(h0[0, i]), float(sc[0, i])) for i in range(int(cnt[0]))]
+        if len(runs) > 1:
+            pos = {f: k for k, f in enumerate(idx)}
+            found.sort(key=lambda c: (-c[2], pos[c[0]]))
+            found = found[:self.cfg.max_cands]
         cands = []
-        for i in range(int(cnt[0])):
-            origin = {"h0_idx": int(h0[0, i]), "f0_idx": int(f0[0, i]), "tsec": int(h0[0, i]) / 25.0,
-                      "fHz": 3.125 * int(f0[0, i]), "score": float(sc[0, i]),
+        for f0i, h0i, sci in found:
+            origin = {"h0_idx": h0i, "f0_idx": f0i, "tsec": h0i / 25.0, "fHz": 3.125 * f0i, "score": sci,
                       "cyclestart_string": cyclestart_string, "band": self.band, "odd_even": odd_even}
-            cands.append(Candidate(origin, [r0 + int(h0[0, i]) + 4, r0 + int(h0[0, i]) + 4 * 71]))
+            cands.append(Candidate(origin, [r0 + h0i + 4, r0 + h0i + 4 * 71]))
         self.candidates = cands
         return cands
 

@@ -205,14 +205,14 @@ def random_message(rng):
     return (a, b, ("RR73", "73", "RRR")[rng.integers(3)])
 
 
-def make_frame(index, n_signals=50, snr_range=(-10.0, 10.0), seed_base=SEED_BASE, return_truth=False):
-    """One synthetic 15-s frame -> int16[180000] (and the truth list if asked)."""
+def make_frame(index, n_signals=50, snr_range=(-10.0, 10.0), seed_base=SEED_BASE, return_truth=False, freq_range=(200.0, 2800.0)):
+    """One synthetic 15-s frame -> int16[180000] (and the truth list if asked).  freq_range: where the carriers go (wide-range tests)."""
     rng = np.random.Generator(np.random.Philox(key=seed_base + int(index)))
     x = rng.standard_normal(NFRAME)
     truth = []
     for _ in range(n_signals):
         msg = random_message(rng)
-        f0 = rng.uniform(200.0, 2800.0)
+        f0 = rng.uniform(*freq_range)
         t0 = 0.5 + rng.uniform(-0.5, 1.0)
         snr = rng.uniform(*snr_range)
         amp = np.sqrt(2.0 * (2500.0 / 6000.0) * 10.0 ** (snr / 10.0))

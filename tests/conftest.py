@@ -21,7 +21,7 @@ def pytest_configure(config):
     try:
         from pyft8_amd import _lib
         import shutil
-        if not os.path.exists(_lib.LIB_PATH) and shutil.which("hipcc"):
+        if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.LIB_PATH_WIDE)) and shutil.which("hipcc"):
             _lib.build()
     except Exception as e:      # the tests that need it will report the real error
         print("note: could not pre-build libft8rx.so:", e)
@@ -96,6 +96,20 @@ def load_light_frames():
         key = ("light", e["index"])
         if key not in _cache:
             _cache[key] = synth.make_frame(e["index"], n_signals=e["recipe"]["n_signals"], snr_range=tuple(e["recipe"]["snr_range"]))
+        out.append((e, _cache[key]))
+    return out
+
+
+def load_wide_frames():
+    """The wide-range goldens of oracle/gen_golden_wide.py (search_freq_range beyond 3000 Hz, decoded by the real reference)."""
+    from pyft8_amd import synth
+    d = json.load(open(os.path.join(GOLDEN, "wide_frames.json")))
+    out = []
+    for e in d["frames"]:
+        key = ("wide", e["index"])
+        if key not in _cache:
+            r = e["recipe"]
+            _cache[key] = synth.make_frame(e["index"], n_signals=r["n_signals"], snr_range=tuple(r["snr_range"]), freq_range=tuple(r["freq_range"]))
         out.append((e, _cache[key]))
     return out
 

@@ -310,6 +310,53 @@ def test_light_goldens_on_the_gpu():
     assert n_msgs > 400 and n_dev == 5
 
 
+def test_wide_build_reference_goldens_and_oracle():
+    """search_freq_range beyond 3000 Hz runs on libft8rx_wide.so (same source, wide layouts): the three wide goldens of the REAL
+    reference (carriers up to 5.6 kHz) through the C ABI -- candidates, outcomes, every message dict field -- and, stage by stage,
+    bit-identical spectrogram / cycle spectrum / whole-frame records against the oracle's wide build; where the two builds
+    overlap they agree bit for bit.  Receiver takes the same kwargs and sizes search_grid like the reference (f0_hi + 16 columns)."""
+    from conftest import check_against_light_golden, load_wide_frames
+    from pyft8_amd import _lib, messages as M
+    from pyft8_amd.receiver import Receiver, config_from_kwargs
+    n_hi = 0
+    for e, audio in load_wide_frames():
+        cfg = config_from_kwargs(**e["kwargs"])
+        h = _lib.Handle(cfg, max_frames=2)
+        assert h.wide and (h.grid_cols, h.spec_bins) == (1920, 96000)
+        ocfg = O.default_config(sync_score_min=cfg.sync_score_min, max_cands=cfg.max_cands, f0_lo=cfg.f0_lo, f0_hi=cfg.f0_hi,
+                                h0_lo=cfg.h0_lo, h0_hi=cfg.h0_hi)
+        assert bits_equal(h.spectrogram(audio)[0], O.spectrogram(audio, ocfg))
+        assert bits_equal(h.cycle_spectrum(audio)[0].view(np.float32), O.cycle_spectrum(audio, ocfg).view(np.float32))
+        rec, cnt, ev, evc = h.decode_batch(np.stack([audio, audio]))
+        h.close()
+        assert rec[0].tobytes() == rec[1].tobytes()
+        n = _check_frame(rec[0], cnt[0], ev[0], evc[0], audio, None, ocfg)              # records, outcomes, messages == oracle (wide)
+        cands = [(int(r["f0_idx"]), int(r["h0_idx"])) for r in rec[0, :cnt[0]]]
+        tab = M.CallHashes()
+        outs = []
+        for r in rec[0, :cnt[0]]:
+            outs.append((int(r["ipass"]), " ".join(M.unpack((int(r["msg_hi"]) << 64) | int(r["msg_lo"]), tab) or ())) if int(r["status"]) == 1 else None)
+        msgs = M.package_frame(rec[0], int(cnt[0]), ev[0], int(evc[0]), cyclestart_string="700101_000015")
+        assert check_against_light_golden(e, cands, outs, msgs) == n == len(e["messages"])
+        n_hi += sum(m["fHz"] > 3000 for m in e["messages"])
+    assert n_hi >= 30
+    e, audio = load_wide_frames()[0]
+    hd, hw = _lib.Handle(max_frames=1), _lib.Handle(_lib.default_config(f0_hi=1800), max_frames=1)
+    assert bits_equal(hd.spectrogram(audio)[0], hw.spectrogram(audio)[0][:, :976])
+    assert bits_equal(hd.cycle_spectrum(audio)[0].view(np.float32), hw.cycle_spectrum(audio)[0][:49152].view(np.float32))
+    hd.close(); hw.close()
+    got = []
+    rx = Receiver("x", got.append, **e["kwargs"])
+    assert list(rx.audio_in.search_grid.shape) == e["grid_shape"]
+    out = rx.decode_frame(audio)
+    assert [" ".join(m["msg_tuple"]) for m in out] == [" ".join(m["msg_tuple"]) for m in e["messages"]]
+    for m, ref in zip(out, e["messages"]):
+        for key in ("tsec", "fHz", "their_snr", "all_txt_format", "tweaks", "decode_notes"):
+            assert m[key] == ref[key], (key, m[key], ref[key])
+    with pytest.raises(_lib.Ft8rxError):
+        Receiver("x", None, search_freq_range=[100, 6000])
+
+
 def test_decode_batch_synthetic_vs_oracle(H, ocfg):
     from pyft8_amd import synth
     audio = synth.make_batch(1000, 8)
@@ -381,8 +428,21 @@ def test_search_sub_range_and_second_cycle():
     assert [(c.origin["f0_idx"], c.origin["h0_idx"]) for c in sub] == [(int(c.f0_idx), int(c.h0_idx)) for c in oc]
     assert np.array_equal(np.float32([c.origin["score"] for c in sub]), np.float32([c.score for c in oc]))
     assert rx.search("700101_000015", 0, []) == []
+    # any index sequence (the reference just iterates over it): runs of consecutive indices, single indices, and a descending
+    # tail -- threshold per f0, stable sort by score (ties in iteration order), cut at max_cands
+    idx = list(range(40, 200)) + list(range(500, 640)) + [700, 702, 704] + [330, 329, 328]
+    got = rx.search("700101_000015", 0, idx)
+    ocfg_all = O.default_config(**_lib.fft_plans(), max_cands=2000)
+    allc = {int(c.f0_idx): c for c in O.sync_search(O.spectrogram(audio, ocfg_all), ocfg_all)}
+    pos = {f: k for k, f in enumerate(idx)}
+    want = sorted((allc[f] for f in idx if f in allc), key=lambda c: (-c.score, pos[int(c.f0_idx)]))[:200]
+    assert len(want) > 20
+    assert [(c.origin["f0_idx"], c.origin["h0_idx"]) for c in got] == [(int(c.f0_idx), int(c.h0_idx)) for c in want]
+    assert np.array_equal(np.float32([c.origin["score"] for c in got]), np.float32([c.score for c in want]))
     with pytest.raises(_lib.Ft8rxError):
-        rx.search("700101_000015", 0, [300, 302, 304])
+        rx.search("700101_000015", 0, [300, 300])
+    with pytest.raises(_lib.Ft8rxError):
+        rx.search("700101_000015", 0, range(950, 970))          # beyond the grid the reference would have (f0_hi + 16 columns)
     # the same hops stored as the grid's second cycle (rows 376..749 and the wrap row 0)
     g = rx.audio_in.search_grid
     rows = g[1:376].copy()

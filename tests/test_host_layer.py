@@ -23,6 +23,14 @@ def test_c_abi_exports_every_declared_symbol():
     L = _lib.lib()
     for n in names:
         assert hasattr(L, n), f"libft8rx.so does not export {n}"
+    W = _lib.lib(wide=True)                                    # the wide-layout build of the same source (search ranges beyond 3 kHz)
+    for n in names:
+        assert hasattr(W, n), f"libft8rx_wide.so does not export {n}"
+    info = [ctypes.c_int32() for _ in range(3)]
+    W.ft8rx_build_info(*[ctypes.byref(v) for v in info])
+    assert [v.value for v in info] == [1920, 96000, 1888]
+    L.ft8rx_build_info(*[ctypes.byref(v) for v in info])
+    assert [v.value for v in info] == [976, 49152, 960]
     # and nothing CPU-side pretends to be the product: create must fail without a GPU
     if L.ft8rx_device_count() == 0:
         with pytest.raises(_lib.Ft8rxError):
