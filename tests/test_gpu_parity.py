@@ -340,6 +340,16 @@ def test_wide_build_reference_goldens_and_oracle():
         assert check_against_light_golden(e, cands, outs, msgs) == n == len(e["messages"])
         n_hi += sum(m["fHz"] > 3000 for m in e["messages"])
     assert n_hi >= 30
+    # four more frames (dense, up to 5.6 kHz; sparse and weak) in one batch: every record and message equals the oracle's wide build
+    from pyft8_amd import synth
+    batch = np.stack([synth.make_frame(7200000 + k, n_signals=(60, 60, 6, 6)[k], snr_range=((-6.0, 12.0), (-18.0, 0.0), (-22.0, -10.0), (0.0, 5.0))[k],
+                                       freq_range=(150.0, 5650.0)) for k in range(4)])
+    cfg = config_from_kwargs(search_freq_range=[100, 5900])
+    ocfg = O.default_config(f0_lo=cfg.f0_lo, f0_hi=cfg.f0_hi, h0_lo=cfg.h0_lo, h0_hi=cfg.h0_hi)
+    h = _lib.Handle(cfg, max_frames=4)
+    rec, cnt, ev, evc = h.decode_batch(batch)
+    h.close()
+    assert sum(_check_frame(rec[i], cnt[i], ev[i], evc[i], batch[i], None, ocfg) for i in range(4)) > 50
     e, audio = load_wide_frames()[0]
     hd, hw = _lib.Handle(max_frames=1), _lib.Handle(_lib.default_config(f0_hi=1800), max_frames=1)
     assert bits_equal(hd.spectrogram(audio)[0], hw.spectrogram(audio)[0][:, :976])
