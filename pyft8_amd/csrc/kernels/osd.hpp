@@ -71,7 +71,9 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     }
     __syncthreads();
 #ifndef OSD_TIMING_SKIP_SORT            /* timing-only builds (tools/ab_variants.sh): never defined in the product */
+#pragma unroll                          /* all 36 steps straight-line: positions and directions become constants, no scalar loop control */
     for (int size = 2; size <= 256; size <<= 1) {
+#pragma unroll
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; h2++) {
@@ -128,12 +130,17 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
             }                                                                                                                      \
             lock01 |= b01; lock2 |= b2;                                                                                            \
             ACC |= 1ull << (IL);                                                                                                   \
-            k++;                                                                                                                   \
+            if (++k == 91) lim = 0;                                                                                                \
         }                                                                                                                          \
     }
-    for (int il = 0; il < 64 && k < 91; il++) OSD_STEP(x00, x01, x02, acc0, il)
-    for (int il = 0; il < 64 && k < 91; il++) OSD_STEP(x10, x11, x12, acc1, il)
-    for (int il = 0; il < 46 && k < 91; il++) OSD_STEP(x20, x21, x22, acc2, il)
+    // one loop condition (il < lim; lim drops to 0 when the 91st column is accepted) and a 32-bit opaque counter: the two-condition
+    // form cost 9 scalar instructions of loop control per step on the kernel's bottleneck pipe, this one 3
+#define OSD_RUN(XA, XB, XC, ACC, N) { lim = (k < 91) ? (N) : 0; for (int il = 0; il < lim; il++) { asm volatile("" : "+s"(il)); OSD_STEP(XA, XB, XC, ACC, il) } }
+    int lim;
+    OSD_RUN(x00, x01, x02, acc0, 64)
+    OSD_RUN(x10, x11, x12, acc1, 64)
+    OSD_RUN(x20, x21, x22, acc2, 46)
+#undef OSD_RUN
 #undef OSD_STEP
     // Every accepted column is now a unit vector (its pivot row).  Acceptance order = position order, so the accepted column at
     // position p is the kk-th accepted one with kk = number of accepted positions before p.
