@@ -212,6 +212,12 @@ typedef struct ft8rx_hashes ft8rx_hashes;
 int  ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, const ft8rx_event* events, const int32_t* event_counts,
                          int n_frames, int max_cands, ft8rx_message* out, int max_msgs, int32_t* out_counts, int n_threads,
                          ft8rx_hashes* table, int32_t* flags);
+/* Multi-pass decoding (extension; no GPU needed): append to each frame's message list out[f][0..out_counts[f])
+ * those messages of a later pass, add[f][0..add_counts[f]), whose text the frame does not have yet (pad[0] = pass_tag marks them);
+ * the same messages, untagged, go to fresh[f] (optional; [n_frames][max_add]) -- the input of the next subtraction sweep.
+ * drop_osd != 0 ignores the later pass's OSD decodes (first CRC-valid trial wins there: the source of false decodes). */
+int  ft8rx_merge_messages(ft8rx_message* out, int32_t* out_counts, int max_out, const ft8rx_message* add, const int32_t* add_counts,
+                          int max_add, int n_frames, int pass_tag, int drop_osd, ft8rx_message* fresh, int32_t* fresh_counts);
 /* the persistent call-hash table (databases.py:8-26 `call_hashes` + add_call_hashes) */
 ft8rx_hashes* ft8rx_hashes_create(void);
 void ft8rx_hashes_destroy(ft8rx_hashes* t);

@@ -499,6 +499,27 @@ def package_batch(rec, cnt, ev, evc, max_msgs=None, n_threads=None, table=None, 
     return (out, oc, flags) if return_flags else (out, oc)
 
 
+def merge_messages(out, out_counts, add, add_counts, pass_tag, drop_osd=False):
+    """ft8rx_merge_messages: append (in place) the messages of a later pass that are new for their frame; -> (fresh, fresh_counts),
+    the appended messages without the pass tag."""
+    if out.dtype != MESSAGE_DTYPE or add.dtype != MESSAGE_DTYPE or not out.flags.c_contiguous or out.shape[0] != add.shape[0]:
+        raise Ft8rxError("merge_messages: message arrays as returned by package_batch expected")
+    add = np.ascontiguousarray(add)
+    add_counts = np.ascontiguousarray(add_counts, np.int32)
+    if out_counts.dtype != np.int32 or not out_counts.flags.c_contiguous:
+        raise Ft8rxError("merge_messages: out_counts must be a contiguous int32 array (it is updated in place)")
+    fresh = np.zeros_like(add)
+    fc = np.zeros(add.shape[0], np.int32)
+    L = lib()
+    L.ft8rx_merge_messages.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p]
+    rc = L.ft8rx_merge_messages(out.ctypes.data, out_counts.ctypes.data, int(out.shape[1]), add.ctypes.data, add_counts.ctypes.data,
+                                int(add.shape[1]), int(out.shape[0]), int(pass_tag), int(bool(drop_osd)), fresh.ctypes.data, fc.ctypes.data)
+    if rc != 0:
+        raise Ft8rxError(f"ft8rx_merge_messages failed ({rc})")
+    return fresh, fc
+
+
 _default = {}
 
 

@@ -882,6 +882,13 @@ int ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, cons
                                   table ? &table->H : nullptr, flags);
 }
 
+int ft8rx_merge_messages(ft8rx_message* out, int32_t* out_counts, int max_out, const ft8rx_message* add, const int32_t* add_counts,
+                         int max_add, int n_frames, int pass_tag, int drop_osd, ft8rx_message* fresh, int32_t* fresh_counts) {
+    if (!out || !out_counts || !add || !add_counts || n_frames < 0 || max_out < 1 || max_add < 1) return -1;
+    hostmsg::merge_messages(out, out_counts, max_out, add, add_counts, max_add, n_frames, pass_tag, drop_osd, fresh, fresh_counts);
+    return 0;
+}
+
 ft8rx_hashes* ft8rx_hashes_create(void) { return new (std::nothrow) ft8rx_hashes(); }
 void ft8rx_hashes_destroy(ft8rx_hashes* t) { delete t; }
 int ft8rx_hashes_clear(ft8rx_hashes* t) { if (!t) return -1; t->H.m.clear(); return 0; }

@@ -246,6 +246,32 @@ static int package_batch(const ft8rx_record* records, const int32_t* counts, con
     for (auto& th : pool) th.join();
     return 0;
 }
+// Multi-pass decoding (extension): append the messages of a later pass that are new for their frame.
+// out[f][0 .. out_counts[f]) holds the messages so far; add[f][0 .. add_counts[f]) the later pass's; a message is new if its three
+// text fields differ from every message the frame already has.  New ones are appended to out (pad[0] = pass_tag) and, untagged, to
+// fresh[f] -- the list the next subtraction sweep works from.  drop_osd: ignore OSD decodes (ipass 5 / 6) of the later pass.
+static void merge_messages(ft8rx_message* out, int32_t* out_counts, int max_out, const ft8rx_message* add, const int32_t* add_counts,
+                           int max_add, int n_frames, int pass_tag, int drop_osd, ft8rx_message* fresh, int32_t* fresh_counts) {
+    for (int f = 0; f < n_frames; f++) {
+        ft8rx_message* o = out + (size_t)f * max_out;
+        const ft8rx_message* a = add + (size_t)f * max_add;
+        ft8rx_message* fr = fresh ? fresh + (size_t)f * max_add : nullptr;
+        int n = out_counts[f], nf = 0;
+        const int na = add_counts[f] < max_add ? add_counts[f] : max_add;
+        for (int i = 0; i < na; i++) {
+            if (drop_osd && (a[i].method == FT8RX_M_OSD || a[i].method == FT8RX_M_LDPC_B_OSD)) continue;
+            if (n >= max_out) break;
+            bool seen = false;
+            for (int j = 0; j < n && !seen; j++) seen = memcmp(o[j].f, a[i].f, sizeof(a[i].f)) == 0;
+            if (seen) continue;
+            o[n] = a[i]; o[n].pad[0] = (uint8_t)pass_tag; n++;
+            if (fr) fr[nf] = a[i];
+            nf++;
+        }
+        out_counts[f] = n;
+        if (fresh_counts) fresh_counts[f] = nf;
+    }
+}
 }  // namespace hostmsg
 
 #endif

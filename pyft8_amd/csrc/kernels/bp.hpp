@@ -34,7 +34,12 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
         if (rec[(size_t)frame * MAXC + ci].status != FT8RX_ST_ACTIVE) return;
         vec = (size_t)c;
     }
-    for (int i = lane; i < 174; i += 64) llr[i] = ap_value(ap, i, llr_in[vec * 174 + i]);
+    {   // three loads in flight, then the AP override (ap_value around the load would branch over it: one round trip per basic block)
+        const float* src = llr_in + vec * 174;
+        const float v0 = src[lane], v1 = src[64 + lane], v2 = src[128 + (lane < 46 ? lane : 0)];
+        llr[lane] = ap_value(ap, lane, v0); llr[64 + lane] = ap_value(ap, 64 + lane, v1);
+        if (lane < 46) llr[128 + lane] = ap_value(ap, 128 + lane, v2);
+    }
     if (lane < 2) llr[174 + lane] = 0.0f;
     if (lane == 0) P[83] = 1.0f;
     __syncthreads();

@@ -261,10 +261,20 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     const int fb0 = 50 * f0;                                      // int(0.5 + fHz*16)
     {
         const cpx* __restrict__ Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
-#ifndef FINE_NO_SLICE
-        for (int i = tid; i < FINE_SLICE; i += FINE_NT) slice[i] = Sg[i];
-#endif
-        for (int i = tid; i < 400; i += FINE_NT) w400[i] = T.W3200[8 * i];
+        // the candidate's spectrum window and the stage-2 twiddles: all loads requested together, then stored (a load->store loop waits
+        // for every load separately: 3.07 -> 2.99 ms)
+        {
+            constexpr int NS = (FINE_SLICE + FINE_NT - 1) / FINE_NT, NW = (400 + FINE_NT - 1) / FINE_NT;
+            cpx sv[NS], wv[NW];
+#pragma unroll
+            for (int q = 0; q < NS; q++) { const int i = tid + FINE_NT * q; sv[q] = Sg[i < FINE_SLICE ? i : 0]; }
+#pragma unroll
+            for (int q = 0; q < NW; q++) { const int i = tid + FINE_NT * q; wv[q] = T.W3200[8 * (i < 400 ? i : 0)]; }
+#pragma unroll
+            for (int q = 0; q < NS; q++) { const int i = tid + FINE_NT * q; if (i < FINE_SLICE) slice[i] = sv[q]; }
+#pragma unroll
+            for (int q = 0; q < NW; q++) { const int i = tid + FINE_NT * q; if (i < 400) w400[i] = wv[q]; }
+        }
         __syncthreads();
     }
 #ifndef FINE_NO_SLICE

@@ -150,9 +150,15 @@ __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid,
     ChkMasks cm;
     if (att0) cm = chk_masks(lane);              // issued with the gather below
     const float* g = grid + (size_t)frame * FT8RX_GRID_ROWS * FT8RX_GRID_COLS;
-    for (int i = lane; i < 464; i += 64) {
-        int s = i >> 3, t = i & 7;
-        p[i] = grid_at(g, h0 + 4 + 4 * (int)d_PAYSYM[s], f0 + 1 + 2 * t);        // receiver.py:358-362
+    {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {                  // all eight gathers of a lane in flight together (a load->store loop: 129 -> 105 us)
+            const int i = lane + 64 * q, ic = i < 464 ? i : 0;
+            v[q] = grid_at(g, h0 + 4 + 4 * (int)d_PAYSYM[ic >> 3], f0 + 1 + 2 * (ic & 7));        // receiver.py:358-362
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (lane + 64 * q < 464) p[lane + 64 * q] = v[q];
     }
     __syncthreads();
     float sd; int snr;

@@ -48,11 +48,13 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
         slot = bid % 10; int c = bid / 10; frame = c / MAXC; ci = c % MAXC;
         if (ci >= ncand[frame]) return;
         if (rec[(size_t)frame * MAXC + ci].status != FT8RX_ST_ACTIVE) return;
-        if (slot < 5) { for (int i = lane; i < 174; i += 64) llr[i] = ap_value(slot, i, llr_in[(size_t)c * 174 + i]); }
-        else {
-            if (!attB[(size_t)c * 5 + (slot - 5)].has_out) { if (lane == 0) { Att a; memset(&a, 0, sizeof(a)); a.n_its = -1; attO[(size_t)c * 10 + slot] = a; } return; }
-            for (int i = lane; i < 174; i += 64) llr[i] = saved[((size_t)c * 5 + (slot - 5)) * 174 + i];
-        }
+        if (slot >= 5 && !attB[(size_t)c * 5 + (slot - 5)].has_out) { if (lane == 0) { Att a; memset(&a, 0, sizeof(a)); a.n_its = -1; attO[(size_t)c * 10 + slot] = a; } return; }
+        // slots 0..4: the fine LLRs with the AP override, slots 5..9: the saved BP outputs; three loads in flight either way
+        const float* src = slot < 5 ? llr_in + (size_t)c * 174 : saved + ((size_t)c * 5 + (slot - 5)) * 174;
+        const int apx = slot < 5 ? slot : 0;                                   // ap_value(0, ...) is the identity
+        const float v0 = src[lane], v1 = src[64 + lane], v2 = src[128 + (lane < 46 ? lane : 0)];
+        llr[lane] = ap_value(apx, lane, v0); llr[64 + lane] = ap_value(apx, 64 + lane, v1);
+        if (lane < 46) llr[128 + lane] = ap_value(apx, 128 + lane, v2);
         vec = (size_t)c * 10 + slot;
     } else {
         for (int i = lane; i < 174; i += 64) llr[i] = llr_in[vec * 174 + i];

@@ -88,11 +88,20 @@ FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __r
         F::store_affine<640, 128>(z, tid, v);
         __syncthreads();
     }
-    for (int k = tid; k < FT8RX_GRID_COLS; k += SPEC_NT) {
-        cpx p = z[k], q = z[(1920 - k) % 1920];
-        float er = 0.5f * (p.x + q.x), ei = 0.5f * (p.y - q.y);
-        float orr = 0.5f * (p.y + q.y), oi = 0.5f * (q.x - p.x);
-        cpx w = T.WR3840[k];
+    // real-FFT split + dB: the split twiddles of the thread's eight bins are requested together, ahead of the sqrt/log10 chain
+    // (with the load inside the loop every iteration waited for its own twiddle: 498 -> 467 us)
+    constexpr int NE = (FT8RX_GRID_COLS + SPEC_NT - 1) / SPEC_NT;
+    cpx we[NE];
+#pragma unroll
+    for (int q = 0; q < NE; q++) { const int k = tid + SPEC_NT * q; we[q] = T.WR3840[k < FT8RX_GRID_COLS ? k : 0]; }
+#pragma unroll
+    for (int q = 0; q < NE; q++) {
+        const int k = tid + SPEC_NT * q;
+        if (k >= FT8RX_GRID_COLS) break;
+        cpx p = z[k], q2 = z[(1920 - k) % 1920];
+        float er = 0.5f * (p.x + q2.x), ei = 0.5f * (p.y - q2.y);
+        float orr = 0.5f * (p.y + q2.y), oi = 0.5f * (q2.x - p.x);
+        cpx w = we[q];
         float xr = er + (w.x * orr - w.y * oi);
         float xi = ei + (w.x * oi + w.y * orr);
         float mag = sqrtf(xr * xr + xi * xi);

@@ -462,9 +462,8 @@ class Receiver:
         msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=n_threads)
         if passes <= 1:
             return msgs, mcnt, rec, cnt
-        out, ocnt = msgs.copy(), mcnt.copy()
+        out, ocnt = msgs.copy(), np.ascontiguousarray(mcnt, np.int32).copy()
         cur_m, cur_c, cur_rec = msgs, mcnt, rec
-        osd_methods = (_lib.M_OSD, _lib.M_LDPC_B_OSD)
         for p in range(1, int(passes)):
             sigs = self._subtraction_list(cur_m, cur_c, cur_rec, subtract_min_snr)
             if not sigs[1].any():
@@ -473,22 +472,7 @@ class Receiver:
             h.enqueue(h.staging_ptr(), B)
             rec2, cnt2, ev2, evc2 = h.fetch(B)
             m2, c2 = _lib.package_batch(rec2, cnt2, ev2, evc2, n_threads=n_threads)
-            new_m = np.zeros_like(m2)
-            new_c = np.zeros_like(c2)
-            for f in range(B):
-                seen = set(out[f, :ocnt[f]]["f"].tobytes()[i * 48:(i + 1) * 48] for i in range(ocnt[f]))
-                for i in range(c2[f]):
-                    row = m2[f, i]
-                    key = row["f"].tobytes()
-                    if key in seen or (not sub_pass_osd and row["method"] in osd_methods) or ocnt[f] >= out.shape[1]:
-                        continue
-                    seen.add(key)
-                    row = row.copy()
-                    row["pad"][0] = p
-                    out[f, ocnt[f]] = row
-                    ocnt[f] += 1
-                    new_m[f, new_c[f]] = m2[f, i]
-                    new_c[f] += 1
+            new_m, new_c = _lib.merge_messages(out, ocnt, m2, c2, p, drop_osd=not sub_pass_osd)      # native: appends in place
             cur_m, cur_c, cur_rec = new_m, new_c, rec2
         return out, ocnt, rec, cnt
 

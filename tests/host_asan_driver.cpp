@@ -40,6 +40,24 @@ int main(int argc, char** argv) {
         evc[3] = FT8RX_EVENT_CAP + 100; cnt[5] = MC + 50;                      // overflowing counts are clamped and flagged
         if (hostmsg::package_batch(R.data(), cnt.data(), E.data(), evc.data(), B, MC, out.data(), 3, oc.data(), 2, nullptr, fl.data())) return 3;
         if (!(fl[3] & FT8RX_PKG_EVENTS_TRUNCATED) || !(fl[0] & FT8RX_PKG_MSG_TRUNCATED) || oc[0] != 3) return 5;
+        {   // multi-pass merge: nothing of the same list is new; a list with one changed text is; capacity is respected
+            std::vector<ft8rx_message> base((size_t)B * MC), add((size_t)B * MC), fresh((size_t)B * MC);
+            std::vector<int32_t> bc(B), ac(B), fc(B);
+            if (hostmsg::package_batch(R.data(), std::vector<int32_t>(B, n).data(), E.data(), std::vector<int32_t>(B, nev).data(), B, MC, base.data(), MC, bc.data(), 2, nullptr, fl.data())) return 3;
+            add = base; ac = bc;
+            hostmsg::merge_messages(base.data(), bc.data(), MC, add.data(), ac.data(), MC, B, 1, 0, fresh.data(), fc.data());
+            for (int b = 0; b < B; b++) if (fc[b] != 0 || bc[b] != ac[b]) return 6;
+            if (ac[0] > 0) {
+                add[0].f[0][0] ^= 1;
+                hostmsg::merge_messages(base.data(), bc.data(), MC, add.data(), ac.data(), MC, B, 2, 1, fresh.data(), fc.data());
+                const bool osd = add[0].method == FT8RX_M_OSD || add[0].method == FT8RX_M_LDPC_B_OSD;
+                if (fc[0] != (osd ? 0 : 1)) return 7;
+                bc[1] = MC;                                                   // full list: nothing may be appended
+                add[(size_t)MC].f[0][0] ^= 1;
+                hostmsg::merge_messages(base.data(), bc.data(), MC, add.data(), ac.data(), MC, B, 3, 0, nullptr, nullptr);
+                if (bc[1] != MC) return 8;
+            }
+        }
         printf("frame dump: %d candidates, %d events, %d messages per frame\n", n, nev, (int)(total / B));
     }
     // (b) random words through unpack (all i3 values, hashed calls, boundaries) and the encoder
