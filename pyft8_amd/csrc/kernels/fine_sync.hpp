@@ -257,7 +257,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         if (r.status != FT8RX_ST_ACTIVE) return;
         f0 = r.f0_idx; h0 = r.h0_idx;
     }
-    if (tid < 32) w32[tid] = T.W32[tid];
+    const cpx w32v = T.W32[tid & 31];                             // requested with the window loads below, stored before the barrier
     const int fb0 = 50 * f0;                                      // int(0.5 + fHz*16)
     {
         const cpx* __restrict__ Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
@@ -274,6 +274,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
             for (int q = 0; q < NS; q++) { const int i = tid + FINE_NT * q; if (i < FINE_SLICE) slice[i] = sv[q]; }
 #pragma unroll
             for (int q = 0; q < NW; q++) { const int i = tid + FINE_NT * q; if (i < 400) w400[i] = wv[q]; }
+            if (tid < 32) w32[tid] = w32v;
         }
         __syncthreads();
     }

@@ -14,7 +14,9 @@
 FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __restrict__ out, const Tables& T,
                              cpx* z, cpx* w240, int tid) {
     const cpx* __restrict__ W = T.W1920;
-    for (int i = tid; i < 240; i += SPEC_NT) w240[i] = W[8 * i];
+    // stage-2 twiddle table: requested now, stored to LDS just before the first barrier (a load -> wait -> store loop here delayed
+    // the whole block by a memory round trip before its first sample load)
+    const cpx wa = W[8 * tid], wb = W[8 * (tid + SPEC_NT < 240 ? tid + SPEC_NT : 0)];
     {   // pass [8]: n = 1920, s = 1, m = 240: butterfly p reads samples m = p + 240 j.  Straight-line: loads from clamped addresses,
         // zeros by select (hops before the frame start), twiddle multiplies unconditional (W^0 = (1, -0) is an exact identity).
         cpx v[2][8];
@@ -48,6 +50,8 @@ FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __r
             }
         }
     }
+    w240[tid] = wa;
+    if (tid + SPEC_NT < 240) w240[tid + SPEC_NT] = wb;
     __syncthreads();
     {   // passes [4,4]: n = 240, s = 8; group g = (pp = g / 8, q = g % 8): in q + 8(pp + 15 j' + 60 j), out q + 8 j + 32(4 pp + j')
         typedef Fused2<1920, 240, 8, 4, 4> F;
