@@ -143,7 +143,7 @@ int  ft8rx_fetch_results_view(ft8rx_handle* h, int n_frames, const ft8rx_record*
 int  ft8rx_results_to_device(ft8rx_handle* h, int n_frames, ft8rx_record* d_records, int32_t* d_counts,
                              ft8rx_event* d_events, int32_t* d_event_counts);
 /* per-kernel HIP-event timing of the most recent enqueue (enable before enqueue). names/ms: up to 16 */
-/* number of HIP streams a batch is cut across (1..8, default 4); profiling mode always uses one */
+/* number of HIP streams a batch is cut across (1..8, default 2: measured best, profiles/r02_notes.md); profiling mode always uses one */
 int  ft8rx_set_streams(ft8rx_handle* h, int n);
 /* how the fine-stage BP attempts of a batch are launched; records and messages are identical either way:
  * 0 (default) = in the reference's ladder order (receiver.py:84-98) as three launches, candidates that are decided dropping out in
