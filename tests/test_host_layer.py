@@ -37,6 +37,33 @@ def test_c_abi_exports_every_declared_symbol():
             _lib.Handle()
 
 
+def test_merge_messages_native():
+    """ft8rx_merge_messages (multi-pass extension, host only): new texts are appended with the pass tag and returned as the fresh
+    list; texts the frame already has, OSD decodes when asked, and anything beyond the capacity are not."""
+    from pyft8_amd import _lib
+    def mk(rows, cap):
+        a = np.zeros((len(rows), cap), _lib.MESSAGE_DTYPE)
+        c = np.zeros(len(rows), np.int32)
+        for f, msgs in enumerate(rows):
+            for i, (txt, method) in enumerate(msgs):
+                for k, w in enumerate(txt.split(" ")):
+                    a[f, i]["f"][k] = w.encode()
+                a[f, i]["method"] = method
+            c[f] = len(msgs)
+        return a, c
+    out, oc = mk([[("CQ K1ABC FN42", 0), ("K1ABC W9XYZ EN37", 1)], [], [("CQ DL1AA JO62", 0)]], 4)
+    add, ac = mk([[("K1ABC W9XYZ EN37", 2), ("W9XYZ K1ABC -05", 3), ("CQ PA5S JO21", 1), ("CQ PA5S JO21", 1)],
+                  [("CQ G4ABC IO91", 4)], [("CQ DL1AA JO62", 1), ("A B C", 1), ("D E F", 1), ("G H I", 1), ("J K L", 1)]], 5)
+    fresh, fc = _lib.merge_messages(out, oc, add, ac, 1, drop_osd=True)
+    txt = lambda a, n: [b" ".join(r["f"]).decode() for r in a[:n]]
+    assert txt(out[0], oc[0]) == ["CQ K1ABC FN42", "K1ABC W9XYZ EN37", "CQ PA5S JO21"]            # duplicate dropped, OSD (method 3) dropped
+    assert txt(out[1], oc[1]) == [] and fc[1] == 0                                                   # method 4 = OSD on saved LLRs: dropped
+    assert txt(out[2], oc[2]) == ["CQ DL1AA JO62", "A B C", "D E F", "G H I"] and fc[2] == 3         # capacity 4
+    assert txt(fresh[0], fc[0]) == ["CQ PA5S JO21"] and int(out[0, 2]["pad"][0]) == 1 and int(fresh[0, 0]["pad"][0]) == 0
+    fresh, fc = _lib.merge_messages(out, oc, add, ac, 2, drop_osd=False)
+    assert txt(out[0], oc[0])[-1] == "W9XYZ K1ABC -05" and int(out[0, 3]["pad"][0]) == 2 and txt(out[1], oc[1]) == ["CQ G4ABC IO91"]
+
+
 def test_record_layouts_match_header():
     from pyft8_amd import _lib
     assert _lib.RECORD_DTYPE.itemsize == 48 and _lib.EVENT_DTYPE.itemsize == 24
