@@ -344,7 +344,9 @@ class Handle:
 
     def subtract(self, d_audio_ptr, n_frames, signals, return_float=False, refine=False, return_origins=False):
         """Subtract decoded signals from device-resident int16 audio in place (ft8rx_subtract).
-        signals: per frame a list of (tones79, fHz, tsec), subtracted in list order.  -> float32 residual if return_float."""
+        signals: per frame a list of (tones79, fHz, tsec), subtracted in list order.  -> float32 residual if return_float.
+        refine: 0 = as given (the reference's subtract_signal), 1 = re-estimate each origin first with full-rate scans, 2 = the same on
+        a decimated baseband copy (fast; what Receiver's multi-pass decode uses)."""
         B = int(n_frames)
         if isinstance(signals, tuple):          # (array [B, max_sigs] of SUBSIG_DTYPE, counts [B]) -- the fast path
             arr, cnt = signals
@@ -364,7 +366,7 @@ class Handle:
         L = self._L
         L.ft8rx_subtract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         self._chk(L.ft8rx_subtract(self._h, C.c_void_p(d_audio_ptr), B, arr.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32), ms,
-                                   int(bool(refine)), out.ctypes.data_as(C.c_void_p) if return_float else None), "ft8rx_subtract")
+                                   int(refine), out.ctypes.data_as(C.c_void_p) if return_float else None), "ft8rx_subtract")
         if return_origins:                 # (fHz, tsec) per signal after refinement
             return out, [[(float(arr[f, i]["fHz"]), float(arr[f, i]["tsec"])) for i in range(cnt[f])] for f in range(B)]
         return out

@@ -104,6 +104,7 @@ struct ft8rx_handle {
     int slot_enq, slot_fetch, inflight, last_slot, slot_B[2];
     // signal subtraction (extension, allocated on first use): float32 working copy, per-chunk partial sums, GFSK tables
     float* d_wf; double2* d_part; double* d_pulse; double* d_pc; ft8rx_subsig* d_sigs; int32_t* d_sigcnt; int sig_cap;
+    float2 *d_zdec, *d_model, *d_adec; SubdCtx* d_subctx;      // decimated-baseband refinement (refine = 2), allocated on first use
     std::string err;
     bool profiling;
     std::vector<hipEvent_t> pev;
@@ -230,6 +231,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
+    h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
     int rc = 0;
@@ -816,12 +818,41 @@ int ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int B, ft8rx_subsig* sigs,
     coarse.n = 16; for (int i = 0; i < 16; i++) coarse.shift[i] = -1680 + 120 * i;          // -140 .. +10 ms
     fine.n = 9;    for (int i = 0; i < 9; i++) fine.shift[i] = -120 + 30 * i;               // -10 .. +10 ms
     for (int i = 9; i < SUB_MAXSHIFT; i++) fine.shift[i] = 0;
+    if (refine == 2 && !h->d_zdec) {
+        const size_t MB = (size_t)h->max_frames;
+        int rc = dalloc(h, &h->d_zdec, MB * SUBD_NZ);
+        rc |= dalloc(h, &h->d_model, MB * SUBD_N);
+        rc |= dalloc(h, &h->d_adec, MB * (SUBD_N + 1));
+        rc |= dalloc(h, &h->d_subctx, MB);
+        if (rc) return -2;
+    }
+    // refine = 2: the same steps on a decimated baseband copy (kernels/subtract.hpp): time shifts in units of 32 samples
+    SubShifts dcoarse, dfine;
+    dcoarse.stride = 1; dfine.stride = 1;
+    dcoarse.n = 15; for (int i = 0; i < 15; i++) dcoarse.shift[i] = SUBD_D * (-52 + 4 * i);        // -138.7 .. +10.7 ms in 10.7 ms steps
+    dcoarse.shift[15] = 0;
+    dfine.n = 9;    for (int i = 0; i < 9; i++) dfine.shift[i] = SUBD_D * (-4 + i);                // -10.7 .. +10.7 ms in 2.67 ms steps
+    for (int i = 9; i < SUB_MAXSHIFT; i++) dfine.shift[i] = 0;
+    const dim3 gmodel((SUBD_N + 255) / 256, B);
     for (int s = 0; s < nmax; s++) {
+        if (refine == 2) {
+            k_subd_mix<<<dim3(SUBD_NZ / 256, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, h->d_zdec, h->d_subctx);
+            k_subd_model<<<gmodel, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_subctx, h->d_model);
+            k_subd_scan<<<B, 256, 0, h->stream>>>(h->d_zdec, h->d_model, h->d_sigs, h->d_sigcnt, max_sigs, s, h->d_subctx, dcoarse, h->d_part);
+            k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, dcoarse, h->d_part, -1.0f, 0.0625f, 113, SUBD_D * SUBD_CH);
+            k_subd_model<<<gmodel, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_subctx, h->d_model);
+            k_subd_scan<<<B, 256, 0, h->stream>>>(h->d_zdec, h->d_model, h->d_sigs, h->d_sigcnt, max_sigs, s, h->d_subctx, dfine, h->d_part);
+            k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, dfine, h->d_part, 0.4375f, 0.015625f, 9, SUBD_D * SUBD_CH);
+            k_subd_model<<<gmodel, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_subctx, h->d_model);
+            k_subd_accum<<<B, 256, 0, h->stream>>>(h->d_zdec, h->d_model, h->d_sigs, h->d_sigcnt, max_sigs, s, h->d_subctx, h->d_adec);
+            k_subd_apply<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_adec);
+            continue;
+        }
         if (refine) {
             k_sub_scan<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, coarse, h->d_part);
-            k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, coarse, h->d_part, -1.0f, 0.0625f, 113);   // signal - model: -1 .. +6 Hz; the sum is coherent over 12.6 s, so the grid must be as fine as 1/16 Hz
+            k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, coarse, h->d_part, -1.0f, 0.0625f, 113, SUB_CH);   // signal - model: -1 .. +6 Hz; the sum is coherent over 12.6 s, so the grid must be as fine as 1/16 Hz
             k_sub_scan<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, fine, h->d_part);
-            k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, fine, h->d_part, 0.4375f, 0.015625f, 9);   // around the +0.5 Hz the coarse step left
+            k_sub_pick<<<B, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, fine, h->d_part, 0.4375f, 0.015625f, 9, SUB_CH);   // around the +0.5 Hz the coarse step left
         }
         k_sub_accum<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);
         k_sub_apply<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void k_sub_scan(const float* __restrict__ wf, 
 
 // one block per frame: best (shift, df) of signal s; df on [df_lo, df_lo + ndf * df_step)
 __global__ __launch_bounds__(256) void k_sub_pick(ft8rx_subsig* __restrict__ sigs, const int32_t* __restrict__ counts, int max_sigs, int s,
-                                                  SubShifts sh, const double2* __restrict__ scan, float df_lo, float df_step, int ndf) {
+                                                  SubShifts sh, const double2* __restrict__ scan, float df_lo, float df_step, int ndf,
+                                                  int chunk_samples) {
     __shared__ float best_e[256];
     __shared__ int best_i[256];
     const int frame = blockIdx.x, tid = threadIdx.x;
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(256) void k_sub_pick(ft8rx_subsig* __restrict__ sig
         float er = 0.0f, ei = 0.0f;
         // e^{-2 pi i df t_c} at the chunk centres t_c = (c + 1/2) CH / 12000: one rotation step per chunk
         float wr, wi, rr, ri;
-        sincosf(-6.28318531f * df * ((float)SUB_CH / 12000.0f), &wi, &wr);
-        sincosf(-6.28318531f * df * (0.5f * (float)SUB_CH / 12000.0f), &ri, &rr);
+        sincosf(-6.28318531f * df * ((float)chunk_samples / 12000.0f), &wi, &wr);
+        sincosf(-6.28318531f * df * (0.5f * (float)chunk_samples / 12000.0f), &ri, &rr);
         for (int c = 0; c < SUB_NCH; c++) {
             const float yr = (float)Y[c].x, yi = (float)Y[c].y;
             er += yr * rr - yi * ri; ei += yr * ri + yi * rr;
@@ -225,6 +226,224 @@ __global__ __launch_bounds__(256) void k_sub_pick(ft8rx_subsig* __restrict__ sig
         // the model's tone 0 is at fHz - 0.5 (receiver_sub.py:387), so that the signal sits mid-band of the 0 .. 1.19 Hz low-pass:
         // df is the signal's offset from the model, and the new fHz puts it at +0.5 Hz again
         S.fHz += (double)(df_lo + df_step * (float)j) - 0.5;
+    }
+}
+
+// ---- fast origin refinement + amplitude estimate on a decimated baseband copy (extension, refine = 2) ---------------------------
+// The full-rate scans above evaluate the signal model four times per sample and signal.  Everything they estimate lives within
+// +-25 Hz of the signal's centre frequency, so: mix the residual audio down by f_c = (fHz - 0.5) + 21.875 Hz (middle of the eight
+// tones) and decimate by 32 with a triangular (two-stage boxcar) filter -- nulls at every multiple of 375 Hz, i.e. exactly where
+// the decimation folds other signals onto this one; worst-case alias < -45 dB -- ONCE per signal (k_subd_mix); run the time /
+// frequency scans and the 20-bin amplitude estimate on the 375 Hz series (4736 samples instead of 151 680: k_subd_scan,
+// k_sub_pick, k_subd_accum) against the model sampled at the same instants with the filter's per-tone droop divided out
+// (k_subd_model); and go back to full rate only to subtract (k_subd_apply: exact model, the slowly varying amplitude a(t)
+// interpolated linearly between its 375 Hz samples -- it is band-limited to 1.2 Hz).  Time shifts are multiples of 32 samples
+// (2.67 ms).  Decimated sample m sits at full-rate index s00 + 32 (m - SUBD_PAD), s00 = the decoder's start sample.
+#define SUBD_D 32
+#define SUBD_CH 37                              /* decimated samples per chunk: 128 chunks x 37 x 32 = 151 552 of the 151 680 model samples */
+#define SUBD_N (SUB_NCH * SUBD_CH)              /* 4736 */
+#define SUBD_PAD 64                             /* decimated samples kept before s00 (coarse shifts reach -56) */
+#define SUBD_NZ (SUBD_PAD + SUBD_N + 64)        /* 4864 = 19 x 256 */
+struct SubdCtx { double fc; int s00; int pad; };
+
+// response of the triangular decimator (boxcar 32 applied twice) at offset f Hz from the mixing frequency, relative to DC
+FT8_DEV float subd_droop(float f) {
+    const float x = 3.14159265f * f / 12000.0f;
+    if (fabsf(x) < 1e-6f) return 1.0f;
+    const float r = sinf(32.0f * x) / (32.0f * sinf(x));
+    return r * r;
+}
+
+// block sums of the mixed-down samples of LDS block lb (32 samples): S = sum xb, R = sum k xb
+FT8_DEV void subd_block(const float* xs, int nb, int lb, double fc, float* sr_, float* si_, float* rr_, float* ri_) {
+    const int n0 = nb + SUBD_D * lb;
+    const double rev = fc * ((double)n0 / 12000.0);
+    const float fr = (float)(rev - floor(rev));
+    float cr = __builtin_amdgcn_cosf(fr), ci = -__builtin_amdgcn_sinf(fr);              // e^{-2 pi i fc n0 / fs}
+    const float st = (float)(fc / 12000.0);
+    const float wr = __builtin_amdgcn_cosf(st), wi = -__builtin_amdgcn_sinf(st);        // per-sample rotation
+    float sr = 0.0f, si = 0.0f, rr = 0.0f, ri = 0.0f;
+    const float* b = xs + 33 * lb;
+#pragma unroll 8
+    for (int k = 0; k < 32; k++) {
+        const float v = b[k];
+        const float br = v * cr, bi = v * ci;
+        sr += br; si += bi; rr += (float)k * br; ri += (float)k * bi;
+        const float t = cr * wr - ci * wi; ci = cr * wi + ci * wr; cr = t;
+    }
+    *sr_ = sr; *si_ = si; *rr_ = rr; *ri_ = ri;
+}
+// grid (SUBD_NZ / 256, B): z[m] = sum_{j=-31..31} (32 - |j|) x[n_c + j] e^{-2 pi i fc (n_c + j) / 12000},  n_c = s00 + 32 (m - SUBD_PAD)
+//   = R[m-1] + 32 S[m] - R[m]  with the block sums S[m] = sum_{k<32} xb[32 m + k], R[m] = sum_k k xb[32 m + k]
+__global__ __launch_bounds__(256) void k_subd_mix(const float* __restrict__ wf, const ft8rx_subsig* __restrict__ sigs,
+                                                  const int32_t* __restrict__ counts, int max_sigs, int s,
+                                                  float2* __restrict__ zdec /*[B][SUBD_NZ]*/, SubdCtx* __restrict__ ctx /*[B]*/) {
+    __shared__ float xs[257 * 33];                                       // 257 blocks of 32 samples, one pad word per block (bank-conflict free)
+    __shared__ float2 Rs[257];
+    const int frame = blockIdx.y, tid = threadIdx.x;
+    if (s >= counts[frame]) return;
+    const ft8rx_subsig& S = sigs[(size_t)frame * max_sigs + s];
+    const double fc = S.fHz - 0.5 + 21.875;
+    const int s00 = (int)(12000.0 * S.tsec);
+    if (blockIdx.x == 0 && tid == 0) { SubdCtx c; c.fc = fc; c.s00 = s00; c.pad = 0; ctx[frame] = c; }
+    const int m0 = 256 * (int)blockIdx.x;                                // first decimated sample of this block
+    const int nb = s00 + SUBD_D * (m0 - 1 - SUBD_PAD);                   // full-rate index of LDS block 0 (= decimated block m0 - 1)
+    const float* x = wf + (size_t)frame * FT8RX_NSAMP;
+    for (int i = tid; i < 257 * 32; i += 256) { const int g = nb + i; xs[i + (i >> 5)] = (g >= 0 && g < FT8RX_NSAMP) ? x[g] : 0.0f; }
+    __syncthreads();
+    float sr, si, rr, ri;
+    if (tid == 0) { subd_block(xs, nb, 0, fc, &sr, &si, &rr, &ri); Rs[0] = make_float2(rr, ri); }      // the halo block: only its R is needed
+    subd_block(xs, nb, tid + 1, fc, &sr, &si, &rr, &ri);
+    Rs[tid + 1] = make_float2(rr, ri);
+    __syncthreads();
+    const float2 rp = Rs[tid];
+    zdec[(size_t)frame * SUBD_NZ + m0 + tid] = make_float2(rp.x + 32.0f * sr - rr, rp.y + 32.0f * si - ri);
+}
+
+// grid (ceil(SUBD_N / 256), B): c[m] = conj(model_bb[m]) / (1024 g) -- the correlation weight against z -- for the signal's CURRENT
+// origin (fHz, tsec as refined so far): model_bb[m] = sig[32 m] e^{-2 pi i fc (s0 + 32 m) / fs}, g = the decimator's droop at the current tone
+__global__ __launch_bounds__(256) void k_subd_model(const ft8rx_subsig* __restrict__ sigs, const int32_t* __restrict__ counts, int max_sigs,
+                                                    int s, SubTables T, const SubdCtx* __restrict__ ctx, float2* __restrict__ model /*[B][SUBD_N]*/) {
+    __shared__ ft8rx_subsig S;
+    __shared__ double cum[80];
+    const int frame = blockIdx.y, tid = threadIdx.x;
+    int s0;
+    if (s >= counts[frame]) return;
+    sub_setup(sigs, counts, max_sigs, s, frame, &S, cum, &s0);
+    const int m = 256 * (int)blockIdx.x + tid;
+    if (m >= SUBD_N) return;
+    const int n = SUBD_D * m;
+    float sr, si;
+    sub_signal(S, cum, T, n, &sr, &si);
+    const double fc = ctx[frame].fc;
+    const double rev = fc * ((double)(s0 + n) / 12000.0);              // k_subd_mix mixes with the ABSOLUTE sample index: so must the model,
+    const float fr = (float)(rev - floor(rev));                        // or the amplitude estimate comes out rotated by a constant phase
+    const float cr = __builtin_amdgcn_cosf(fr), ci = __builtin_amdgcn_sinf(fr);
+    // conj(sig e^{-i th}) = conj(sig) e^{+i th}
+    const float mr = sr * cr + si * ci, mi = sr * ci - si * cr;
+    int ih = (n + 1920) / 1920; if (ih > 78) ih = 78;
+    const float g = subd_droop((float)(S.fHz - 0.5 + 6.25 * (double)S.tones[ih] - fc));
+    const float sc = 1.0f / (1024.0f * g);
+    model[(size_t)frame * SUBD_N + m] = make_float2(mr * sc, mi * sc);
+}
+
+// one block per frame: Y[z][c] = sum_{m in chunk c} zdec[SUBD_PAD + off + m + shift_z / 32] c[m], off = (int(12000 tsec) - s00) / 32.
+// Same output layout as k_sub_scan (-> k_sub_pick).  Thread = (chunk, half of the shifts).
+__global__ __launch_bounds__(256) void k_subd_scan(const float2* __restrict__ zdec, const float2* __restrict__ model,
+                                                   const ft8rx_subsig* __restrict__ sigs, const int32_t* __restrict__ counts, int max_sigs,
+                                                   int s, const SubdCtx* __restrict__ ctx, SubShifts sh, double2* __restrict__ scan) {
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    if (s >= counts[frame]) return;
+    const ft8rx_subsig& S = sigs[(size_t)frame * max_sigs + s];
+    const int s0 = (int)(12000.0 * S.tsec);
+    const int off = (s0 - ctx[frame].s00) / SUBD_D;
+    const int c = tid & 127, zh = tid >> 7;
+    const float2* z = zdec + (size_t)frame * SUBD_NZ + SUBD_PAD + off + c * SUBD_CH;
+    const float2* w = model + (size_t)frame * SUBD_N + c * SUBD_CH;
+    float ar[SUB_MAXSHIFT / 2], ai[SUB_MAXSHIFT / 2];
+#pragma unroll
+    for (int q = 0; q < SUB_MAXSHIFT / 2; q++) { ar[q] = 0.0f; ai[q] = 0.0f; }
+    for (int m = 0; m < SUBD_CH; m++) {
+        const float2 wv = w[m];
+#pragma unroll
+        for (int q = 0; q < SUB_MAXSHIFT / 2; q++) {
+            const int zi = 2 * q + zh;
+            const int b0 = s0 + sh.shift[zi < sh.n ? zi : 0];
+            if (zi < sh.n && b0 > 0 && b0 + SUB_L <= FT8RX_NSAMP) {
+                const int idx = m + sh.shift[zi] / SUBD_D;
+                const int lo = -(SUBD_PAD + off + c * SUBD_CH), hi = SUBD_NZ + lo;       // stay inside this frame's zdec row
+                const float2 zv = (idx >= lo && idx < hi) ? z[idx] : make_float2(0.0f, 0.0f);
+                ar[q] += zv.x * wv.x - zv.y * wv.y; ai[q] += zv.x * wv.y + zv.y * wv.x;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SUB_MAXSHIFT / 2; q++) {
+        const int zi = 2 * q + zh;
+        if (zi < sh.n) scan[((size_t)frame * SUB_MAXSHIFT + zi) * SUB_NCH + c] = make_double2((double)ar[q], (double)ai[q]);
+    }
+}
+
+// one block per frame: the 20 low bins of y[m] = zdec[..] c[m] (the complex amplitude), then a(t) on the 375 Hz grid:
+// adec[m] = (32 / 192000) sum_k A_k e^{+2 pi i k 32 m / 192000},  m = 0 .. SUBD_N  (what Receiver.subtract_signal's ifft of the 20
+// kept bins gives at sample 32 m)
+__global__ __launch_bounds__(256) void k_subd_accum(const float2* __restrict__ zdec, const float2* __restrict__ model,
+                                                    const ft8rx_subsig* __restrict__ sigs, const int32_t* __restrict__ counts, int max_sigs,
+                                                    int s, const SubdCtx* __restrict__ ctx, float2* __restrict__ adec /*[B][SUBD_N + 1]*/) {
+    __shared__ double pr[4][20], pi_[4][20];
+    __shared__ float Ar[20], Ai[20];
+    const int frame = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (s >= counts[frame]) return;
+    const ft8rx_subsig& S = sigs[(size_t)frame * max_sigs + s];
+    const int s0 = (int)(12000.0 * S.tsec);
+    const bool ok = s0 > 0 && s0 + SUB_L <= FT8RX_NSAMP;
+    const int off = (s0 - ctx[frame].s00) / SUBD_D;
+    const float2* z = zdec + (size_t)frame * SUBD_NZ + SUBD_PAD + off;
+    const float2* w = model + (size_t)frame * SUBD_N;
+    float fr_[20], fi_[20];
+#pragma unroll
+    for (int k = 0; k < 20; k++) { fr_[k] = 0.0f; fi_[k] = 0.0f; }
+    for (int m = tid; m < SUBD_N; m += 256) {
+        const float2 zv = z[m], wv = w[m];
+        const float yr = zv.x * wv.x - zv.y * wv.y, yi = zv.x * wv.y + zv.y * wv.x;
+        const float rv = (float)(SUBD_D * m) * (1.0f / 192000.0f);
+        const float wr = __builtin_amdgcn_cosf(rv), wi = -__builtin_amdgcn_sinf(rv);
+        float rr = 1.0f, ri = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 20; k++) {
+            fr_[k] += yr * rr - yi * ri; fi_[k] += yr * ri + yi * rr;
+            const float t = rr * wr - ri * wi; ri = rr * wi + ri * wr; rr = t;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 20; k++) {
+        double vr = (double)fr_[k], vi = (double)fi_[k];
+        for (int o = 32; o > 0; o >>= 1) { vr += __shfl_xor(vr, o); vi += __shfl_xor(vi, o); }
+        if (lane == 0) { pr[wave][k] = vr; pi_[wave][k] = vi; }
+    }
+    __syncthreads();
+    if (tid < 20) {
+        const double sc = ok ? (double)SUBD_D / 192000.0 : 0.0;           // each decimated sample stands for 32; ifft scale; nothing to subtract if out of range
+        Ar[tid] = (float)(((pr[0][tid] + pr[1][tid]) + (pr[2][tid] + pr[3][tid])) * sc);
+        Ai[tid] = (float)(((pi_[0][tid] + pi_[1][tid]) + (pi_[2][tid] + pi_[3][tid])) * sc);
+    }
+    __syncthreads();
+    for (int m = tid; m <= SUBD_N; m += 256) {
+        const float rv = (float)(SUBD_D * m) * (1.0f / 192000.0f);
+        const float wr = __builtin_amdgcn_cosf(rv), wi = __builtin_amdgcn_sinf(rv);
+        float rr = 1.0f, ri = 0.0f, er = 0.0f, ei = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 20; k++) {
+            er += Ar[k] * rr - Ai[k] * ri; ei += Ar[k] * ri + Ai[k] * rr;
+            const float t = rr * wr - ri * wi; ri = rr * wi + ri * wr; rr = t;
+        }
+        adec[(size_t)frame * (SUBD_N + 1) + m] = make_float2(er, ei);
+    }
+}
+
+// full rate: x[n] -= 2 Re(a(n) sig[n]) with a(n) interpolated between adec[n / 32] and adec[n / 32 + 1] (beyond the last decimated
+// sample -- the final 128 of the 151 680 -- the last value is held)
+__global__ __launch_bounds__(256) void k_subd_apply(float* __restrict__ wf, const ft8rx_subsig* __restrict__ sigs,
+                                                    const int32_t* __restrict__ counts, int max_sigs, int s, SubTables T,
+                                                    const float2* __restrict__ adec) {
+    __shared__ ft8rx_subsig S;
+    __shared__ double cum[80];
+    const int frame = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int s0;
+    if (!sub_setup(sigs, counts, max_sigs, s, frame, &S, cum, &s0)) return;
+    float* x = wf + (size_t)frame * FT8RX_NSAMP + s0;
+    const float2* a = adec + (size_t)frame * (SUBD_N + 1);
+    for (int i = 0; i < SUB_CPW; i++) {
+        const int ch = (blockIdx.x * 4 + wave) * SUB_CPW + i;
+        for (int m = ch * SUB_CH + lane; m < (ch + 1) * SUB_CH; m += 64) {
+            float sr, si;
+            sub_signal(S, cum, T, m, &sr, &si);
+            int md = m >> 5; if (md > SUBD_N - 1) md = SUBD_N - 1;
+            const float2 a0 = a[md], a1 = a[md + 1];
+            float fq = (float)(m - SUBD_D * md) * (1.0f / 32.0f); if (fq > 1.0f) fq = 1.0f;
+            const float er = a0.x + fq * (a1.x - a0.x), ei = a0.y + fq * (a1.y - a0.y);
+            x[m] = x[m] - 2.0f * (er * sr - ei * si);
+        }
     }
 }
 

@@ -267,6 +267,8 @@ class Receiver:
         self.device = device
         self._h = None
         self._subs = {}                       # handles for search() over other f0 ranges, keyed by (lo, hi)
+        self.subtract_refine = 2              # multi-pass decode: how origins are re-estimated before subtraction (_lib.Handle.subtract):
+                                              # 2 = on a decimated baseband copy (same yield as the full-rate scans of 1, 5x faster)
         self.call_hashes = _lib.CallHashTable()       # persistent across the cycles of the stream (poll); batches use fresh ones
         self._handle(max_frames)                      # fail loudly now if there is no GPU / library
         self.audio_in = AudioIn(search_freq_range, self, input_device_keywords)
@@ -405,7 +407,7 @@ class Receiver:
             sigs = self._subtraction_list(msgs, mcnt, rec, subtract_min_snr)
             if not sigs[1].any():
                 break
-            h.subtract(h.staging_ptr(), B, sigs, refine=True)    # decode_batch left the frames in the handle's device buffer
+            h.subtract(h.staging_ptr(), B, sigs, refine=self.subtract_refine)    # decode_batch left the frames in the handle's device buffer
             h.enqueue(h.staging_ptr(), B)
             rec, cnt, ev, evc = h.fetch(B)
             msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc)
@@ -468,7 +470,7 @@ class Receiver:
             sigs = self._subtraction_list(cur_m, cur_c, cur_rec, subtract_min_snr)
             if not sigs[1].any():
                 break
-            h.subtract(h.staging_ptr(), B, sigs, refine=True)
+            h.subtract(h.staging_ptr(), B, sigs, refine=self.subtract_refine)
             h.enqueue(h.staging_ptr(), B)
             rec2, cnt2, ev2, evc2 = h.fetch(B)
             m2, c2 = _lib.package_batch(rec2, cnt2, ev2, evc2, n_threads=n_threads)

@@ -656,10 +656,17 @@ def test_multi_pass_decode_with_subtraction():
         keep = [d for d in one[f] if " ".join(d["msg_tuple"]) in want[f] and int(d["their_snr"]) > -10]
         tr.append([want[f][" ".join(d["msg_tuple"])] for d in keep])
         sigs.append([(synth.tones79(synth.pack77(*d["msg_tuple"])), d["fHz"], d["tsec"]) for d in keep])
-    _, orig = h.subtract(h.staging_ptr(), n, sigs, refine=True, return_origins=True)
-    dt = np.array([o[1] - t["t0"] for f in range(n) for o, t in zip(orig[f], tr[f])])
-    df = np.array([o[0] - t["f0"] for f in range(n) for o, t in zip(orig[f], tr[f])])
-    assert len(dt) > 15 * n and np.abs(dt).max() < 0.003 and np.abs(df).max() < 0.1, (np.abs(dt).max(), np.abs(df).max())
+    resid = {}
+    for mode in (1, 2):                     # 1 = full-rate scans, 2 = the decimated-baseband path Receiver uses (kernels/subtract.hpp)
+        h.decode_batch(audio)
+        res, orig = h.subtract(h.staging_ptr(), n, sigs, refine=mode, return_origins=True, return_float=True)
+        dt = np.array([o[1] - t["t0"] for f in range(n) for o, t in zip(orig[f], tr[f])])
+        df = np.array([o[0] - t["f0"] for f in range(n) for o, t in zip(orig[f], tr[f])])
+        assert len(dt) > 15 * n and np.abs(dt).max() < 0.003 and np.abs(df).max() < 0.1, (mode, np.abs(dt).max(), np.abs(df).max())
+        resid[mode] = float(res.astype(np.float64).std())
+    rms_in = float(audio.astype(np.float64).std())
+    assert resid[1] < 0.7 * rms_in and abs(resid[2] - resid[1]) < 0.01 * resid[1], (resid, rms_in)      # both cancel equally well
+    assert rx.subtract_refine == 2
     # edge cases: nothing to subtract, a single frame, more passes than there is anything to find, a real recording, late signals
     rx1 = Receiver("", None)
     rng = np.random.default_rng(4)

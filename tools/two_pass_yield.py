@@ -19,7 +19,13 @@ def main():
     want = [{t["msg"] for t in truth[f]} for f in range(n)]
     print(f"{n} frames x {nsig} signals, -10..+10 dB")
     print("passes  true decodes/frame  false/frame   s per batch")
-    for passes, osd in ((1, True), (2, True), (3, True), (2, False), (3, False)):
+    modes = [int(a) for a in sys.argv[3:]] or [rx.subtract_refine]
+    for mode in modes:
+      rx.subtract_refine = mode
+      print(f"-- origin refinement mode {mode} (1 = full-rate scans, 2 = decimated baseband)")
+      for passes, osd in ((1, True), (2, True), (3, True), (2, False), (3, False)):
+        if passes == 1 and mode != modes[0]:
+            continue
         rx.decode_frames(audio[:2], passes=passes)
         t0 = time.perf_counter()
         out = rx.decode_frames(audio, passes=passes, sub_pass_osd=osd)
