@@ -354,12 +354,14 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         if (i == 0 || s > best) { best = s; ft = fcur; }
     }
     fine_fft(S, 182 + ft, z, w400, T, tid, 0, 3200 FT_PASS);   // full series for the 79 x 8 grid
-#pragma unroll FINE_UNROLL_GRID
-    for (int r = 0; r < (316 + FINE_NT - 1) / FINE_NT; r++) {                 // full 79 x 8 grid
-        const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;
-        const bool valid = sy < 79;
+    // the 21 Costas symbols first (84 quad tasks: one round), then the gate; the 58 payload symbols (two rounds) only for the
+    // candidates that pass it -- 59 % of the candidates stop here (tools/ladder_stats.py)
+    {
+        const int q = tid >> 2, n2 = tid & 3;
+        const bool valid = q < 21;
+        const int sy = valid ? 36 * (q / 7) + (q % 7) : 0;
         float mag[8];
-        fine_sym_quad<8>(z, tb0 + tt + 32 * (valid ? sy : 0), n2, wq, mag);
+        fine_sym_quad<8>(z, tb0 + tt + 32 * sy, n2, wq, mag);
         if (valid && n2 == 0) {
 #pragma unroll
             for (int b = 0; b < 8; b++) mg[sy * 8 + b] = mag[b];
@@ -377,6 +379,21 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     if (tid < 64) { int nm = __popcll(__ballot(match)); if (tid == 0) ish[1] = nm; }
     __syncthreads();
     const int nsync = ish[1];
+    if (nsync > 6 || (trip && t_sgrid)) {                                      // block-uniform
+#pragma unroll FINE_UNROLL_GRID
+        for (int r = 0; r < (232 + FINE_NT - 1) / FINE_NT; r++) {             // payload symbols (receiver.py:14)
+            const int task = tid + FINE_NT * r, j = task >> 2, n2 = task & 3;
+            const bool valid = j < 58;
+            const int sy = (int)d_PAYSYM[valid ? j : 0];
+            float mag[8];
+            fine_sym_quad<8>(z, tb0 + tt + 32 * sy, n2, wq, mag);
+            if (valid && n2 == 0) {
+#pragma unroll
+                for (int b = 0; b < 8; b++) mg[sy * 8 + b] = mag[b];
+            }
+        }
+        __syncthreads();
+    }
     if (trip && t_sgrid) for (int i = tid; i < 632; i += FINE_NT) t_sgrid[(size_t)bid * 632 + i] = mg[i];
     int ret = 1; float sd = 0.0f; int snr = 0;
     if (nsync <= 6) ret = 0;           // block-uniform
