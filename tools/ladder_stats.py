@@ -13,7 +13,7 @@ c = Counter()
 for f in range(256):
     r = rec[f, :cnt[f]]
     tot += cnt[f]
-    for s, ip, ap in zip(r["status"], r["ipass"], r["ap"]):
-        c[(int(s), int(ip) if s == 1 else -1, int(ap) if s == 1 else -1)] += 1
-print("candidates", tot)
+    for s, ip, ap, me in zip(r["status"], r["ipass"], r["ap"], r["method"]):
+        c[(int(s), int(ip) if s == 1 else -1, int(ap) if s == 1 else -1, int(me) if s == 1 else -1)] += 1
+print("candidates", tot, " key = (status, ipass, ap, method): status 1 decoded / 2 stop grid sd / 3 stop Costas / 4 stop fine sd / 5 exhausted; method 0 GOOD91, 1 LDPC_A, 2 LDPC_B, 3 OSD, 4 LDPC_B+OSD")
 for k in sorted(c): print(k, c[k])
