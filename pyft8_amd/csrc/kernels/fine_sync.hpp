@@ -15,12 +15,6 @@
 #define FINE_WV 2
 #endif
 #define FINE_INV 0.0003125f
-#ifndef FINE_UNROLL_SCAN
-#define FINE_UNROLL_SCAN 1
-#endif
-#ifndef FINE_UNROLL_GRID
-#define FINE_UNROLL_GRID 1
-#endif
 
 // Timing-only instrumentation (build with -DFINE_TIMING, tools/fine_timing.py; never defined in the product): wave 0 of every block
 // accumulates the shader cycles between consecutive marks into an LDS table and flushes it to g_fine_t[] once at the end.
@@ -117,9 +111,6 @@ FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W
 #pragma unroll
             for (int j = 0; j < 8; j++) z[8 * p + j] = a[i][j];
         }
-#ifdef FINE_S1_SPLIT
-        if (i == 1) __builtin_amdgcn_sched_barrier(0);        // (experiment) two rounds at a time: lower register pressure
-#endif
     }
     FT(1);
     __syncthreads();
@@ -202,12 +193,7 @@ FT8_DEV void fine_stage3(cpx* z, const cpx* __restrict__ W, int tid, int lo, int
     __syncthreads();
     FT(10);
 }
-#ifdef FINE_NOINLINE
-__device__ __attribute__((noinline))
-#else
-FT8_DEV
-#endif
-void fine_fft(const cpx* S, int fb, cpx* z, const cpx* w400, const Tables& T, int tid, int lo, int hi FT_ARG) {
+FT8_DEV void fine_fft(const cpx* S, int fb, cpx* z, const cpx* w400, const Tables& T, int tid, int lo, int hi FT_ARG) {
     FT(0);
     fine_stage1(S, fb, z, T.W3200, T.taper, tid FT_PASS);
     fine_stage2(z, w400, tid FT_PASS);
@@ -230,15 +216,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
                             const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
                             float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
     __shared__ cpx z[3200];
-#ifndef FINE_NO_SLICE
     __shared__ cpx slice[FINE_SLICE];  // the candidate's 1064 spectrum bins, read by the first stage of all ten IFFTs
-#else
-    cpx* slice = z;                    // (experiment) no staging: stage 1 reads the spectrum window from global memory; the LLR scratch aliases z
-#endif
-#ifdef FINE_PAD_LDS                    /* (experiment) fewer k_fine blocks per CU, leaving LDS and registers for other streams' kernels */
-    __shared__ float pad_lds[FINE_PAD_LDS];
-    if (cfg.max_cands < 0) { pad_lds[threadIdx.x * 17 % FINE_PAD_LDS] = 1.0f; __syncthreads(); if (t_sd) t_sd[0] = pad_lds[cfg.max_cands & 1023]; }
-#endif
     __shared__ __attribute__((aligned(8))) float mg[640];   // scoring (on, off) sums as fp64, later the [79][8] grid
     __shared__ cpx w400[400];          // W3200[8 t]: every twiddle of the [4,4] stage
     float* p = reinterpret_cast<float*>(slice);      // [464] the slice is dead once the last IFFT has run: reuse it
@@ -278,18 +256,10 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         }
         __syncthreads();
     }
-#ifndef FINE_NO_SLICE
     const cpx* S = slice;
-#else
-    const cpx* __restrict__ S = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
-#endif
     FT_DECL
-#ifndef FINE_NO_WQ_HOIST
     cpx wq[8];
     sym32_twiddles(w32, tid & 3, wq);                             // every symbol DFT of this thread uses n2 = tid & 3
-#else
-    const cpx* wq = w32 + 0;                                      // (experiment) twiddles re-read from LDS by every symbol DFT
-#endif
     const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);                    // int(0.5 + tsec/0.005) truncates toward zero
     // Score of one Costas block (contract): per symbol a the quad leader forms on_a = |tone costas[a]| and off_a = sum of
     // the other six tones (b ascending) in fp64 from its registers; after ONE barrier every thread combines
@@ -297,7 +267,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     double* dsum = reinterpret_cast<double*>(mg);              // [8][7][2] (on, off); mg is free until the final grid
     // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
     fine_fft(S, 182, z, w400, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43 FT_PASS);   // the 8 time tweaks of the middle Costas block
-#pragma unroll FINE_UNROLL_SCAN
+#pragma unroll 1
     for (int r = 0; r < (224 + FINE_NT - 1) / FINE_NT; r++) {
         const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
         const bool valid = qd < 56;
@@ -380,7 +350,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     __syncthreads();
     const int nsync = ish[1];
     if (nsync > 6 || (trip && t_sgrid)) {                                      // block-uniform
-#pragma unroll FINE_UNROLL_GRID
+#pragma unroll 1
         for (int r = 0; r < (232 + FINE_NT - 1) / FINE_NT; r++) {             // payload symbols (receiver.py:14)
             const int task = tid + FINE_NT * r, j = task >> 2, n2 = task & 3;
             const bool valid = j < 58;
