@@ -774,7 +774,7 @@ int ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t b
 int ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int B, ft8rx_subsig* sigs, const int32_t* counts, int max_sigs,
                    int refine, float* audio_f32_out) {
     if (!h || !d_audio || !sigs || !counts) return -1;
-    if (B < 1 || B > h->max_frames || max_sigs < 1 || max_sigs > 256) { set_err(h, "ft8rx_subtract: bad n_frames / max_sigs"); return -1; }
+    if (B < 1 || B > h->max_frames || max_sigs < 1 || max_sigs > 256 || refine < 0 || refine > 2) { set_err(h, "ft8rx_subtract: bad n_frames / max_sigs / refine"); return -1; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!h->d_wf) {              // first use: working buffers for max_frames frames and the GFSK pulse tables (transmitter.py:41-50)

@@ -256,7 +256,7 @@ static void merge_messages(ft8rx_message* out, int32_t* out_counts, int max_out,
         ft8rx_message* o = out + (size_t)f * max_out;
         const ft8rx_message* a = add + (size_t)f * max_add;
         ft8rx_message* fr = fresh ? fresh + (size_t)f * max_add : nullptr;
-        int n = out_counts[f], nf = 0;
+        int n = out_counts[f] < 0 ? 0 : out_counts[f], nf = 0;
         const int na = add_counts[f] < max_add ? add_counts[f] : max_add;
         for (int i = 0; i < na; i++) {
             if (drop_osd && (a[i].method == FT8RX_M_OSD || a[i].method == FT8RX_M_LDPC_B_OSD)) continue;
