@@ -23,6 +23,12 @@ pytestmark = [pytest.mark.ref, pytest.mark.skipif(not (N and HAVE_REF), reason="
 RECIPES = [dict(n_signals=50, snr_range=(-10.0, 10.0)), dict(n_signals=30, snr_range=(-20.0, 0.0)), dict(n_signals=8, snr_range=(-24.0, -12.0)),
            dict(n_signals=70, snr_range=(-5.0, 15.0)), dict(n_signals=1, snr_range=(0.0, 5.0)), dict(n_signals=0)]
 KWARGS = [dict(), dict(), dict(), dict(sync_score_min=100, max_cands=150), dict(search_freq_range=[300, 2500], search_time_range=[-1.0, 2.0])]
+BASE = 7000000
+if os.environ.get("PYFT8_REF_CROSSCHECK_WIDE"):          # the wide layouts (search ranges beyond 3 kHz): other frames, carriers up to 5.65 kHz
+    KWARGS = [dict(search_freq_range=[100, 5800]), dict(search_freq_range=[2000, 4500], max_cands=120),
+              dict(search_freq_range=[100, 5900], search_time_range=[-1.0, 2.0]), dict(search_freq_range=[100, 4000], sync_score_min=100)]
+    RECIPES = [dict(r, freq_range=(150.0, 5650.0)) for r in RECIPES]
+    BASE = 7300000
 
 
 @pytest.mark.parametrize("k", range(N))
@@ -32,7 +38,7 @@ def test_oracle_equals_reference_on_fresh_frame(k):
     from pyft8_amd import synth
     from pyft8_amd.receiver import config_from_kwargs
     recipe, kw = RECIPES[k % len(RECIPES)], KWARGS[k % len(KWARGS)]
-    audio = synth.make_frame(7000000 + k, **recipe)
+    audio = synth.make_frame(BASE + k, **recipe)
     cands, tr, rx = run_frame(audio, **kw)
     cfg = config_from_kwargs(**kw)
     ocfg = O.default_config(sync_score_min=cfg.sync_score_min, max_cands=cfg.max_cands, f0_lo=cfg.f0_lo, f0_hi=cfg.f0_hi,
