@@ -379,9 +379,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     cpx* A = h->d_A + F * 96000; cpx* spec = h->d_spec + F * FT8RX_SPEC_BINS;
     ft8rx_event* ev = h->s_ev[slot] + F * FT8RX_EVENT_CAP; int32_t* evc = h->s_evcount[slot] + F;
 #define STAGE(name) do { if (prof) { hipEventRecord(h->pev[h->pnames.size()], s); h->pnames.push_back(name); } } while (0)
-    hipMemsetAsync(evc, 0, sizeof(int32_t) * B, s);
-    int32_t* wc = h->d_wcount + WL_N * chunk;
-    hipMemsetAsync(wc, 0, sizeof(int32_t) * WL_N, s);
+    int32_t* wc = h->d_wcount + WL_N * chunk;                      // (evc and wc are zeroed by k_topk)
     WorkList wl[WL_N];
     for (int i = 0; i < WL_N; i++) { wl[i].items = h->d_work[i] + F * MAXC * (i == WL_BP0 ? 5 : 1); wl[i].count = wc + i; }
     STAGE("spectrogram");
@@ -390,7 +388,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
     k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, c);
     STAGE("topk");
-    k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c);
+    k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c, evc, wc);
     STAGE("grid_llr");
     k_grid_llr<<<B * MAXC, 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr, att0, ev, evc);
     k_worklist_att<<<(B * MAXC * 5 + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_BP0]);
@@ -616,7 +614,7 @@ int ft8rx_sync_search(ft8rx_handle* h, const float* grid, int B, int32_t* f0_idx
     HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
     const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
     k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), h->stream>>>(h->d_grid, h->d_best_score, h->d_best_h0, c);
-    k_topk<<<B, 1024, 0, h->stream>>>(h->d_best_score, h->d_best_h0, h->d_rec, h->d_ncand, c);
+    k_topk<<<B, 1024, 0, h->stream>>>(h->d_best_score, h->d_best_h0, h->d_rec, h->d_ncand, c, nullptr, nullptr);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<ft8rx_record> rec((size_t)B * MAXC);
     HIPCHK(h, hipMemcpy(rec.data(), h->d_rec, sizeof(ft8rx_record) * rec.size(), hipMemcpyDeviceToHost));

@@ -73,8 +73,13 @@ __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, fl
 // threshold, stable sort by score descending (ties: f0 ascending = original order), keep max_cands.
 // NF0MAX keys (1024; 2048 in the wide build) on 1024 threads: bitonic network in LDS, KPT compare-exchanges per thread and step.
 __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ best_score, const int32_t* __restrict__ best_h0,
-                                               ft8rx_record* __restrict__ rec, int32_t* __restrict__ ncand, ft8rx_config cfg) {
+                                               ft8rx_record* __restrict__ rec, int32_t* __restrict__ ncand, ft8rx_config cfg,
+                                               int32_t* __restrict__ evcount, int32_t* __restrict__ wcount) {
     constexpr int KPT = NF0MAX / 1024;
+    // the chain's per-frame event counters and its work-list lengths start at zero: cleared here (the first kernel after which they
+    // are used) instead of by two memset launches per chain
+    if (evcount && threadIdx.x == 0) evcount[blockIdx.x] = 0;
+    if (wcount && blockIdx.x == 0 && threadIdx.x < WL_N) wcount[threadIdx.x] = 0;
     __shared__ uint64_t key[NF0MAX];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int nf0 = cfg.f0_hi - cfg.f0_lo;
