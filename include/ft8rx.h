@@ -250,6 +250,11 @@ int  ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int n_frames, ft8rx_subsi
  * refine = 2 (extension): the same re-estimation on a copy of the residual that is mixed down to the signal's centre frequency and
  * decimated by 32 (time grid 2.67 ms): same accuracy and decode yield, a third of the time; the subtraction itself stays at full
  * rate with the exact model.  This is what Receiver's multi-pass decode uses. */
+/* Multi-pass decoding: the signals a subtraction sweep removes = every message of a frame with snr > min_snr, in emit order, with the
+ * tones of its codeword (ft8rx_encode_tones of the candidate's word) and the origin its message dict reports (receiver.py:166).
+ * sigs: [n_frames][max_sigs]; returns the largest per-frame count (or < 0). */
+int  ft8rx_subtraction_list(const ft8rx_message* msgs, const int32_t* counts, int max_msgs, const ft8rx_record* records, int max_cands,
+                            int n_frames, int min_snr, ft8rx_subsig* sigs, int max_sigs, int32_t* sig_counts);
 /* 77-bit words -> the 79 transmitted tones (CRC-14, LDPC(174,91) encode, Gray map, Costas framing; reference
  * transmitter.py:181-223 `encode_bits77`).  Host function, no GPU.  tones: [n][79]. */
 int  ft8rx_encode_tones(const uint64_t* msg_lo, const uint64_t* msg_hi, int n, uint8_t* tones);

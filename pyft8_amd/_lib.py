@@ -522,6 +522,28 @@ def merge_messages(out, out_counts, add, add_counts, pass_tag, drop_osd=False):
     return fresh, fc
 
 
+def subtraction_list(msgs, mcnt, rec, min_snr):
+    """ft8rx_subtraction_list (host only): the signals a subtraction sweep removes -- every message with snr > min_snr, in emit order,
+    as (tones, fHz, tsec).  -> (signals[B, max] of SUBSIG_DTYPE, counts[B])."""
+    import math
+    msgs = np.ascontiguousarray(msgs)
+    rec = np.ascontiguousarray(rec)
+    mcnt = np.ascontiguousarray(mcnt, np.int32)
+    if msgs.dtype != MESSAGE_DTYPE or rec.dtype != RECORD_DTYPE or msgs.shape[0] != rec.shape[0]:
+        raise Ft8rxError("subtraction_list: message / record arrays as returned by package_batch / decode_batch expected")
+    B = msgs.shape[0]
+    cap = max(1, int(mcnt.max()) if B else 1)
+    arr = np.zeros((B, cap), SUBSIG_DTYPE)
+    cnt = np.zeros(B, np.int32)
+    L = lib()
+    L.ft8rx_subtraction_list.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    most = L.ft8rx_subtraction_list(msgs.ctypes.data, mcnt.ctypes.data, int(msgs.shape[1]), rec.ctypes.data, int(rec.shape[1]), int(B),
+                                    int(math.floor(min_snr)), arr.ctypes.data, int(cap), cnt.ctypes.data)
+    if most < 0:
+        raise Ft8rxError(f"ft8rx_subtraction_list failed ({most})")
+    return np.ascontiguousarray(arr[:, :max(1, most)]), cnt
+
+
 _default = {}
 
 

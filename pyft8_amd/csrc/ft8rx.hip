@@ -918,6 +918,12 @@ int ft8rx_merge_messages(ft8rx_message* out, int32_t* out_counts, int max_out, c
     return 0;
 }
 
+int ft8rx_subtraction_list(const ft8rx_message* msgs, const int32_t* counts, int max_msgs, const ft8rx_record* records, int max_cands,
+                           int n_frames, int min_snr, ft8rx_subsig* sigs, int max_sigs, int32_t* sig_counts) {
+    if (!msgs || !counts || !records || !sigs || !sig_counts || n_frames < 0 || max_msgs < 1 || max_cands < 1 || max_sigs < 1) return -1;
+    return hostmsg::subtraction_list(msgs, counts, max_msgs, records, max_cands, n_frames, min_snr, sigs, max_sigs, sig_counts);
+}
+
 ft8rx_hashes* ft8rx_hashes_create(void) { return new (std::nothrow) ft8rx_hashes(); }
 void ft8rx_hashes_destroy(ft8rx_hashes* t) { delete t; }
 int ft8rx_hashes_clear(ft8rx_hashes* t) { if (!t) return -1; t->H.m.clear(); return 0; }

@@ -272,6 +272,31 @@ static void merge_messages(ft8rx_message* out, int32_t* out_counts, int max_out,
         if (fresh_counts) fresh_counts[f] = nf;
     }
 }
+// Input of a subtraction sweep (multi-pass extension): every message of a frame with snr > min_snr, in emit order, as
+// (tones of its codeword, the decoder's origin: fHz = 3.125 f0_idx (+ ftweak / 16), tsec = h0_idx / 25 (+ ttweak / 200) -- the values
+// the message dict reports, receiver.py:166).  -> the largest per-frame count.
+static int subtraction_list(const ft8rx_message* msgs, const int32_t* counts, int max_msgs, const ft8rx_record* records, int max_cands,
+                            int n_frames, int min_snr, ft8rx_subsig* sigs, int max_sigs, int32_t* sig_counts) {
+    int most = 0;
+    for (int f = 0; f < n_frames; f++) {
+        const ft8rx_message* m = msgs + (size_t)f * max_msgs;
+        ft8rx_subsig* o = sigs + (size_t)f * max_sigs;
+        int n = 0;
+        const int nm = counts[f] < max_msgs ? counts[f] : max_msgs;
+        for (int i = 0; i < nm && n < max_sigs; i++) {
+            if ((int)m[i].snr <= min_snr || m[i].cand < 0 || m[i].cand >= max_cands) continue;
+            const ft8rx_record& r = records[(size_t)f * max_cands + m[i].cand];
+            memset(&o[n], 0, sizeof(o[n]));
+            encode_tones(r.msg_lo, r.msg_hi, o[n].tones);
+            o[n].fHz = 3.125 * (double)m[i].f0_idx + (m[i].fine ? (double)m[i].ftweak / 16.0 : 0.0);
+            o[n].tsec = (double)m[i].h0_idx / 25.0 + (m[i].fine ? (double)m[i].ttweak / 200.0 : 0.0);
+            n++;
+        }
+        sig_counts[f] = n;
+        if (n > most) most = n;
+    }
+    return most;
+}
 }  // namespace hostmsg
 
 #endif

@@ -431,7 +431,12 @@ class Receiver:
     @staticmethod
     def _subtraction_list(msgs, mcnt, rec, min_snr):
         """(signals[B, max] of _lib.SUBSIG_DTYPE, counts[B]): every emitted message with snr > min_snr, in emit order, with the
-        tones of its codeword and the decoder's origin (fHz, tsec as the message dict reports them)."""
+        tones of its codeword and the decoder's origin (fHz, tsec as the message dict reports them).  Native (ft8rx_subtraction_list);
+        _subtraction_list_py is its numpy twin."""
+        return _lib.subtraction_list(msgs, mcnt, rec, min_snr)
+
+    @staticmethod
+    def _subtraction_list_py(msgs, mcnt, rec, min_snr):
         B = len(mcnt)
         col = np.arange(msgs.shape[1])[None, :]
         sel = (col < np.asarray(mcnt)[:, None]) & (msgs["snr"] > min_snr)

@@ -58,6 +58,14 @@ int main(int argc, char** argv) {
                 if (bc[1] != MC) return 8;
             }
         }
+        {   // subtraction list of the multi-pass extension: bounded by max_sigs, tolerant of out-of-range candidate indices
+            std::vector<ft8rx_message> ms((size_t)B * MC); std::vector<int32_t> mc(B);
+            if (hostmsg::package_batch(R.data(), std::vector<int32_t>(B, n).data(), E.data(), std::vector<int32_t>(B, nev).data(), B, MC, ms.data(), MC, mc.data(), 2, nullptr, fl.data())) return 3;
+            std::vector<ft8rx_subsig> sg((size_t)B * 4); std::vector<int32_t> sc(B);
+            if (mc[0] > 0) ms[0].cand = 30000;
+            const int most = hostmsg::subtraction_list(ms.data(), mc.data(), MC, R.data(), MC, B, -30, sg.data(), 4, sc.data());
+            if (most > 4 || sc[0] > 4) return 9;
+        }
         printf("frame dump: %d candidates, %d events, %d messages per frame\n", n, nev, (int)(total / B));
     }
     // (b) random words through unpack (all i3 values, hashed calls, boundaries) and the encoder

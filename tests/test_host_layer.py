@@ -64,6 +64,26 @@ def test_merge_messages_native():
     assert txt(out[0], oc[0])[-1] == "W9XYZ K1ABC -05" and int(out[0, 3]["pad"][0]) == 2 and txt(out[1], oc[1]) == ["CQ G4ABC IO91"]
 
 
+def test_subtraction_list_native_equals_numpy_twin():
+    """ft8rx_subtraction_list (host only) against Receiver._subtraction_list_py on the message arrays of the golden frames."""
+    from pyft8_amd import _lib
+    from pyft8_amd.receiver import Receiver
+    names = ["test_09", "synth_100000", "synth_200000"]
+    recs = [records_from_oracle(oracle_frame(load_golden(n)[0])) for n in names]
+    rec = np.stack([r[0] for r in recs]); cnt = np.array([r[1] for r in recs], np.int32)
+    ev = np.zeros((len(names), _lib.EVENT_CAP), _lib.EVENT_DTYPE)
+    for f, r in enumerate(recs):
+        ev[f, :min(len(r[2]), _lib.EVENT_CAP)] = r[2][:_lib.EVENT_CAP]
+    evc = np.array([r[3] for r in recs], np.int32)
+    msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc)
+    for thr in (-10, -30, 3, -10.5):
+        a, ac = _lib.subtraction_list(msgs, mcnt, rec, thr)
+        b, bc = Receiver._subtraction_list_py(msgs, mcnt, rec, thr)
+        assert np.array_equal(ac, bc) and ac.sum() > 0
+        for f in range(len(names)):
+            assert a[f, :ac[f]].tobytes() == b[f, :bc[f]].tobytes()
+
+
 def test_record_layouts_match_header():
     from pyft8_amd import _lib
     assert _lib.RECORD_DTYPE.itemsize == 48 and _lib.EVENT_DTYPE.itemsize == 24

@@ -27,7 +27,7 @@ def main():
     for _ in range(n):
         t0 = time.perf_counter(); rec, cnt, ev, evc = h.decode_batch(audio); tick("pass 1: decode_batch (H2D + kernels + D2H)", t0)
         t0 = time.perf_counter(); msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc); tick("pass 1: package_batch", t0)
-        t0 = time.perf_counter(); sigs = rx._subtraction_list(msgs, mcnt, rec, -10); tick("subtraction list (numpy + encode_tones)", t0)
+        t0 = time.perf_counter(); sigs = rx._subtraction_list(msgs, mcnt, rec, -10); tick("subtraction list (native: ft8rx_subtraction_list)", t0)
         t0 = time.perf_counter(); h.subtract(h.staging_ptr(), B, sigs, refine=rx.subtract_refine); tick("ft8rx_subtract (refine mode %d + subtract, %d sequential signals)" % (rx.subtract_refine, int(sigs[1].max())), t0)
         t0 = time.perf_counter(); h.enqueue(h.staging_ptr(), B); r2 = h.fetch(B); tick("pass 2: kernels + D2H", t0)
         t0 = time.perf_counter(); m2, c2 = _lib.package_batch(*r2); tick("pass 2: package_batch", t0)
