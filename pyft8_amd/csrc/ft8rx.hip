@@ -926,9 +926,9 @@ int ft8rx_subtraction_list(const ft8rx_message* msgs, const int32_t* counts, int
 
 ft8rx_hashes* ft8rx_hashes_create(void) { return new (std::nothrow) ft8rx_hashes(); }
 void ft8rx_hashes_destroy(ft8rx_hashes* t) { delete t; }
-int ft8rx_hashes_clear(ft8rx_hashes* t) { if (!t) return -1; t->H.m.clear(); return 0; }
+int ft8rx_hashes_clear(ft8rx_hashes* t) { if (!t) return -1; t->H.clear(); return 0; }
 int ft8rx_hashes_add(ft8rx_hashes* t, const char* call) { if (!t || !call) return -1; t->H.add(call); return 0; }
-int ft8rx_hashes_size(const ft8rx_hashes* t) { return t ? (int)t->H.m.size() : -1; }
+int ft8rx_hashes_size(const ft8rx_hashes* t) { return t ? (int)t->H.size() : -1; }
 
 int ft8rx_set_reject_log(const char* path) {
     std::lock_guard<std::mutex> lk(hostmsg::g_reject_mu);

@@ -31,8 +31,30 @@ static void log_reject(const std::string& call) {
 static const char A37[] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ";
 static const char A38[] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ/";
 static const char A27[] = " ABCDEFGHIJKLMNOPQRSTUVWXYZ";
+// The call-hash table (databases.py:8-26): key = (number of hash bits, hash) -> callsign, last writer wins.  An open-addressing
+// table of fixed 24-byte entries: every valid callsign of every replayed unpack() call is entered under three keys, so a node-based
+// map spent most of the message layer's time in its allocator.
 struct Hashes {
-    std::unordered_map<uint64_t, std::string> m;                 // key = nbits << 32 | hash
+    struct Entry { uint64_t key; char call[15]; uint8_t len; };   // len = 0xFF: empty slot (keys themselves may be any value)
+    std::vector<Entry> tab;
+    size_t used = 0;
+    Hashes() { tab.resize(1024); clear(); }
+    void clear() { for (auto& e : tab) e.len = 0xFF; used = 0; }
+    size_t size() const { return used; }
+    static size_t slot_of(uint64_t key, size_t cap) { return (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 32) & (cap - 1); }
+    void put(uint64_t key, const std::string& call) {
+        if (2 * (used + 1) > tab.size()) {                        // keep the load factor <= 1/2
+            std::vector<Entry> old; old.swap(tab);
+            tab.resize(old.size() * 2); clear();
+            for (const auto& e : old) if (e.len != 0xFF) put(e.key, std::string(e.call, e.len));
+        }
+        size_t i = slot_of(key, tab.size());
+        while (tab[i].len != 0xFF && tab[i].key != key) i = (i + 1) & (tab.size() - 1);
+        if (tab[i].len == 0xFF) used++;
+        tab[i].key = key;
+        tab[i].len = (uint8_t)(call.size() < sizeof(tab[i].call) ? call.size() : sizeof(tab[i].call));
+        memcpy(tab[i].call, call.data(), tab[i].len);
+    }
     void add(const std::string& call) {
         uint64_t acc = 0;
         for (int i = 0; i < 11; i++) {
@@ -43,9 +65,14 @@ struct Hashes {
         }
         acc *= 47055833459ULL;
         const int nb[3] = {10, 12, 22};
-        for (int k = 0; k < 3; k++) m[((uint64_t)nb[k] << 32) | (acc >> (64 - nb[k]))] = call;
+        for (int k = 0; k < 3; k++) put(((uint64_t)nb[k] << 32) | (acc >> (64 - nb[k])), call);
     }
-    std::string get(uint32_t h, int nb) const { auto it = m.find(((uint64_t)nb << 32) | h); return it == m.end() ? std::string("...") : it->second; }
+    std::string get(uint32_t h, int nb) const {
+        const uint64_t key = ((uint64_t)nb << 32) | h;
+        size_t i = slot_of(key, tab.size());
+        while (tab[i].len != 0xFF) { if (tab[i].key == key) return std::string(tab[i].call, tab[i].len); i = (i + 1) & (tab.size() - 1); }
+        return std::string("...");
+    }
 };
 static std::string strip(const std::string& t) {
     size_t a = 0, b = t.size();
@@ -101,7 +128,7 @@ static bool unpack(uint64_t lo, uint64_t hi, Hashes& H, std::string f[3]) {
         const uint32_t ca = (uint32_t)(((lo >> 48) | (hi << 16)) & 0x1FFFFFFFu), g15 = g16 & 0x7FFFu;
         if (g15 == 0) return false;
         char g[16];
-        if (g15 < 32400) { unsigned q = g15 / 1800, r = g15 % 1800; snprintf(g, sizeof g, "%c%c%02u", 'A' + q, 'A' + r / 100, r % 100); }
+        if (g15 < 32400) { unsigned q = g15 / 1800, r = g15 % 1800; g[0] = (char)('A' + q); g[1] = (char)('A' + r / 100); g[2] = (char)('0' + (r % 100) / 10); g[3] = (char)('0' + r % 10); g[4] = 0; }
         else if (g15 <= 32404) { static const char* T5[5] = {"", "", "RRR", "RR73", "73"}; snprintf(g, sizeof g, "%s", T5[g15 - 32400]); }
         else snprintf(g, sizeof g, "%s%+03d", (g16 >> 15) ? "R" : "", (int)g15 - 32435);
         const bool oka = field29(ca, (int)i3, H, f[0]);
@@ -175,7 +202,7 @@ static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, 
             seen.push_back(text);
             if (nm < cap) {
                 ft8rx_message& o = out[nm]; memset(&o, 0, sizeof(o));
-                snprintf(o.f[0], 16, "%s", got[0].c_str()); snprintf(o.f[1], 16, "%s", got[1].c_str()); snprintf(o.f[2], 16, "%s", got[2].c_str());
+                for (int k = 0; k < 3; k++) { const size_t L = got[k].size() < 15 ? got[k].size() : 15; memcpy(o.f[k], got[k].data(), L); }      // (o is zeroed: NUL-terminated)
                 o.cand = (int16_t)i; o.f0_idx = r.f0_idx; o.h0_idx = r.h0_idx; o.ipass = r.ipass; o.ap = r.ap; o.method = r.method;
                 const bool fine = rnd >= 2;
                 o.fine = fine; o.snr = fine ? r.snr_fine : r.snr_grid; o.ttweak = fine ? r.ttweak : 0; o.ftweak = fine ? r.ftweak : 0;
@@ -228,13 +255,14 @@ static int package_batch(const ft8rx_record* records, const int32_t* counts, con
     if (n_threads < 1 || table) n_threads = 1;
     if (n_threads > n_frames) n_threads = n_frames;
     auto work = [&](int t) {
+        Hashes local;                                             // one table per worker, emptied for every frame
         for (int f = t; f < n_frames; f += n_threads) {
             int fl = 0;
             int nev = event_counts[f];
             if (nev > FT8RX_EVENT_CAP) { nev = FT8RX_EVENT_CAP; fl |= FT8RX_PKG_EVENTS_TRUNCATED; }
             if (nev < 0) nev = 0;
             int n = counts[f] < 0 ? 0 : (counts[f] > max_cands ? max_cands : counts[f]);
-            Hashes local;
+            if (!table) local.clear();
             out_counts[f] = package_frame(records + (size_t)f * max_cands, n, events + (size_t)f * FT8RX_EVENT_CAP, nev,
                                           out + (size_t)f * max_msgs, max_msgs, table ? *table : local, &fl);
             if (flags) flags[f] = fl;

@@ -78,6 +78,6 @@ int main(int argc, char** argv) {
         ok += hostmsg::unpack(lo, hi, H, f);
         if (i % 16 == 0) { hostmsg::encode_tones(lo, hi, tones); acc += tones[40]; }
     }
-    printf("random words: %ld unpacked, %zu hash keys, tone checksum %u\n", ok, H.m.size(), acc);
+    printf("random words: %ld unpacked, %zu hash keys, tone checksum %u\n", ok, H.size(), acc);
     return 0;
 }
