@@ -149,7 +149,7 @@ int  ft8rx_set_streams(ft8rx_handle* h, int n);
  * 0 (default) = in the reference's ladder order (receiver.py:84-98) as three launches, candidates that are decided dropping out in
  *     between -- least work, highest throughput;
  * 1 = all five AP variants in one launch -- one dependent BP instead of three: lower latency for batches too small to fill the GPU
- *     (one frame: 0.41 vs 0.52 ms host to host).  The event log then also holds CRC-passing words of attempts the ladder would not
+ *     (one frame: 0.38 vs 0.49 ms host to host).  The event log then also holds CRC-passing words of attempts the ladder would not
  *     have reached; ft8rx_package_batch skips them. */
 int  ft8rx_set_ladder_mode(ft8rx_handle* h, int mode);
 int  ft8rx_set_profiling(ft8rx_handle* h, int on);
