@@ -225,16 +225,20 @@ def message_dicts(msgs, count, cyclestart_string="", band=None, odd_even=0, on_m
     (receiver.py:57-65).  Same formatting as package_frame above."""
     out = []
     now = time.time()
-    for m in msgs[:min(int(count), len(msgs))]:
-        text = tuple(x.decode() for x in m["f"])
-        fine = bool(m["fine"])
-        tsec = int(m["h0_idx"]) / 25.0
-        fHz = 3.125 * int(m["f0_idx"])
-        if fine:
-            tsec = float(tsec + int(m["ttweak"]) / 200)
-            fHz = float(fHz + int(m["ftweak"]) / 16)
-        snr = "%+03d" % int(m["snr"])
-        rec = {"ipass": int(m["ipass"]), "method": int(m["method"]), "ap": int(m["ap"]), "ttweak": int(m["ttweak"]), "ftweak": int(m["ftweak"])}
+    rows = msgs[:min(int(count), len(msgs))]
+    if len(rows) == 0:
+        return out
+    # whole columns to Python lists first: field access on numpy structured scalars costs more than everything else here
+    cols = [rows[k].tolist() for k in ("f", "h0_idx", "f0_idx", "ttweak", "ftweak", "snr", "ipass", "method", "ap", "fine")]
+    for f3, h0, f0, tt, ft, sn, ipass, method, ap, fn in zip(*cols):
+        text = tuple(x.decode() for x in f3)
+        tsec = h0 / 25.0
+        fHz = 3.125 * f0
+        if fn:
+            tsec = float(tsec + tt / 200)
+            fHz = float(fHz + ft / 16)
+        snr = "%+03d" % sn
+        rec = {"ipass": ipass, "method": method, "ap": ap, "ttweak": tt, "ftweak": ft}
         notes, tw = decode_notes(rec)
         d = {"band": band, "tsec": tsec, "fHz": fHz, "msg_tuple": text, "their_snr": snr, "their_tx_cycle": odd_even,
              "all_txt_format": f"{cyclestart_string} {snr} {(tsec - 0.6):4.1f} {fHz:4.0f} ~ {' '.join(text)}",
