@@ -205,10 +205,12 @@ def main():
         local = local % torch.cuda.device_count()          # flow test: several ranks may share one GPU
     torch.cuda.set_device(local)
     if world > 1:
+        import datetime
+        tmo = datetime.timedelta(seconds=300)      # a rank that dies must not leave the others in a collective for the default 10+ minutes
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
     from pyft8_amd import _lib, messages
     B = args.frames
     cfg = _lib.default_config()
