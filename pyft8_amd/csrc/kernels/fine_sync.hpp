@@ -56,6 +56,36 @@ FT8_DEV cpx fine_conj(cpx v) { return make_float2(v.x, -v.y); }
 //   i = 2 (p <  384): bins p, p+400 (tapered for p >= 350), p+2800 (tapered for p < 350): exactly one of the two is tapered
 //   i = 3 (p <  400): bins p, p+400 (tapered, index p - 350), p+2800 (untapered)
 // Twiddle multiplies are unconditional: W^0 = (1, -0) is an exact identity (the skip rule "j p = 0" of the contract only avoids it).
+// dft<8> (ft8_dev.h) for the two input patterns of this stage, with the additions of exact zeros left out: the non-zero terms go
+// through the same operations in the same order as in the generic butterfly, so every non-zero result is bit-identical (only the
+// sign of an exact zero can differ: x + 0 turns -0 into +0, leaving the term out keeps -0 -- no output can see that).
+//   inputs 0, 1, 2 (round 0):      56 -> 28 flops        inputs 0, 1, 7 (rounds 1..3):      56 -> 32 flops
+FT8_DEV void dft8_in012(cpx* a) {
+    const float h = 0.70710678f;
+    const cpx a0 = a[0], a1 = a[1], a2 = a[2];
+    const cpx e0 = cadd(a0, a2), e2 = csub(a0, a2);
+    const cpx e1 = make_float2(a0.x + a2.y, a0.y - a2.x), e3 = make_float2(a0.x - a2.y, a0.y + a2.x);
+    const cpx o1 = make_float2(h * (a1.x + a1.y), h * (a1.y - a1.x));
+    const cpx o2 = make_float2(a1.y, -a1.x);
+    const cpx o3 = make_float2(o1.y, -o1.x);                     // = (h (a1.y - a1.x), -(h (a1.x + a1.y)))
+    a[0] = cadd(e0, a1); a[4] = csub(e0, a1);
+    a[1] = cadd(e1, o1); a[5] = csub(e1, o1);
+    a[2] = cadd(e2, o2); a[6] = csub(e2, o2);
+    a[3] = cadd(e3, o3); a[7] = csub(e3, o3);
+}
+FT8_DEV void dft8_in017(cpx* a) {
+    const float h = 0.70710678f;
+    const cpx a0 = a[0], a1 = a[1], a7 = a[7];
+    const cpx q0 = cadd(a1, a7), q2 = csub(a1, a7);
+    const cpx q1 = make_float2(a1.x - a7.y, a1.y + a7.x), q3 = make_float2(a1.x + a7.y, a1.y - a7.x);
+    const cpx o1 = make_float2(h * (q1.x + q1.y), h * (q1.y - q1.x));
+    const cpx o2 = make_float2(q2.y, -q2.x);
+    const cpx o3 = make_float2(h * (q3.y - q3.x), -(h * (q3.x + q3.y)));
+    a[0] = cadd(a0, q0); a[4] = csub(a0, q0);
+    a[1] = cadd(a0, o1); a[5] = csub(a0, o1);
+    a[2] = cadd(a0, o2); a[6] = csub(a0, o2);
+    a[3] = cadd(a0, o3); a[7] = csub(a0, o3);
+}
 static_assert(FINE_NT == 128, "fine_stage1 is written for 128 threads");
 FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W,
                          const double* __restrict__ taper, int tid FT_ARG) {
@@ -104,7 +134,7 @@ FT8_DEV void fine_stage1(const cpx* S, int fb, cpx* z, const cpx* __restrict__ W
         cpx w[8];
 #pragma unroll
         for (int j = 1; j < 8; j++) w[j] = W[j * pw];
-        dft<8>(a[i]);
+        if (i == 0) dft8_in012(a[i]); else dft8_in017(a[i]);     // which inputs exist is static per round (above)
 #pragma unroll
         for (int j = 1; j < 8; j++) a[i][j] = cmul(a[i][j], w[j]);
         if (i < 3 || r3) {
