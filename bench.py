@@ -48,9 +48,10 @@ ALG_FLOP_FRAME = 1.3e9
 ALG_FLOP_FINE = 0.78e9
 VALU_PEAK_TFLOPS = 157.3
 # executed fp32 operations of k_fine per candidate (counted from the kernel's butterflies): a pruned scoring IFFT
-# 150 k (sparse radix-8 pass 39 k + [4,4] stage 54 k + [5,5] stage with the last pass pruned 57 k), the full final IFFT 170 k, a
-# 32-point symbol DFT on a lane quad 0.6 k: 150 k + 56 x 0.6 k + 8 x (150 k + 7 x 0.6 k) + 170 k + 79 x 0.6 k
-EXEC_FLOP_FINE_CAND = 150e3 + 56 * 0.6e3 + 8 * (150e3 + 7 * 0.6e3) + 170e3 + 79 * 0.6e3
+# 140 k (radix-8 pass with its zero inputs left out 29 k + [4,4] stage 54 k + [5,5] stage with the last pass pruned 57 k), the full
+# final IFFT 160 k, a 32-point symbol DFT on a lane quad 0.6 k; final grid: 21 Costas symbols always, the 58 payload symbols for the
+# 41 % of candidates that pass the gate (45 symbols on average): 140 k + 56 x 0.6 k + 8 x (140 k + 7 x 0.6 k) + 160 k + 45 x 0.6 k
+EXEC_FLOP_FINE_CAND = 140e3 + 56 * 0.6e3 + 8 * (140e3 + 7 * 0.6e3) + 160e3 + 45 * 0.6e3
 PMC_PROFILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
                                                                   # command (tools/pmc_summary.py), B = 256
 
