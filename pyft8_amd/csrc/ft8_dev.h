@@ -35,6 +35,26 @@ FT8_DEV float ft8_log10f(float x) {
     return fe * 0.301025390625f + (fe * 4.6050390e-6f + lnm * 0.4342945f);
 }
 
+// The same function for arguments known to be positive, normal and finite (2^-126 <= x <= 3e38): the three range checks above are
+// dead code for them and cost two divergent branches per call.  The spectrogram's argument is |X| + 1e-12 with |X| <= 32768 x 3840.
+FT8_DEV float ft8_log10f_normal(float x) {
+    const uint32_t ix = __float_as_uint(x);
+    int e = (int)(ix >> 23) - 127;
+    float m = __uint_as_float((ix & 0x007fffffu) | 0x3f800000u);
+    const bool big = m > 1.41421356f;
+    m = big ? m * 0.5f : m; e += big ? 1 : 0;
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.11111111f;
+    p = p * s2 + 0.14285715f;
+    p = p * s2 + 0.2f;
+    p = p * s2 + 0.33333334f;
+    p = p * s2 + 1.0f;
+    float lnm = (2.0f * s) * p;
+    float fe = (float)e;
+    return fe * 0.301025390625f + (fe * 4.6050390e-6f + lnm * 0.4342945f);
+}
+
 // single-branch clamped rational (no divergence inside a wavefront): x P(x^2) / Q(x^2), one IEEE division
 FT8_DEV float ft8_tanhf(float x) {
     float xc = x;                    // NaN fails both clamps and propagates through P / Q (the oracle returns x itself: same NaN-ness)
