@@ -218,6 +218,12 @@ int  ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, con
  * drop_osd != 0 ignores the later pass's OSD decodes (first CRC-valid trial wins there: the source of false decodes). */
 int  ft8rx_merge_messages(ft8rx_message* out, int32_t* out_counts, int max_out, const ft8rx_message* add, const int32_t* add_counts,
                           int max_add, int n_frames, int pass_tag, int drop_osd, ft8rx_message* fresh, int32_t* fresh_counts);
+/* The whole drop-in in one call -- what a compiled-language binding (cgo / JNI / N-API) would bind: host audio [n_frames][180000]
+ * int16 in, the frames' messages out (Receiver's on_message payloads before string formatting, in the reference's emit order):
+ * ft8rx_decode_batch followed by ft8rx_package_batch on the handle's own result buffers.  out: [n_frames][max_msgs] (max_msgs >=
+ * cfg.max_cands rules truncation out); n_threads / table / flags as for ft8rx_package_batch. */
+int  ft8rx_decode_messages(ft8rx_handle* h, const int16_t* audio, int n_frames, ft8rx_message* out, int max_msgs, int32_t* out_counts,
+                           int n_threads, ft8rx_hashes* table, int32_t* flags);
 /* the persistent call-hash table (databases.py:8-26 `call_hashes` + add_call_hashes) */
 ft8rx_hashes* ft8rx_hashes_create(void);
 void ft8rx_hashes_destroy(ft8rx_hashes* t);

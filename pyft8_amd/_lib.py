@@ -177,6 +177,25 @@ class Handle:
         self._chk(rc, "ft8rx_decode_batch")
         return rec, cnt, ev, evc
 
+    def decode_messages(self, audio, max_msgs=None, n_threads=None, table=None):
+        """ft8rx_decode_messages: host audio -> (messages[B, max_msgs] of MESSAGE_DTYPE, counts[B]) in one native call."""
+        audio = np.ascontiguousarray(audio, np.int16)
+        if audio.ndim == 1:
+            audio = audio[None]
+        B = audio.shape[0]
+        if audio.shape[1] != NSAMP or B > self.max_frames:
+            raise Ft8rxError(f"audio must be [n<={self.max_frames}, {NSAMP}] int16, got {audio.shape}")
+        max_msgs = int(max_msgs or max(1, self.cfg.max_cands))
+        out = np.zeros((B, max_msgs), MESSAGE_DTYPE)
+        oc = np.zeros(B, np.int32)
+        flags = np.zeros(B, np.int32)
+        L = self._L
+        L.ft8rx_decode_messages.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self._chk(L.ft8rx_decode_messages(self._h, audio.ctypes.data, int(B), out.ctypes.data, max_msgs, oc.ctypes.data,
+                                          int(n_threads or min(32, os.cpu_count() or 1)), table._t if table is not None else None,
+                                          flags.ctypes.data), "ft8rx_decode_messages")
+        return out, oc
+
     def enqueue(self, d_audio_ptr, B):
         self._chk(self._L.ft8rx_enqueue_batch(self._h, C.c_void_p(d_audio_ptr), int(B)), "ft8rx_enqueue_batch")
 

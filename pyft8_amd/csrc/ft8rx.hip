@@ -583,6 +583,21 @@ int ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_recor
     return ft8rx_fetch_results(h, B, records, counts, events, event_counts);
 }
 
+// One call from host audio to rendered messages: ft8rx_decode_batch + ft8rx_package_batch without the intermediate copies (the
+// packager reads the handle's page-locked result buffers in place).
+int ft8rx_decode_messages(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_message* out, int max_msgs, int32_t* out_counts,
+                          int n_threads, ft8rx_hashes* table, int32_t* flags) {
+    if (!h || !audio || !out || !out_counts) return -1;
+    if (B < 1 || B > h->max_frames || max_msgs < 1) { set_err(h, "ft8rx_decode_messages: bad n_frames / max_msgs"); return -1; }
+    h->inflight = 0; h->slot_fetch = h->slot_enq;                     // synchronous entry: nothing older is kept
+    int rc = launch_batch(h, h->d_audio, audio, B);
+    if (rc) return rc;
+    const ft8rx_record* rec; const int32_t* cnt; const ft8rx_event* ev; const int32_t* evc;
+    rc = ft8rx_fetch_results_view(h, B, &rec, &cnt, &ev, &evc);
+    if (rc) return rc;
+    return hostmsg::package_batch(rec, cnt, ev, evc, B, h->cfg.max_cands, out, max_msgs, out_counts, n_threads, table ? &table->H : nullptr, flags);
+}
+
 // ---------------------------------------------------------------------------- stage entry points
 #define NEED(p) do { if (!(p)) { set_err(h, "scratch allocation/copy failed (%s:%d)", __FILE__, __LINE__); return -2; } } while (0)
 

@@ -946,6 +946,19 @@ def test_repeatable_across_runs_and_stream_counts(ocfg):
             assert rec[f][:cnt[f]].tobytes() == outs[0][0][f][:cnt[f]].tobytes()
 
 
+def test_decode_messages_single_call(H):
+    """ft8rx_decode_messages (audio -> messages in one native call) == ft8rx_decode_batch + ft8rx_package_batch."""
+    from pyft8_amd import _lib
+    audio = np.stack([load_golden(n)[0] for n in ("test_09", "synth_100000", "test_08")])
+    rec, cnt, ev, evc = H.decode_batch(audio)
+    want, wc = _lib.package_batch(rec, cnt, ev, evc)
+    got, gc = H.decode_messages(audio)
+    assert np.array_equal(gc, wc) and gc.sum() > 40
+    for f in range(3):
+        assert got[f, :gc[f]].tobytes() == want[f, :wc[f]].tobytes()
+    assert [b" ".join(m["f"]).decode() for m in got[0, :gc[0]]] == [" ".join(m["msg_tuple"]) for m in load_golden("test_09")[2]["messages"]]
+
+
 def test_ladder_modes_give_the_same_records_and_messages():
     """ft8rx_set_ladder_mode: fine-stage BP in ladder order (three launches, default) vs all five AP variants in one launch --
     identical records and rendered messages; the one-launch event log is a superset (attempts the ladder would not have reached)."""
