@@ -143,6 +143,53 @@ def cpu_baseline(frames, budget_s=15.0):
     return out
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def place_rank(local_rank, world, bus_id_of):
+    """Pin this rank (and every thread it starts later: the packaging pool, RCCL's and HIP's helper threads) to its own slice of host
+    cores -- on the NUMA node of its GPU when sysfs says which one that is -- so that eight ranks do not float over both sockets and
+    page-locked buffers allocated afterwards are first-touched next to the GPU that reads them.  bus_id_of(r) -> PCI address of rank
+    r's GPU (or None).  -> a dict describing the placement (it goes into the JSON line).  Never fatal."""
+    info = {"cpus": None, "numa_node": None, "how": "unpinned"}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+
+        def node_of(r):
+            bdf = bus_id_of(r)
+            path = f"/sys/bus/pci/devices/{bdf.lower()}/numa_node" if bdf else None
+            return int(open(path).read().strip()) if path and os.path.exists(path) else None
+        nodes = [node_of(r) for r in range(world)]
+        node = nodes[local_rank]
+        info["gpu_pci"] = bus_id_of(local_rank)
+        node_cpus = None
+        lst = f"/sys/devices/system/node/node{node}/cpulist" if node is not None and node >= 0 else None
+        if lst and os.path.exists(lst):
+            node_cpus = [c for c in _cpulist(open(lst).read()) if c in allowed]
+        if node_cpus:
+            peers = [r for r in range(world) if nodes[r] == node]          # ranks whose GPUs hang off the same node share its cores
+            k, n = peers.index(local_rank), len(peers)
+            per = max(1, len(node_cpus) // n)
+            mine = node_cpus[k * per:(k + 1) * per] or node_cpus
+            info.update(numa_node=node, how=f"slice {k + 1}/{n} of NUMA node {node}")
+        else:
+            per = max(1, len(allowed) // max(1, world))
+            mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+            info.update(how=f"slice {local_rank + 1}/{world} of the {len(allowed)} allowed cores (no NUMA node known for the GPU)")
+        os.sched_setaffinity(0, mine)
+        info["cpus"] = f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else ",".join(map(str, mine))
+        info["n_cpus"] = len(mine)
+    except Exception as e:                                   # placement is an optimisation
+        info["how"] = f"unpinned ({type(e).__name__}: {e})"
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +202,9 @@ def main():
     ap.add_argument("--no-host-entry", action="store_true", help="skip the informational host-pointer (PCIe-inclusive) passes, whose "
                     "chunked launches would mix part-batch kernels into a rocprofv3 per-kernel average")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for flow tests on one GPU)")
+    ap.add_argument("--force-gather", action="store_true", help="run the gather collectives even with one rank (a one-rank process group is "
+                    "initialised): the RCCL device path on a one-GPU box")
+    ap.add_argument("--no-pin", action="store_true", help="leave the rank's CPU affinity alone")
     ap.add_argument("--share-gpu", action="store_true", help="flow tests on a box with fewer GPUs than ranks: rank r uses device r %% device_count "
                     "(gloo always does this; RCCL itself refuses two ranks on one device)")
     ap.add_argument("--signals", type=int, default=50, help="signals per synthetic frame (config 1/2: 50, config 4: <= 10)")
@@ -205,6 +255,22 @@ def main():
     if args.backend != "nccl" or args.share_gpu:
         local = local % torch.cuda.device_count()          # flow test: several ranks may share one GPU
     torch.cuda.set_device(local)
+    # CPU/NUMA placement before anything allocates page-locked memory or starts threads (the handle, the packaging pool)
+    from pyft8_amd import _lib, messages
+    placement = {"how": "unpinned (--no-pin)"}
+    orig_affinity = os.sched_getaffinity(0)
+    if not args.no_pin:
+        ndev = max(1, torch.cuda.device_count())
+        placement = place_rank(int(os.environ.get("LOCAL_RANK", "0")), world, lambda r: _lib.device_pci_bus_id(r % ndev))
+    if world == 1 and args.force_gather:
+        import datetime
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        kw = dict(device_id=torch.device("cuda", local)) if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                timeout=datetime.timedelta(seconds=300), **kw)
     if world > 1:
         import datetime
         tmo = datetime.timedelta(seconds=300)      # a rank that dies must not leave the others in a collective for the default 10+ minutes
@@ -212,7 +278,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
         else:
             dist.init_process_group(args.backend, timeout=tmo)
-    from pyft8_amd import _lib, messages
     B = args.frames
     cfg = _lib.default_config()
     if args.bp_iters is not None:
@@ -251,8 +316,8 @@ def main():
     # One step = one batch through the whole path: kernels on the GPU, results to the host (double-buffered D2H on a copy stream)
     # and the native host message layer (every message tuple rendered), pipelined: while batch k computes, the host fetches and
     # packages batch k-1.  All K batches are fully decoded to message arrays inside the timed region.
-    cores = os.cpu_count() or 8
-    pk_threads = max(2, min(32, cores // max(1, world)))
+    cores = len(os.sched_getaffinity(0))                   # this rank's slice after place_rank
+    pk_threads = max(2, min(32, cores if not args.no_pin else cores // max(1, world)))
 
     def run_steps(n):
         msgs = None
@@ -287,10 +352,16 @@ def main():
         h.enqueue(d_audio.data_ptr(), B)
     h.sync()
     kernel_only = B * args.steps / (time.perf_counter() - t1)
-    t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+    cdev = "cuda" if args.backend == "nccl" else "cpu"
+    t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+    own = torch.tensor([dt, kernel_only], device=cdev, dtype=torch.float64)       # this rank's own clock, for the per-rank table
+    per_rank_raw = [own]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank_raw = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(per_rank_raw, own)
     dt = float(t.item())
+    per_rank_raw = [[float(x) for x in r.tolist()] for r in per_rank_raw]
 
     # per-kernel timing (HIP events on the library's stream), outside the timed region
     h.set_profiling(True)
@@ -344,24 +415,38 @@ def main():
 
     # gather path (RCCL): per-rank fixed-capacity record blocks to rank 0 -- off the timed path
     gather_note = "single rank"
-    if world > 1:
+    gather_ms = None
+    if world > 1 or args.force_gather:
         from pyft8_amd.distributed import gather_results, gather_results_device
         try:
-            t3 = time.perf_counter()
-            if args.backend == "nccl":           # device-resident: D2D into torch buffers, RCCL gather over xGMI, one D2H on rank 0
-                allres = gather_results_device(h, B, dst=0)
-            else:
-                allres = gather_results(rec, cnt, ev, evc, dst=0)
-            torch.cuda.synchronize()
-            gather_note = (f"records/events of {world} ranks gathered to rank 0 over {args.backend}"
-                           f"{' (device-resident buffers)' if args.backend == 'nccl' else ''} in {1e3 * (time.perf_counter() - t3):.1f} ms")
-            if rank == 0 and not (np.array_equal(allres[1][:B], cnt) and np.array_equal(allres[0][:B], rec)):
-                gather_note = "gather mismatch: rank 0's own block differs from its local results"
+            gather_ms = []
+            for _ in range(2):                       # first call: communicator set-up included; second: the steady-state cost
+                barrier()
+                t3 = time.perf_counter()
+                if args.backend == "nccl":           # device-resident: D2D into torch buffers, RCCL gather over xGMI, one D2H on rank 0
+                    allres = gather_results_device(h, B, dst=0, force=args.force_gather)
+                else:
+                    allres = gather_results(rec, cnt, ev, evc, dst=0, force=args.force_gather)
+                torch.cuda.synchronize()
+                gather_ms.append(1e3 * (time.perf_counter() - t3))
+            gather_note = (f"records/events of {world} rank{'s' if world > 1 else ' (forced)'} gathered to rank 0 over {args.backend}"
+                           f"{' (device-resident buffers)' if args.backend == 'nccl' else ''} in {gather_ms[-1]:.1f} ms "
+                           f"(first call {gather_ms[0]:.1f} ms)")
+            if rank == 0:
+                # (the gathered batch is a later decode of the same audio: records are deterministic, the order of a frame's log is not)
+                same_ev = all(sorted(allres[2][f, :min(int(evc[f]), ev.shape[1])].tolist()) == sorted(ev[f, :min(int(evc[f]), ev.shape[1])].tolist())
+                              for f in range(min(B, 64)))
+                if not (np.array_equal(allres[1][:B], cnt) and allres[0][:B].tobytes() == rec.tobytes() and np.array_equal(allres[3][:B], evc) and same_ev):
+                    gather_note = "gather mismatch: rank 0's own block differs from its local results"
             if rank == 0 and allres[0].shape[0] != world * B:
                 gather_note = f"gather returned {allres[0].shape[0]} frames, expected {world * B}"
         except Exception as e:                    # the gather is validation outside the timed region: report, do not lose the line
             gather_note = f"gather failed: {type(e).__name__}: {e}"
 
+    placements = [placement]
+    if world > 1:
+        placements = [None] * world
+        dist.all_gather_object(placements, placement)
     if rank == 0:
         dom = max(acc, key=acc.get)
         dom_ms = acc[dom]
@@ -407,12 +492,18 @@ def main():
                                           "fine sync 0.78 G of 18 full IFFTs); the kernels execute fewer (10 pruned IFFTs) and, by the "
                                           "bit-exact arithmetic contract, without FMA contraction"}},
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
+            # each rank's own clock over the K timed steps (value uses the max), its kernels-only rate, and where it ran
+            "per_rank": {"ms_per_step": [round(1e3 * r[0] / args.steps, 4) for r in per_rank_raw],
+                         "frames_per_s": [round(B * args.steps / r[0], 1) for r in per_rank_raw],
+                         "kernel_only_frames_per_s": [round(r[1], 1) for r in per_rank_raw],
+                         "placement": placements, "gather_ms": gather_ms},
         }
         if not args.no_cpu_baseline:
             # the CPU oracle timed on this box's host cores: rank 0 at N = 1 only (the contract); null in multi-GPU runs
+            os.sched_setaffinity(0, orig_affinity)      # the CPU baseline may use every host core, not this rank's slice
             line["cpu_baseline"] = cpu_baseline(frames) if world == 1 else None
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     h.close()

@@ -104,6 +104,9 @@ int  ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_han
 void ft8rx_destroy(ft8rx_handle* h);
 const char* ft8rx_last_error(ft8rx_handle* h);                      /* h may be NULL: last create error */
 int  ft8rx_device_count(void);
+/* PCI address of a device ("0000:c1:00.0"; buf >= 16 bytes): lets a multi-rank host place each rank's threads and page-locked
+ * buffers on the GPU's NUMA node (/sys/bus/pci/devices/<address>/numa_node), as bench.py does */
+int  ft8rx_device_pci_bus_id(int device, char* buf, int len);
 /* the compile-time widths of the loaded library (FT8RX_GRID_COLS, FT8RX_SPEC_BINS, FT8RX_MAX_F0): 976 / 49152 / 960, or
  * 1920 / 96000 / 1888 for the wide build */
 int  ft8rx_build_info(int32_t* grid_cols, int32_t* spec_bins, int32_t* max_f0);
@@ -132,6 +135,10 @@ int  ft8rx_enqueue_batch_host(ft8rx_handle* h, const int16_t* audio, int n_frame
 int  ft8rx_sync(ft8rx_handle* h);
 int  ft8rx_fetch_results(ft8rx_handle* h, int n_frames, ft8rx_record* records, int32_t* counts,
                          ft8rx_event* events, int32_t* event_counts);
+/* Only events[f][0 .. min(event_counts[f], FT8RX_EVENT_CAP)) are written / valid -- here, in the view below and in
+ * ft8rx_decode_batch; the rest of a frame's row is left as it was.  For batches whose event log exceeds 1 MB the fetch copies the log
+ * device-to-host itself, after the counts have arrived, and only the columns in use (the log is 12 KB per frame, a tenth of it
+ * used): eight ranks sharing the host links move ~15 MB instead of 100 MB per 8192-frame shard. */
 /* Zero-copy variant of ft8rx_fetch_results: waits for the same batch and returns pointers INTO the handle's page-locked result
  * buffers (records packed [n_frames][cfg.max_cands], events [n_frames][FT8RX_EVENT_CAP]).  They stay valid until two more
  * batches have been enqueued (the slot is then reused). */

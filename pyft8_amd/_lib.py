@@ -113,6 +113,14 @@ def default_config(**kw):
     return c
 
 
+def device_pci_bus_id(device):
+    """PCI address ("0000:c1:00.0") of HIP device `device` (ft8rx_device_pci_bus_id), or None."""
+    buf = C.create_string_buffer(64)
+    L = lib()
+    L.ft8rx_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    return buf.value.decode() if L.ft8rx_device_pci_bus_id(int(device), buf, 64) == 0 else None
+
+
 def fft_plans():
     ps = [(C.c_int32 * 8)() for _ in range(4)]
     lib().ft8rx_get_fft_plans(*ps)

@@ -77,6 +77,7 @@ struct ft8rx_handle {
     hipStream_t sub[8];
     hipEvent_t ev_fork, ev_join[8];
     hipStream_t copy_s;              // host-to-device chunk copies of ft8rx_decode_batch, in order, never queued behind kernels
+    hipStream_t evcopy_s;            // second step of a large batch's result copy: the used part of the event log (fetch_events)
     hipEvent_t ev_chunk[16];
     Tables T;
     std::vector<void*> allocs;
@@ -102,6 +103,7 @@ struct ft8rx_handle {
     ft8rx_record* h_rec[2]; int32_t* h_cnt[2]; ft8rx_event* h_ev[2]; int32_t* h_evc[2];
     hipEvent_t ev_comp[2], ev_done[2];
     int slot_enq, slot_fetch, inflight, last_slot, slot_B[2];
+    bool slot_evpending[2];          // the slot's event log has not been copied yet: fetch copies the used rows only (fetch_events)
     // signal subtraction (extension, allocated on first use): float32 working copy, per-chunk partial sums, GFSK tables
     float* d_wf; double2* d_part; double* d_pulse; double* d_pc; ft8rx_subsig* d_sigs; int32_t* d_sigcnt; int sig_cap;
     float2 *d_zdec, *d_model, *d_adec; SubdCtx* d_subctx;      // decimated-baseband refinement (refine = 2), allocated on first use
@@ -171,6 +173,10 @@ int ft8rx_default_config(ft8rx_config* c) {
 }
 
 int ft8rx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int ft8rx_device_pci_bus_id(int device, char* buf, int len) {
+    if (!buf || len < 16) return -1;
+    return hipDeviceGetPCIBusId(buf, len, device) == hipSuccess ? 0 : -2;
+}
 int ft8rx_build_info(int32_t* grid_cols, int32_t* spec_bins, int32_t* max_f0) {
     static_assert(NF0MAX >= FT8RX_GRID_COLS && NF0MAX >= FT8RX_MAX_F0, "per-f0 scratch stride");
     if (grid_cols) *grid_cols = FT8RX_GRID_COLS;
@@ -198,6 +204,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
     for (auto e : h->pev) hipEventDestroy(e);
     for (int i = 0; i < 8; i++) { if (h->sub[i]) hipStreamDestroy(h->sub[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     if (h->copy_s) hipStreamDestroy(h->copy_s);
+    if (h->evcopy_s) hipStreamDestroy(h->evcopy_s);
     if (h->h2d_s) hipStreamDestroy(h->h2d_s);
     for (int i = 0; i < 16; i++) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -227,7 +234,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     ft8rx_handle* h = new ft8rx_handle();
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
     h->n_streams = 2; h->ladder_mode = 0; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
-    h->copy_s = nullptr; h->h2d_s = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
+    h->copy_s = nullptr; h->evcopy_s = nullptr; h->slot_evpending[0] = h->slot_evpending[1] = false; h->h2d_s = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
     for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
@@ -337,6 +344,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
         okc = okc && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
     okc = okc && hipStreamCreateWithFlags(&h->copy_s, hipStreamNonBlocking) == hipSuccess;
+    okc = okc && hipStreamCreateWithFlags(&h->evcopy_s, hipStreamNonBlocking) == hipSuccess;
     okc = okc && hipStreamCreateWithFlags(&h->h2d_s, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 16; i++) okc = okc && hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
     okc = okc && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -363,6 +371,7 @@ int ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms
 #ifndef LADDER_GRID_CAP
 #define LADDER_GRID_CAP (4 * 256 * 32)
 #endif
+#define EV_EAGER_BYTES ((size_t)1 << 20)      /* event logs up to this size travel with the records (launch_batch) */
 // ladder kernels launch a bounded grid that strides over their work list (a few items per block at most): enough blocks to fill the
 // chip four times over, never more than there can be items
 static int ladder_grid(int max_items) { const int cap = LADDER_GRID_CAP; return max_items < cap ? max_items : cap; }
@@ -491,9 +500,32 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     HIPCHK(h, hipMemcpy2DAsync(h->h_rec[slot], sizeof(ft8rx_record) * mc, h->s_rec[slot], sizeof(ft8rx_record) * MAXC,
                                sizeof(ft8rx_record) * mc, B, hipMemcpyDeviceToHost, h->copy_s));
     HIPCHK(h, hipMemcpyAsync(h->h_evc[slot], h->s_evcount[slot], sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->copy_s));
-    HIPCHK(h, hipMemcpyAsync(h->h_ev[slot], h->s_ev[slot], sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP, hipMemcpyDeviceToHost, h->copy_s));
+    // The event log is [B][FT8RX_EVENT_CAP] x 24 B = 12 KB per frame of which a frame typically uses a tenth (config 1: ~40 events).
+    // Small batches copy it whole (one round trip: the latency case); large ones leave it to the fetch, which knows the counts by
+    // then and copies only the used columns (fetch_events) -- 100 MB -> ~15 MB per 8192-frame shard on the host link.
+    h->slot_evpending[slot] = (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES;
+    if (!h->slot_evpending[slot])
+        HIPCHK(h, hipMemcpyAsync(h->h_ev[slot], h->s_ev[slot], sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP, hipMemcpyDeviceToHost, h->copy_s));
     HIPCHK(h, hipEventRecord(h->ev_done[slot], h->copy_s));
     h->slot_B[slot] = B; h->last_slot = slot; h->slot_enq ^= 1; h->inflight++;
+    return 0;
+}
+
+// Second step of a large batch's result copy (launch_batch): the per-frame event counts have arrived, so only the columns in use --
+// max over the batch's frames of min(count, cap) -- are copied, as one 2-D copy with the same [frame][FT8RX_EVENT_CAP] layout on both
+// sides.  Rows beyond a frame's count are not written (consumers read events[f][0 .. min(event_counts[f], cap)) only).  The copy has
+// its own stream: the result-copy stream may already be queued behind the next batch's kernels.
+static int fetch_events(ft8rx_handle* h, int slot) {
+    if (!h->slot_evpending[slot]) return 0;
+    const int B = h->slot_B[slot];
+    int used = 0;
+    for (int f = 0; f < B; f++) { int c = h->h_evc[slot][f]; if (c > FT8RX_EVENT_CAP) c = FT8RX_EVENT_CAP; if (c > used) used = c; }
+    if (used > 0) {
+        HIPCHK(h, hipMemcpy2DAsync(h->h_ev[slot], sizeof(ft8rx_event) * FT8RX_EVENT_CAP, h->s_ev[slot], sizeof(ft8rx_event) * FT8RX_EVENT_CAP,
+                                   sizeof(ft8rx_event) * (size_t)used, B, hipMemcpyDeviceToHost, h->evcopy_s));
+        HIPCHK(h, hipStreamSynchronize(h->evcopy_s));
+    }
+    h->slot_evpending[slot] = false;
     return 0;
 }
 
@@ -531,11 +563,15 @@ int ft8rx_fetch_results(ft8rx_handle* h, int B, ft8rx_record* records, int32_t* 
     const int slot = h->inflight ? h->slot_fetch : h->last_slot;      // oldest unfetched batch, else the latest one again
     if (B > h->slot_B[slot]) { set_err(h, "ft8rx_fetch_results: %d frames requested, the batch had %d", B, h->slot_B[slot]); return -1; }
     HIPCHK(h, hipEventSynchronize(h->ev_done[slot]));
+    if (events) { const int rc = fetch_events(h, slot); if (rc) return rc; }
     const size_t mc = (size_t)h->cfg.max_cands;
     if (counts) memcpy(counts, h->h_cnt[slot], sizeof(int32_t) * B);
     if (records) memcpy(records, h->h_rec[slot], sizeof(ft8rx_record) * mc * B);
     if (event_counts) memcpy(event_counts, h->h_evc[slot], sizeof(int32_t) * B);
-    if (events) memcpy(events, h->h_ev[slot], sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP);
+    if (events) for (int f = 0; f < B; f++) {              // the used entries of each frame; the rest of the caller's row is left alone
+        int c = h->h_evc[slot][f]; if (c > FT8RX_EVENT_CAP) c = FT8RX_EVENT_CAP;
+        if (c > 0) memcpy(events + (size_t)f * FT8RX_EVENT_CAP, h->h_ev[slot] + (size_t)f * FT8RX_EVENT_CAP, sizeof(ft8rx_event) * (size_t)c);
+    }
     if (h->inflight) { h->slot_fetch ^= 1; h->inflight--; }
     return 0;
 }
@@ -548,6 +584,7 @@ int ft8rx_fetch_results_view(ft8rx_handle* h, int B, const ft8rx_record** record
     const int slot = h->inflight ? h->slot_fetch : h->last_slot;
     if (B > h->slot_B[slot]) { set_err(h, "ft8rx_fetch_results_view: %d frames requested, the batch had %d", B, h->slot_B[slot]); return -1; }
     HIPCHK(h, hipEventSynchronize(h->ev_done[slot]));
+    if (events) { const int rc = fetch_events(h, slot); if (rc) return rc; }
     if (records) *records = h->h_rec[slot];
     if (counts) *counts = h->h_cnt[slot];
     if (events) *events = h->h_ev[slot];

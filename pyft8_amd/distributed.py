@@ -58,19 +58,38 @@ def _gather_bytes(arr, dst, group):
     return np.concatenate(parts)
 
 
-def gather_results(rec, cnt, ev, evc, dst=0, group=None):
+def _used_events(evc, cap, dev, group):
+    """Event-log columns in use anywhere in the job: max over all ranks and frames of min(event_count, cap).  One all_reduce."""
+    t = torch.clamp(evc.to(torch.int64).max() if evc.numel() else torch.zeros((), dtype=torch.int64, device=dev), 0, cap).reshape(1).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+def gather_results(rec, cnt, ev, evc, dst=0, group=None, force=False):
     """Per-rank (records[B_r, max_cands], counts[B_r], events[B_r, CAP], event_counts[B_r]) -> on `dst` the
-    concatenation over ranks in rank order (= global frame order for shard()); None elsewhere."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    concatenation over ranks in rank order (= global frame order for shard()); None elsewhere.  Only the event-log columns in use
+    travel; the rest of each returned row is zero.  force=True runs the collectives even in a one-rank group (tests)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return rec, cnt, ev, evc
-    outs = [_gather_bytes(a, dst, group) for a in (rec, cnt, ev, evc)]
-    return tuple(outs) if dist.get_rank(group) == dst else None
+    used = _used_events(torch.from_numpy(np.ascontiguousarray(evc)), ev.shape[1], _device(), group)
+    outs = [_gather_bytes(a, dst, group) for a in (rec, cnt, ev[:, :max(used, 1)], evc)]
+    if dist.get_rank(group) != dst:
+        return None
+    full = np.zeros((outs[2].shape[0], ev.shape[1]), ev.dtype)
+    full[:, :outs[2].shape[1]] = outs[2]
+    return outs[0], outs[1], full, outs[3]
 
 
-def gather_results_device(handle, n_frames, dst=0, group=None):
-    """RCCL gather of the handle's latest batch straight from device memory (backend nccl).  -> like gather_results."""
+def gather_results_device(handle, n_frames, dst=0, group=None, force=False):
+    """RCCL gather of the handle's latest batch straight from device memory (backend nccl).  -> like gather_results.
+    force=True runs the whole device path (D2D into torch buffers, RCCL all_gather / gather, one D2H on dst) even in a one-rank
+    group: that is how the path is exercised on a one-GPU test box."""
     from . import _lib
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
+        if force:
+            raise _lib.Ft8rxError("gather_results_device(force=True) needs an initialised process group")
+        return handle.fetch(n_frames)
+    if dist.get_world_size(group) == 1 and not force:
         return handle.fetch(n_frames)
     if dist.get_backend(group) != "nccl":
         raise _lib.Ft8rxError("gather_results_device needs the nccl (RCCL) backend; use gather_results with gloo")
@@ -80,12 +99,18 @@ def gather_results_device(handle, n_frames, dst=0, group=None):
     bufs = [torch.empty(s, dtype=torch.uint8, device=dev) for s in shapes]
     handle.results_to_device(B, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr())
     counts = _counts(B, dev, group)
+    # only the event-log columns in use cross xGMI and PCIe (the log is [B][512] x 24 B, typically a tenth used)
+    used = max(1, _used_events(bufs[3].view(torch.int32).reshape(-1), _lib.EVENT_CAP, dev, group))
+    bufs[2] = bufs[2][:, :used * _lib.EVENT_DTYPE.itemsize].contiguous()
     outs = [_gather_rows(b, counts, dst, group) for b in bufs]
     if dist.get_rank(group) != dst:
         return None
-    dts = [(_lib.RECORD_DTYPE, (mc,)), (np.dtype(np.int32), ()), (_lib.EVENT_DTYPE, (_lib.EVENT_CAP,)), (np.dtype(np.int32), ())]
+    dts = [(_lib.RECORD_DTYPE, (mc,)), (np.dtype(np.int32), ()), (_lib.EVENT_DTYPE, (used,)), (np.dtype(np.int32), ())]
     res = []
     for out, (dt, tail) in zip(outs, dts):
         parts = [o[:c].cpu().numpy().reshape(-1).view(dt).reshape((c,) + tail) for o, c in zip(out, counts)]
         res.append(np.concatenate(parts))
+    full = np.zeros((res[2].shape[0], _lib.EVENT_CAP), _lib.EVENT_DTYPE)
+    full[:, :used] = res[2]
+    res[2] = full
     return tuple(res)

@@ -58,17 +58,70 @@ def test_two_ranks_one_gpu_gloo():
     assert d["value"] > 500
 
 
-def test_two_ranks_one_gpu_nccl_or_skip():
+def test_rccl_gather_path_two_ranks_or_forced_single_rank():
+    """The RCCL branch of bench.py (nccl process group, ft8rx_results_to_device -> all_reduce / all_gather / gather on device
+    tensors -> one D2H on rank 0): two ranks where the box has two GPUs; on a one-GPU box (RCCL refuses two ranks on one device) the
+    same collectives run in a ONE-rank nccl group (--force-gather) -- no skip either way."""
     import torch
-    share = [] if torch.cuda.device_count() >= 2 else ["--share-gpu"]
-    out = _launch(2, ["--backend", "nccl"] + share + SMALL)
-    if out.returncode != 0:
-        err = out.stderr + out.stdout
-        if share and any(k in err for k in ("Duplicate GPU", "duplicate GPU", "invalid usage", "ncclInvalidUsage", "NCCL error", "ncclUnhandledCudaError")):
-            pytest.skip("RCCL refuses two ranks on one device (expected on a 1-GPU box); the nccl branch needs >= 2 GPUs")
-        assert False, err[-3000:]
-    d = _one_line(out)
-    assert d["n_gpus"] == 2 and "gathered to rank 0 over nccl (device-resident buffers)" in d["config"]["gather"], d["config"]["gather"]
+    if torch.cuda.device_count() >= 2:
+        out = _launch(2, ["--backend", "nccl"] + SMALL)
+        assert out.returncode == 0, (out.stderr + out.stdout)[-3000:]
+        d = _one_line(out)
+        assert d["n_gpus"] == 2 and "gathered to rank 0 over nccl (device-resident buffers)" in d["config"]["gather"], d["config"]["gather"]
+        assert len(d["per_rank"]["frames_per_s"]) == 2 and len(d["per_rank"]["placement"]) == 2
+    else:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--force-gather",
+                              "--no-cpu-baseline"] + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                             env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+        assert out.returncode == 0, (out.stderr + out.stdout)[-3000:]
+        d = _one_line(out)
+        assert "1 rank (forced) gathered to rank 0 over nccl (device-resident buffers)" in d["config"]["gather"], d["config"]["gather"]
+        assert len(d["per_rank"]["gather_ms"]) == 2 and d["per_rank"]["placement"][0]["how"]
+
+
+_NCCL_ONE_RANK = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from pyft8_amd import _lib
+from pyft8_amd.distributed import gather_results_device, gather_results
+B = 320                                             # > 1 MB of event log: the two-step (used columns only) result copy
+h = _lib.Handle(max_frames=B)
+ptr = h.staging_ptr()
+h.synth_frames(ptr, 5100000, B, n_signals=50, snr_range=(-10.0, 10.0))
+h.enqueue(ptr, B)
+got = gather_results_device(h, B, dst=0, force=True)          # D2D -> RCCL all_reduce / all_gather / gather on CUDA tensors -> D2H
+want = h.fetch(B)
+assert int(want[1].sum()) > 50 * B and int(want[3].max()) > 20
+assert got[0].tobytes() == want[0].tobytes() and np.array_equal(got[1], want[1]) and np.array_equal(got[3], want[3])
+for f in range(B):
+    n = min(int(want[3][f]), _lib.EVENT_CAP)
+    assert got[2][f, :n].tobytes() == want[2][f, :n].tobytes(), f
+via_host = gather_results(*want, dst=0, force=True)             # host arrays through the same backend (one H2D per array)
+assert via_host[0].tobytes() == want[0].tobytes() and np.array_equal(via_host[1], want[1])
+# a zero-copy view of the same batch is the same bytes
+h.enqueue(ptr, B)
+v = h.fetch_view(B)
+assert v[0].tobytes() == want[0].tobytes()
+for f in range(B):
+    n = min(int(v[3][f]), _lib.EVENT_CAP)
+    assert sorted(v[2][f, :n].tolist()) == sorted(want[2][f, :n].tolist()), f        # (log order inside a frame is not deterministic)
+dist.barrier(); dist.destroy_process_group(); h.close()
+print("RCCL_ONE_RANK_OK")
+'''
+
+
+def test_rccl_device_gather_byte_equal_single_rank_group(tmp_path):
+    """A real config-1 batch through ft8rx_results_to_device -> RCCL collectives on CUDA tensors -> D2H, in a one-rank nccl group:
+    byte-identical to fetch().  This is the code the 8-GPU run of configs 3/4 executes; it had never run on any machine."""
+    script = tmp_path / "nccl_one_rank.py"
+    script.write_text(_NCCL_ONE_RANK)
+    out = subprocess.run([sys.executable, str(script), ROOT, str(_port())], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout + out.stderr)[-3000:]
 
 
 def test_bench_gpus_flag_starts_the_launcher_itself():

@@ -181,6 +181,34 @@ def test_gather_two_ranks_gloo(tmp_path):
     assert res == want
 
 
+def test_gather_forced_single_rank_gloo_roundtrips_bytes():
+    """force=True runs the collectives in a one-rank group (the way the RCCL path is exercised on a one-GPU box): the gathered
+    records / counts / used event rows are byte-identical to the inputs, and only the event columns in use travelled."""
+    import torch.distributed as dist
+    from pyft8_amd import _lib
+    from pyft8_amd.distributed import gather_results
+    rng = np.random.default_rng(5)
+    B, mc = 6, 200
+    rec = np.frombuffer(rng.bytes(B * mc * _lib.RECORD_DTYPE.itemsize), _lib.RECORD_DTYPE).reshape(B, mc).copy()
+    ev = np.frombuffer(rng.bytes(B * _lib.EVENT_CAP * _lib.EVENT_DTYPE.itemsize), _lib.EVENT_DTYPE).reshape(B, _lib.EVENT_CAP).copy()
+    cnt = rng.integers(0, mc, B).astype(np.int32)
+    evc = np.array([0, 3, 41, 600, 7, 0], np.int32)              # one frame over the cap
+    assert gather_results(rec, cnt, ev, evc)[2] is ev             # no group: pass-through
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1)
+    try:
+        assert gather_results(rec, cnt, ev, evc)[2] is ev         # one rank, not forced: pass-through
+        r2, c2, e2, ec2 = gather_results(rec, cnt, ev, evc, force=True)
+        assert r2.tobytes() == rec.tobytes() and np.array_equal(c2, cnt) and np.array_equal(ec2, evc) and e2.shape == ev.shape
+        for f in range(B):
+            n = min(int(evc[f]), _lib.EVENT_CAP)
+            assert e2[f, :n].tobytes() == ev[f, :n].tobytes()
+        evc[3] = 50
+        e3 = gather_results(rec, cnt, ev, evc, force=True)[2]
+        assert e3[:, :50].tobytes() == ev[:, :50].tobytes() and not np.ascontiguousarray(e3[:, 50:]).view(np.uint8).any()       # columns past the used ones stayed home
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("name", GOLDEN_FRAMES)
 def test_native_packager_matches_python_and_reference(name):
     """ft8rx_package_batch (C++, pure host) == messages.package_frame (Python) == the reference's dicts."""
