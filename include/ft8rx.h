@@ -136,9 +136,9 @@ int  ft8rx_sync(ft8rx_handle* h);
 int  ft8rx_fetch_results(ft8rx_handle* h, int n_frames, ft8rx_record* records, int32_t* counts,
                          ft8rx_event* events, int32_t* event_counts);
 /* Only events[f][0 .. min(event_counts[f], FT8RX_EVENT_CAP)) are written / valid -- here, in the view below and in
- * ft8rx_decode_batch; the rest of a frame's row is left as it was.  For batches whose event log exceeds 1 MB the fetch copies the log
- * device-to-host itself, after the counts have arrived, and only the columns in use (the log is 12 KB per frame, a tenth of it
- * used): eight ranks sharing the host links move ~15 MB instead of 100 MB per 8192-frame shard. */
+ * ft8rx_decode_batch; the rest of a frame's row is left as it was.  For batches whose event log exceeds 1 MB the log is packed on
+ * the device (it is 12 KB per frame, a tenth of it used) and 80 entries per frame travel with the records; a batch that logged more
+ * gets the rest in its fetch: eight ranks sharing the host links move 16 MB instead of 100 MB per 8192-frame shard. */
 /* Zero-copy variant of ft8rx_fetch_results: waits for the same batch and returns pointers INTO the handle's page-locked result
  * buffers (records packed [n_frames][cfg.max_cands], events [n_frames][FT8RX_EVENT_CAP]).  They stay valid until two more
  * batches have been enqueued (the slot is then reused). */
@@ -170,6 +170,12 @@ int  ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row);
 /* Receiver.search (receiver.py:338-367): per frame <= max_cands (f0,h0,score), sorted */
 int  ft8rx_sync_search(ft8rx_handle* h, const float* grid, int n_frames,
                        int32_t* f0_idx, int32_t* h0_idx, float* score, int32_t* counts);
+/* The inner loops of Receiver.search (receiver.py:341-349) for ANY f0 index range [f0_lo, f0_hi) the grid can hold (4 <= f0_lo,
+ * f0_hi <= FT8RX_GRID_COLS - 15), whatever range the handle was created for: per frame and f0 the first strict maximum of the Costas
+ * score over the handle's h0 range, starting from 0 -- score [n][f0_hi - f0_lo] and its h0 (0 / 0 where no score is positive).  The
+ * threshold, stable sort and cut (receiver.py:350-367) are the caller's; Receiver.search uses this for `search_f_idxs` lists that
+ * are not the configured range. */
+int  ft8rx_sync_scores(ft8rx_handle* h, const float* grid, int n_frames, int f0_lo, int f0_hi, float* score, int32_t* h0_idx);
 /* Candidate._get_llr_grid/_dB_to_llr (receiver.py:136-138, 208-222) for n (frame,f0,h0) triples */
 int  ft8rx_llr_grid(ft8rx_handle* h, const float* grid, int n_frames, int n, const int32_t* frame,
                     const int32_t* f0_idx, const int32_t* h0_idx, float* llr /*[n][174]*/, float* sd, int32_t* snr);

@@ -45,6 +45,7 @@ ST_ACTIVE, ST_DECODED, ST_STOP_GRID_SD, ST_STOP_COSTAS, ST_STOP_FINE_SD, ST_EXHA
 M_GOOD91, M_LDPC_A, M_LDPC_B, M_OSD, M_LDPC_B_OSD = range(5)
 
 _libs = {}
+_reject_log = [None]                  # set_reject_log's current path: applied to builds loaded later as well
 
 
 class Ft8rxError(RuntimeError):
@@ -102,6 +103,9 @@ def lib(wide=False):
         if (gc.value, sb.value, mf.value) != want:
             raise Ft8rxError(f"{path} was built with layouts {(gc.value, sb.value, mf.value)}, expected {want}")
         _libs[wide] = L
+        if _reject_log[0]:                                   # a reject log set before this build was loaded applies to it too
+            L.ft8rx_set_reject_log.argtypes = [C.c_char_p]
+            L.ft8rx_set_reject_log(_reject_log[0].encode())
     return _libs[wide]
 
 
@@ -185,8 +189,9 @@ class Handle:
         self._chk(rc, "ft8rx_decode_batch")
         return rec, cnt, ev, evc
 
-    def decode_messages(self, audio, max_msgs=None, n_threads=None, table=None):
-        """ft8rx_decode_messages: host audio -> (messages[B, max_msgs] of MESSAGE_DTYPE, counts[B]) in one native call."""
+    def decode_messages(self, audio, max_msgs=None, n_threads=None, table=None, return_flags=False):
+        """ft8rx_decode_messages: host audio -> (messages[B, max_msgs] of MESSAGE_DTYPE, counts[B]) in one native call.  An
+        overflowed event log or message list is warned about (Ft8rxTruncationWarning) and reported per frame with return_flags."""
         audio = np.ascontiguousarray(audio, np.int16)
         if audio.ndim == 1:
             audio = audio[None]
@@ -202,7 +207,8 @@ class Handle:
         self._chk(L.ft8rx_decode_messages(self._h, audio.ctypes.data, int(B), out.ctypes.data, max_msgs, oc.ctypes.data,
                                           int(n_threads or min(32, os.cpu_count() or 1)), table._t if table is not None else None,
                                           flags.ctypes.data), "ft8rx_decode_messages")
-        return out, oc
+        _warn_truncation(flags, "decode_messages")
+        return (out, oc, flags) if return_flags else (out, oc)
 
     def enqueue(self, d_audio_ptr, B):
         self._chk(self._L.ft8rx_enqueue_batch(self._h, C.c_void_p(d_audio_ptr), int(B)), "ft8rx_enqueue_batch")
@@ -298,6 +304,16 @@ class Handle:
         self._chk(self._L.ft8rx_sync_search(self._h, _ptr(grid, C.c_float), B, _ptr(f0, C.c_int32), _ptr(h0, C.c_int32),
                                           _ptr(sc, C.c_float), _ptr(cnt, C.c_int32)), "ft8rx_sync_search")
         return f0, h0, sc, cnt
+
+    def sync_scores(self, grid, f0_lo, f0_hi):
+        """ft8rx_sync_scores: per frame and f0 in [f0_lo, f0_hi) the best Costas score (first strict maximum over h0, from 0) and its h0."""
+        grid = self._grid(grid)
+        B, n = grid.shape[0], int(f0_hi) - int(f0_lo)
+        sc = np.zeros((B, max(n, 1)), np.float32); h0 = np.zeros((B, max(n, 1)), np.int32)
+        L = self._L
+        L.ft8rx_sync_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self._chk(L.ft8rx_sync_scores(self._h, grid.ctypes.data, B, int(f0_lo), int(f0_hi), sc.ctypes.data, h0.ctypes.data), "ft8rx_sync_scores")
+        return sc, h0
 
     def llr_grid(self, grid, frame, f0, h0):
         grid = self._grid(grid)
@@ -488,10 +504,21 @@ class CallHashTable:
 
 
 def set_reject_log(path):
-    """Turn the reference's rejected_callsigns.txt side effect (decoders.py:114-115) on (path) or off (None)."""
-    L = lib()
-    L.ft8rx_set_reject_log.argtypes = [C.c_char_p]
-    L.ft8rx_set_reject_log(path.encode() if path else None)
+    """Turn the reference's rejected_callsigns.txt side effect (decoders.py:114-115) on (path) or off (None) -- in every loaded build
+    of the library (the packager inside Handle.decode_messages is the wide build's own copy on a wide handle)."""
+    _reject_log[0] = path
+    lib()
+    for L in _libs.values():
+        L.ft8rx_set_reject_log.argtypes = [C.c_char_p]
+        L.ft8rx_set_reject_log(path.encode() if path else None)
+
+
+def _warn_truncation(flags, who):
+    if flags.any():
+        import warnings
+        nev, nmsg = int((flags & PKG_EVENTS_TRUNCATED != 0).sum()), int((flags & PKG_MSG_TRUNCATED != 0).sum())
+        warnings.warn(f"{who}: event log overflowed in {nev} frame(s) (> {EVENT_CAP} CRC-passing words: `<...>` strings may differ), "
+                      f"message list truncated in {nmsg} frame(s)", Ft8rxTruncationWarning, stacklevel=3)
 
 
 def package_batch(rec, cnt, ev, evc, max_msgs=None, n_threads=None, table=None, return_flags=False):
@@ -520,11 +547,7 @@ def package_batch(rec, cnt, ev, evc, max_msgs=None, n_threads=None, table=None, 
                                int(max_msgs), oc.ctypes.data, int(n_threads), table._t if table is not None else None, flags.ctypes.data)
     if rc != 0:
         raise Ft8rxError(f"ft8rx_package_batch failed ({rc})")
-    if flags.any():
-        import warnings
-        nev, nmsg = int((flags & PKG_EVENTS_TRUNCATED != 0).sum()), int((flags & PKG_MSG_TRUNCATED != 0).sum())
-        warnings.warn(f"package_batch: event log overflowed in {nev} frame(s) (> {EVENT_CAP} CRC-passing words: `<...>` strings may differ), "
-                      f"message list truncated in {nmsg} frame(s)", Ft8rxTruncationWarning, stacklevel=2)
+    _warn_truncation(flags, "package_batch")
     return (out, oc, flags) if return_flags else (out, oc)
 
 

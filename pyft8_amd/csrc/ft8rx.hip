@@ -47,6 +47,8 @@
 #include "host_messages.hpp"
 
 // ====================================================================================== host side
+#define EV_EAGER_BYTES ((size_t)1 << 20)      /* event logs up to this size travel whole with the records (launch_batch) */
+#define EV_PREFIX 80                          /* larger ones: this many compacted entries per frame travel with the records; the rest, if any, on fetch */
 #define HIPCHK(h, x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_err(h, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); return -2; } } while (0)
 
 // OSD trial list in the reference's order (decoders.py:248-272): order 0; single flips i < S; the restricted double flips
@@ -103,7 +105,10 @@ struct ft8rx_handle {
     ft8rx_record* h_rec[2]; int32_t* h_cnt[2]; ft8rx_event* h_ev[2]; int32_t* h_evc[2];
     hipEvent_t ev_comp[2], ev_done[2];
     int slot_enq, slot_fetch, inflight, last_slot, slot_B[2];
-    bool slot_evpending[2];          // the slot's event log has not been copied yet: fetch copies the used rows only (fetch_events)
+    // Large batches (event log > EV_EAGER_BYTES): the log is compacted on the device (k_ev_scan / k_ev_compact), a fixed prefix of
+    // the compact buffer travels with the records, and the fetch scatters it into h_ev's [frame][cap] rows (fetch_events)
+    bool slot_evpending[2];
+    ft8rx_event* d_evc[2]; int32_t* d_evoffs[2]; ft8rx_event* h_evc_compact[2];
     // signal subtraction (extension, allocated on first use): float32 working copy, per-chunk partial sums, GFSK tables
     float* d_wf; double2* d_part; double* d_pulse; double* d_pc; ft8rx_subsig* d_sigs; int32_t* d_sigcnt; int sig_cap;
     float2 *d_zdec, *d_model, *d_adec; SubdCtx* d_subctx;      // decimated-baseband refinement (refine = 2), allocated on first use
@@ -151,9 +156,17 @@ struct Scratch {
         bytes = (bytes + 255) & ~(size_t)255;
         if (!bytes) bytes = 256;
         for (auto& c : h->arena) if (c.cap - c.used >= bytes) { void* q = (char*)c.p + c.used; c.used += bytes; return q; }
-        const size_t cap = bytes > ((size_t)1 << 20) ? bytes : ((size_t)1 << 20);
+        // miss: a new chunk, grown geometrically (twice the largest so far) so that a sequence of calls with growing n settles after
+        // O(log n) allocations; chunks no call is using any more are released first instead of piling up until ft8rx_destroy
+        size_t largest = 0;
+        for (auto& c : h->arena) if (c.cap > largest) largest = c.cap;
+        size_t cap = bytes > 2 * largest ? bytes : 2 * largest;
+        if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
+        for (size_t i = 0; i < h->arena.size();) {
+            if (h->arena[i].used == 0) { hipFree(h->arena[i].p); h->arena.erase(h->arena.begin() + i); } else i++;
+        }
         void* q = nullptr;
-        if (hipMalloc(&q, cap) != hipSuccess) return nullptr;
+        if (hipMalloc(&q, cap) != hipSuccess) { if (cap == bytes || hipMalloc(&q, bytes) != hipSuccess) return nullptr; cap = bytes; }
         h->arena.push_back({q, cap, bytes});
         return q;
     }
@@ -215,6 +228,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
         if (h->h_cnt[k]) hipHostFree(h->h_cnt[k]);
         if (h->h_ev[k]) hipHostFree(h->h_ev[k]);
         if (h->h_evc[k]) hipHostFree(h->h_evc[k]);
+        if (h->h_evc_compact[k]) hipHostFree(h->h_evc_compact[k]);
     }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -235,7 +249,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
     h->n_streams = 2; h->ladder_mode = 0; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
     h->copy_s = nullptr; h->evcopy_s = nullptr; h->slot_evpending[0] = h->slot_evpending[1] = false; h->h2d_s = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
-    for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->slot_B[k] = 0; }
+    for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->h_evc_compact[k] = nullptr; h->d_evc[k] = nullptr; h->d_evoffs[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
     h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr;
@@ -265,11 +279,14 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     rc |= dalloc(h, &h->s_ncand[1], B);
     rc |= dalloc(h, &h->s_ev[1], B * FT8RX_EVENT_CAP);
     rc |= dalloc(h, &h->s_evcount[1], B);
+    const bool ev_compact = B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES;
+    for (int k = 0; k < 2 && ev_compact; k++) { rc |= dalloc(h, &h->d_evc[k], B * FT8RX_EVENT_CAP); rc |= dalloc(h, &h->d_evoffs[k], B + 1); }
     for (int k = 0; k < 2 && !rc; k++) {
         bool okh = hipHostMalloc((void**)&h->h_rec[k], sizeof(ft8rx_record) * B * cfg->max_cands, hipHostMallocDefault) == hipSuccess;
         okh = okh && hipHostMalloc((void**)&h->h_cnt[k], sizeof(int32_t) * B, hipHostMallocDefault) == hipSuccess;
         okh = okh && hipHostMalloc((void**)&h->h_ev[k], sizeof(ft8rx_event) * B * FT8RX_EVENT_CAP, hipHostMallocDefault) == hipSuccess;
         okh = okh && hipHostMalloc((void**)&h->h_evc[k], sizeof(int32_t) * B, hipHostMallocDefault) == hipSuccess;
+        if (ev_compact) okh = okh && hipHostMalloc((void**)&h->h_evc_compact[k], sizeof(ft8rx_event) * B * FT8RX_EVENT_CAP, hipHostMallocDefault) == hipSuccess;
         if (!okh) { set_err(h, "ft8rx_create: page-locked result buffers (%zu frames) could not be allocated", B); rc = -2; }
     }
     if (rc) { g_create_err = h->err; ft8rx_destroy(h); return -2; }
@@ -371,7 +388,7 @@ int ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms
 #ifndef LADDER_GRID_CAP
 #define LADDER_GRID_CAP (4 * 256 * 32)
 #endif
-#define EV_EAGER_BYTES ((size_t)1 << 20)      /* event logs up to this size travel with the records (launch_batch) */
+
 // ladder kernels launch a bounded grid that strides over their work list (a few items per block at most): enough blocks to fill the
 // chip four times over, never more than there can be items
 static int ladder_grid(int max_items) { const int cap = LADDER_GRID_CAP; return max_items < cap ? max_items : cap; }
@@ -494,6 +511,10 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     HIPCHK(h, hipGetLastError());
     // results -> page-locked host buffers on the copy stream (overlaps the next batch, which computes into the other slot)
     const int mc = h->cfg.max_cands;
+    if (h->d_evc[slot] && (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES) {      // pack the event log (see the copy below)
+        k_ev_scan<<<1, 1024, 0, h->stream>>>(h->s_evcount[slot], B, h->d_evoffs[slot]);
+        k_ev_compact<<<B, 64, 0, h->stream>>>(h->s_ev[slot], h->s_evcount[slot], h->d_evoffs[slot], h->d_evc[slot]);
+    }
     HIPCHK(h, hipEventRecord(h->ev_comp[slot], h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_comp[slot], 0));
     HIPCHK(h, hipMemcpyAsync(h->h_cnt[slot], h->s_ncand[slot], sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->copy_s));
@@ -501,29 +522,38 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
                                sizeof(ft8rx_record) * mc, B, hipMemcpyDeviceToHost, h->copy_s));
     HIPCHK(h, hipMemcpyAsync(h->h_evc[slot], h->s_evcount[slot], sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->copy_s));
     // The event log is [B][FT8RX_EVENT_CAP] x 24 B = 12 KB per frame of which a frame typically uses a tenth (config 1: ~40 events).
-    // Small batches copy it whole (one round trip: the latency case); large ones leave it to the fetch, which knows the counts by
-    // then and copies only the used columns (fetch_events) -- 100 MB -> ~15 MB per 8192-frame shard on the host link.
-    h->slot_evpending[slot] = (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES;
+    // Small batches copy it whole (the latency case).  Large ones were packed above (k_ev_scan / k_ev_compact) and B x EV_PREFIX
+    // entries of the packed run travel with the records: 100 MB -> 16 MB per 8192-frame shard on the host link.  A batch that
+    // logged more than that gets the remainder in its fetch (fetch_events).
+    h->slot_evpending[slot] = h->d_evc[slot] && (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES;
     if (!h->slot_evpending[slot])
         HIPCHK(h, hipMemcpyAsync(h->h_ev[slot], h->s_ev[slot], sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP, hipMemcpyDeviceToHost, h->copy_s));
+    else
+        HIPCHK(h, hipMemcpyAsync(h->h_evc_compact[slot], h->d_evc[slot], sizeof(ft8rx_event) * (size_t)B * EV_PREFIX, hipMemcpyDeviceToHost, h->copy_s));
     HIPCHK(h, hipEventRecord(h->ev_done[slot], h->copy_s));
     h->slot_B[slot] = B; h->last_slot = slot; h->slot_enq ^= 1; h->inflight++;
     return 0;
 }
 
-// Second step of a large batch's result copy (launch_batch): the per-frame event counts have arrived, so only the columns in use --
-// max over the batch's frames of min(count, cap) -- are copied, as one 2-D copy with the same [frame][FT8RX_EVENT_CAP] layout on both
-// sides.  Rows beyond a frame's count are not written (consumers read events[f][0 .. min(event_counts[f], cap)) only).  The copy has
-// its own stream: the result-copy stream may already be queued behind the next batch's kernels.
+// Large batches: the compacted event log (launch_batch) -> the [frame][FT8RX_EVENT_CAP] rows of h_ev that the fetch functions hand
+// out.  The per-frame counts have arrived, so the host knows each frame's offset in the compact run (the same prefix sum k_ev_scan
+// made); whatever lies beyond the prefix that travelled with the records is fetched now, on a stream of its own (the result-copy
+// stream may already be queued behind the next batch's kernels).  Rows beyond a frame's count are not written.
 static int fetch_events(ft8rx_handle* h, int slot) {
     if (!h->slot_evpending[slot]) return 0;
     const int B = h->slot_B[slot];
-    int used = 0;
-    for (int f = 0; f < B; f++) { int c = h->h_evc[slot][f]; if (c > FT8RX_EVENT_CAP) c = FT8RX_EVENT_CAP; if (c > used) used = c; }
-    if (used > 0) {
-        HIPCHK(h, hipMemcpy2DAsync(h->h_ev[slot], sizeof(ft8rx_event) * FT8RX_EVENT_CAP, h->s_ev[slot], sizeof(ft8rx_event) * FT8RX_EVENT_CAP,
-                                   sizeof(ft8rx_event) * (size_t)used, B, hipMemcpyDeviceToHost, h->evcopy_s));
+    size_t total = 0;
+    for (int f = 0; f < B; f++) { int c = h->h_evc[slot][f]; total += (size_t)(c > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : (c < 0 ? 0 : c)); }
+    const size_t have = (size_t)B * EV_PREFIX;
+    if (total > have) {
+        HIPCHK(h, hipMemcpyAsync(h->h_evc_compact[slot] + have, h->d_evc[slot] + have, sizeof(ft8rx_event) * (total - have), hipMemcpyDeviceToHost, h->evcopy_s));
         HIPCHK(h, hipStreamSynchronize(h->evcopy_s));
+    }
+    size_t off = 0;
+    for (int f = 0; f < B; f++) {
+        int c = h->h_evc[slot][f]; c = c > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : (c < 0 ? 0 : c);
+        if (c) memcpy(h->h_ev[slot] + (size_t)f * FT8RX_EVENT_CAP, h->h_evc_compact[slot] + off, sizeof(ft8rx_event) * (size_t)c);
+        off += (size_t)c;
     }
     h->slot_evpending[slot] = false;
     return 0;
@@ -677,6 +707,23 @@ int ft8rx_sync_search(ft8rx_handle* h, const float* grid, int B, int32_t* f0_idx
         f0_idx[o] = r.f0_idx; h0_idx[o] = r.h0_idx; score[o] = r.score;
     }
     // restore the 1.0 row in case the caller's grid differed
+    return 0;
+}
+
+int ft8rx_sync_scores(ft8rx_handle* h, const float* grid, int B, int f0_lo, int f0_hi, float* score, int32_t* h0_idx) {
+    if (!h || !grid || !score || !h0_idx || B < 1 || B > h->max_frames) return -1;
+    if (f0_lo < 4 || f0_hi <= f0_lo || f0_hi > FT8RX_GRID_COLS - 15 || f0_hi - f0_lo > NF0MAX) {
+        set_err(h, "ft8rx_sync_scores: f0 range [%d, %d) outside [4, %d]", f0_lo, f0_hi, FT8RX_GRID_COLS - 15); return -1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    ft8rx_config c = h->cfg;
+    c.f0_lo = f0_lo; c.f0_hi = f0_hi;
+    HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
+    const int nf0 = f0_hi - f0_lo, ntile = (nf0 + 15) / 16;
+    k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), h->stream>>>(h->d_grid, h->d_best_score, h->d_best_h0, c);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpy2DAsync(score, sizeof(float) * nf0, h->d_best_score, sizeof(float) * NF0MAX, sizeof(float) * nf0, B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h0_idx, sizeof(int32_t) * nf0, h->d_best_h0, sizeof(int32_t) * NF0MAX, sizeof(int32_t) * nf0, B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -982,11 +1029,7 @@ int ft8rx_hashes_clear(ft8rx_hashes* t) { if (!t) return -1; t->H.clear(); retur
 int ft8rx_hashes_add(ft8rx_hashes* t, const char* call) { if (!t || !call) return -1; t->H.add(call); return 0; }
 int ft8rx_hashes_size(const ft8rx_hashes* t) { return t ? (int)t->H.size() : -1; }
 
-int ft8rx_set_reject_log(const char* path) {
-    std::lock_guard<std::mutex> lk(hostmsg::g_reject_mu);
-    hostmsg::g_reject_log = path ? path : "";
-    return 0;
-}
+int ft8rx_set_reject_log(const char* path) { hostmsg::set_reject_log(path); return 0; }
 
 #ifdef FINE_TIMING
 int ft8rx_debug_fine_times(ft8rx_handle* h, unsigned long long* out32, int reset) {      // timing-only builds (tools/fine_timing.sh)

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -23,9 +24,16 @@ namespace hostmsg {
 // working directory (decoders.py:114-115).  Off by default; ft8rx_set_reject_log(path) turns it on for the process.
 static std::string g_reject_log;
 static std::mutex g_reject_mu;
-static void log_reject(const std::string& call) {
-    if (g_reject_log.empty()) return;
+static std::atomic<bool> g_reject_on{false};      // the packaging threads' fast path; the path string itself is only read under the mutex
+static void set_reject_log(const char* path) {
     std::lock_guard<std::mutex> lk(g_reject_mu);
+    g_reject_log = path ? path : "";
+    g_reject_on.store(!g_reject_log.empty(), std::memory_order_release);
+}
+static void log_reject(const std::string& call) {
+    if (!g_reject_on.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lk(g_reject_mu);
+    if (g_reject_log.empty()) return;
     if (FILE* f = fopen(g_reject_log.c_str(), "a")) { fprintf(f, "%s\n", call.c_str()); fclose(f); }
 }
 static const char A37[] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ";

@@ -100,4 +100,41 @@ FT8_DEV void log_event(ft8rx_event* ev, int32_t* evcount, int frame, int cand, i
     }
 }
 
+// ------------------------------------------------------------------------------------ event-log compaction (result copy of large batches)
+// The log is [B][FT8RX_EVENT_CAP] x 24 B = 12 KB per frame with typically a tenth of it in use.  Before a large batch's results go
+// to the host the used entries are packed back to back, frame after frame: k_ev_scan (one block) writes the exclusive prefix of
+// min(count, cap) over the frames, k_ev_compact (a block per frame) moves the entries as dwords.
+__global__ __launch_bounds__(1024) void k_ev_scan(const int32_t* __restrict__ evcount, int B, int32_t* __restrict__ offs) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int f = base + tid;
+        int c = f < B ? evcount[f] : 0;
+        c = c > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : (c < 0 ? 0 : c);
+        int incl = c;                                                  // inclusive scan inside the wavefront
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        int before = s_carry;
+        for (int i = 0; i < wv; i++) before += s_wave[i];
+        if (f < B) offs[f] = before + incl - c;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) offs[B] = s_carry;
+}
+__global__ __launch_bounds__(64) void k_ev_compact(const ft8rx_event* __restrict__ ev, const int32_t* __restrict__ evcount,
+                                                   const int32_t* __restrict__ offs, ft8rx_event* __restrict__ out) {
+    const int f = blockIdx.x;
+    int c = evcount[f]; c = c > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : c;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(ev + (size_t)f * FT8RX_EVENT_CAP);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + offs[f]);
+    for (int i = threadIdx.x; i < c * 6; i += 64) dst[i] = src[i];
+}
+
 #endif

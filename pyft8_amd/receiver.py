@@ -177,15 +177,21 @@ class AudioIn:
             return self
 
         def feed():
-            for hop in source:
-                if self._rx._stop.is_set():
-                    break
-                self._callback(hop if isinstance(hop, (bytes, bytearray, memoryview)) else np.ascontiguousarray(hop, np.int16).tobytes(),
-                               self.samples_perhop, None, None)
-            self.source_exhausted = True
+            try:
+                for hop in source:
+                    if self._rx._stop.is_set():
+                        break
+                    self._callback(hop if isinstance(hop, (bytes, bytearray, memoryview)) else np.ascontiguousarray(hop, np.int16).tobytes(),
+                                   self.samples_perhop, None, None)
+                else:
+                    self.source_exhausted = True
+            except Exception as e:          # noqa: BLE001 -- surfaced by Receiver.poll()/stop() instead of dying silently on a daemon thread
+                self._rx.thread_error = e
+            finally:
+                self._feeder = None         # a later start() opens a source again instead of running with no input
         self.source_exhausted = False
-        self._feeder = _threading.Thread(target=feed, name="ft8rx-audio-in", daemon=True)
-        self._feeder.start()
+        t = self._feeder = _threading.Thread(target=feed, name="ft8rx-audio-in", daemon=True)
+        t.start()
         return self
 
     def _pa_callback(self, in_data, frame_count, time_info, status_flags):
@@ -193,19 +199,26 @@ class AudioIn:
         self._callback(in_data, frame_count, time_info, status_flags)
         return (None, pyaudio.paContinue)
 
-    def close(self):
+    def close(self, timeout=5.0):
+        """Stop the PortAudio stream / wait for the feeder thread (which ends at its next hop once the receiver's stop flag is set)."""
         if self.stream is not None:
             try:
                 self.stream.stop_stream()
                 self.stream.close()
             finally:
                 self.stream = None
+        t = self._feeder
+        if t is not None and t is not _threading.current_thread():
+            t.join(timeout)
+            if not t.is_alive():
+                self._feeder = None
 
     def load_frame(self, audio_i16):
         """Frame-complete stand-in for 375 calls of _callback (receiver.py:295-306)."""
         self._audio = np.ascontiguousarray(audio_i16, np.int16).reshape(_lib.NSAMP)
         self.audio_buffer[:] = self._audio
-        g = self._rx._handle(1).spectrogram(self._audio)[0]
+        with self._rx._hlock:
+            g = self._rx._handle(1).spectrogram(self._audio)[0]
         self.search_grid[1:376] = g[1:376, :self.search_grid.shape[1]]          # in place: waterfall_data['data'] is a live view
         self.search_grid_ptr = 375
         self.cycle_spectrum = None
@@ -223,14 +236,25 @@ class AudioIn:
             tg = self._grid_time()
             if tg > 0.1:
                 self.search_grid_ptr = int(tg * self.search_hops_per_grid / (2 * T_CYC))
-        with self._rx._hlock:
-            self.search_grid[self.search_grid_ptr, :] = self._rx._handle(1).hop_spectrum(self.audio_buffer[-self.search_fft_len:])[:self.search_grid.shape[1]]
+        # the live path has a handle of its own (Receiver._live): a hop arriving while the owner runs decode_frames / search on the
+        # receiver's main handle must not touch that handle's staging audio, scratch rows or result slots
+        with self._rx._live_lock:
+            self.search_grid[self.search_grid_ptr, :] = self._rx._live_handle().hop_spectrum(self.audio_buffer[-self.search_fft_len:])[:self.search_grid.shape[1]]
+        early = self._rx.early_decode_hop
         if cycle_done:                                                   # the last hop of a cycle just landed
             self._audio = self.audio_buffer.copy()
             self.cycle_spectrum = None
             self.cycles_completed += 1
             with self._lock:
-                self._ready.append((self._audio, self._rx.time_source()))
+                self._ready.append((self._audio, self._rx.time_source(), False))
+        elif early and self.search_grid_ptr % self.search_hops_per_cycle == early:
+            # early pass (reference receiver.py:389-401 decodes candidates as their signals complete, first messages at ~12.9 s): the
+            # cycle so far, silence after it -- every signal that started by +0.8 s is complete at hop 340 (13.6 s)
+            part = np.zeros(_lib.NSAMP, np.int16)
+            n_have = early * self.samples_perhop
+            part[:n_have] = self.audio_buffer[-n_have:]
+            with self._lock:
+                self._ready.append((part, self._rx.time_source(), True))
         return (None, 0)                 # (None, pyaudio.paContinue)
 
     def get_cycle_spectrum(self):
@@ -238,14 +262,16 @@ class AudioIn:
         if self.cycle_spectrum is None:
             if self._audio is None:
                 raise _lib.Ft8rxError("no frame loaded")
-            self.cycle_spectrum = self._rx._handle(1).cycle_spectrum(self._audio)[0]
+            with self._rx._hlock:
+                self.cycle_spectrum = self._rx._handle(1).cycle_spectrum(self._audio)[0]
         return self.cycle_spectrum
 
 
 class Receiver:
     def __init__(self, input_device_keywords, on_message, sync_score_min=85, max_cands=200,
                  search_freq_range=[100, 3000], search_time_range=[-2.5 + 0.5, 2.5 + 0.5], verbose=False,
-                 device=0, max_frames=1, time_source=None, sleep=None, audio_source=None, autostart=None, **extension_knobs):
+                 device=0, max_frames=1, time_source=None, sleep=None, audio_source=None, autostart=None, early_decode_hop=340,
+                 **extension_knobs):
         if search_freq_range[1] > 5900 or search_freq_range[0] < 12.5 or search_freq_range[0] >= search_freq_range[1]:
             # the reference sizes its grid from search_freq_range (receiver.py:234-240) and itself fails beyond ~5940 Hz, where the
             # fine-sync slice runs off the cycle spectrum (receiver.py:181-182).  Here the layouts are compile-time: up to 3000 Hz runs
@@ -256,7 +282,21 @@ class Receiver:
         self.sleep = sleep or _time.sleep                     # time_utils.py:13-14
         self._stop = _threading.Event()
         self._thread = None
-        self._hlock = _threading.RLock()                      # one handle, two threads (audio callback, manage_cycle stand-in)
+        # Two handles, two locks.  The owner's calls (decode_frames, search, load_frame, get_cycle_spectrum) share the main handle
+        # self._h under _hlock -- including its reallocation in _handle().  The live path (audio callback: hop spectra; manage_cycle
+        # stand-in: poll) runs on its own one-frame handle self._live under _live_lock, so a hop that arrives in the middle of a
+        # multi-pass decode cannot touch the main handle's staging audio, scratch rows or result slots.
+        self._hlock = _threading.RLock()
+        self._live_lock = _threading.RLock()
+        self._live = None
+        self.thread_error = None
+        # streaming: also decode the partial cycle when this hop has arrived (340 = 13.6 s into the cycle), so that most messages are
+        # delivered before the next cycle starts, as the reference's are (its first decodes appear at ~12.9 s); None / 0 = only at
+        # the end of the cycle
+        if early_decode_hop and not 330 <= int(early_decode_hop) < 375:
+            raise _lib.Ft8rxError("early_decode_hop must lie in [330, 375) (a signal that starts at 0 s ends at hop 320) or be None")
+        self.early_decode_hop = int(early_decode_hop) if early_decode_hop else None
+        self._cycle_seen = {}                                 # cycle start -> message texts already delivered (early pass, then the full one)
         self.sync_score_min, self.max_cands = sync_score_min, max_cands
         self.verbose = verbose
         self.band = None
@@ -266,7 +306,6 @@ class Receiver:
         self.search_start_hop = self.search_h0_range[1] + 43 * 4
         self.device = device
         self._h = None
-        self._subs = {}                       # handles for search() over other f0 ranges, keyed by (lo, hi)
         self.subtract_refine = 2              # multi-pass decode: how origins are re-estimated before subtraction (_lib.Handle.subtract):
                                               # 2 = on a decimated baseband copy (same yield as the full-rate scans of 1, 5x faster)
         self.call_hashes = _lib.CallHashTable()       # persistent across the cycles of the stream (poll); batches use fresh ones
@@ -288,6 +327,8 @@ class Receiver:
             return self
         self._stop.clear()
         self.thread_error = None
+        if self.audio_in._feeder is not None and not self.audio_in._feeder.is_alive():
+            self.audio_in._feeder = None
         if audio_source is not None or self.audio_in.stream is None and self.audio_in._feeder is None:
             self.audio_in.open(audio_source)
 
@@ -303,19 +344,34 @@ class Receiver:
         return self
 
     def stop(self, timeout=5.0):
+        """Stop the daemon and the audio source, wait for both; an exception that ended either thread is raised here."""
         self._stop.set()
-        if self._thread is not None:
+        if self._thread is not None and self._thread is not _threading.current_thread():
             self._thread.join(timeout)
-        self.audio_in.close()
+        self.audio_in.close(timeout)
+        self._raise_thread_error()
+
+    def _raise_thread_error(self):
+        e, self.thread_error = self.thread_error, None
+        if e is not None:
+            raise _lib.Ft8rxError(f"receiver thread failed: {type(e).__name__}: {e}") from e
 
     def _handle(self, n_frames):
-        if self._h is None or self._h.max_frames < n_frames:
-            if self._h is not None:
-                self._h.close()
-            self._h = _lib.Handle(self.cfg, device=self.device, max_frames=n_frames)
-        # small batches (the live receiver decodes one frame per cycle): latency over work -- see ft8rx_set_ladder_mode
-        self._h.set_ladder_mode(1 if n_frames < 128 else 0)       # crossover measured at 64..128 frames per call (profiles/r02_latency.txt)
-        return self._h
+        with self._hlock:
+            if self._h is None or self._h.max_frames < n_frames:
+                if self._h is not None:
+                    self._h.close()
+                self._h = _lib.Handle(self.cfg, device=self.device, max_frames=n_frames)
+            # small batches: latency over work -- see ft8rx_set_ladder_mode
+            self._h.set_ladder_mode(1 if n_frames < 128 else 0)       # crossover measured at 64..128 frames per call (profiles/r02_latency.txt)
+            return self._h
+
+    def _live_handle(self):
+        """The live path's own one-frame handle (hop spectra and the per-cycle decodes of poll); call with _live_lock held."""
+        if self._live is None:
+            self._live = _lib.Handle(self.cfg, device=self.device, max_frames=1)
+            self._live.set_ladder_mode(1)
+        return self._live
 
     def set_band(self, band):
         self.band = band
@@ -327,8 +383,9 @@ class Receiver:
         first row read 1.0 (frame-complete semantics, DESIGN.md section 1 -- the live reference would see the
         tail of the previous cycle there).  search_f_idxs: any sequence of f0 indices (the reference iterates over it, keeps
         the f0 whose best score clears the threshold, sorts by score -- stably, so ties keep the iteration order -- and cuts
-        at max_cands).  Each run of consecutive ascending indices is one GPU search (the configured range on the receiver's
-        own handle, other runs on small cached handles); the runs are merged the same way."""
+        at max_cands).  The configured range runs entirely on the device (k_sync + k_topk, as in the decode pipeline); any other
+        sequence is one pass of the correlation kernel over [min, max] of the list on the same handle (ft8rx_sync_scores) followed
+        by those three steps on the host."""
         if odd_even not in (0, 1):
             raise _lib.Ft8rxError("odd_even must be 0 or 1")
         if search_f_idxs is None:
@@ -343,35 +400,27 @@ class Receiver:
             raise _lib.Ft8rxError(f"search_f_idxs must stay within [4, {width - 16}] (the grid has {width} columns, receiver.py:240)")
         if len(set(idx)) != len(idx):
             raise _lib.Ft8rxError("search_f_idxs holds an index twice")
-        runs, start = [], 0
-        for k in range(1, len(idx) + 1):
-            if k == len(idx) or idx[k] != idx[k - 1] + 1:
-                runs.append((idx[start], idx[k - 1] + 1))
-                start = k
         r0 = odd_even * self.audio_in.search_hops_per_cycle
         rows = self.audio_in.search_grid[r0 + 1:r0 + 376] if odd_even == 0 else \
             np.concatenate([self.audio_in.search_grid[r0 + 1:], self.audio_in.search_grid[:1]])
-        found = []
-        for rng in runs:
-            if list(rng) == list(self.audio_in.search_f0_idx_range):
-                h = self._handle(1)
-            else:
-                h = self._subs.pop(rng, None)
-                if h is None:
-                    cfg = _lib.Config.from_buffer_copy(bytes(self.cfg))
-                    cfg.f0_lo, cfg.f0_hi = rng
-                    if len(self._subs) >= 8:                     # bounded cache of per-range handles, oldest out
-                        self._subs.pop(next(iter(self._subs))).close()
-                    h = _lib.Handle(cfg, device=self.device, max_frames=1)
-                self._subs[rng] = h
+        with self._hlock:
+            h = self._handle(1)
             grid = np.ones((1, _lib.GRID_ROWS, h.grid_cols), np.float32)
             grid[0, 1:376, :width] = rows
-            f0, h0, sc, cnt = h.sync_search(grid)
-            found += [(int(f0[0, i]), int(h0[0, i]), float(sc[0, i])) for i in range(int(cnt[0]))]
-        if len(runs) > 1:
-            pos = {f: k for k, f in enumerate(idx)}
-            found.sort(key=lambda c: (-c[2], pos[c[0]]))
-            found = found[:self.cfg.max_cands]
+            if idx == list(range(*self.audio_in.search_f0_idx_range)):
+                # the configured range: threshold / stable sort / cut on the device (k_topk), as in the decode pipeline
+                f0, h0, sc, cnt = h.sync_search(grid)
+                found = [(int(f0[0, i]), int(h0[0, i]), float(sc[0, i])) for i in range(int(cnt[0]))]
+            else:
+                # any other index sequence: ONE pass of the same correlation kernel over [min, max] on this handle
+                # (ft8rx_sync_scores), then the reference's own steps on the host -- keep the f0 whose best score clears the
+                # threshold, in iteration order; sort by score, stably; cut at max_cands (receiver.py:350-367)
+                lo, hi = min(idx), max(idx) + 1
+                sc, h0 = h.sync_scores(grid, lo, hi)
+                thr = np.float32(self.cfg.sync_score_min)
+                found = [(f, int(h0[0, f - lo]), float(sc[0, f - lo])) for f in idx if sc[0, f - lo] > thr]
+                found.sort(key=lambda c: -c[2])
+                found = found[:self.cfg.max_cands]
         cands = []
         for f0i, h0i, sci in found:
             origin = {"h0_idx": h0i, "f0_idx": f0i, "tsec": h0i / 25.0, "fHz": 3.125 * f0i, "score": sci,
@@ -395,6 +444,10 @@ class Receiver:
         B = audio.shape[0]
         if B == 0:
             return ([], np.zeros((0, self.cfg.max_cands), _lib.RECORD_DTYPE), np.zeros(0, np.int32)) if return_records else []
+        with self._hlock:
+            return self._decode_frames_locked(audio, B, cyclestart_strings, return_records, passes, subtract_min_snr, sub_pass_osd)
+
+    def _decode_frames_locked(self, audio, B, cyclestart_strings, return_records, passes, subtract_min_snr, sub_pass_osd):
         h = self._handle(B)
         rec, cnt, ev, evc = h.decode_batch(audio)
         # host message layer: native, multithreaded (ft8rx_package_batch); messages.package_frame is its Python twin
@@ -464,6 +517,10 @@ class Receiver:
         B = audio.shape[0]
         if B == 0:
             raise _lib.Ft8rxError("empty batch")
+        with self._hlock:
+            return self._decode_frames_arrays_locked(audio, B, n_threads, passes, subtract_min_snr, sub_pass_osd)
+
+    def _decode_frames_arrays_locked(self, audio, B, n_threads, passes, subtract_min_snr, sub_pass_osd):
         h = self._handle(B)
         rec, cnt, ev, evc = h.decode_batch(audio)
         msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=n_threads)
@@ -495,19 +552,35 @@ class Receiver:
         Unlike batched decode_frames (independent frames, a fresh call-hash table per frame), the stream is ONE receiver: the
         frames share the persistent table self.call_hashes, as the reference's process-global databases.call_hashes does
         (databases.py:8), so a hashed / non-standard call heard in cycle N resolves `<...>` in cycle N+1."""
+        self._raise_thread_error()                                     # an exception on the audio / daemon thread surfaces here
         out = []
         while True:
             with self.audio_in._lock:
                 if not self.audio_in._ready:
                     break
-                frame, t_end = self.audio_in._ready.pop(0)
-            t0 = T_CYC * int((t_end - T_CYC / 2) / T_CYC)              # start of the cycle that just ended
+                frame, t_now, early = self.audio_in._ready.pop(0)
+            # start of the cycle the frame belongs to: a full frame is handed over at its end, an early one inside it
+            t0 = T_CYC * int(t_now / T_CYC) if early else T_CYC * int((t_now - T_CYC / 2) / T_CYC)
             cs = _time.strftime("%y%m%d_%H%M%S", _time.gmtime(t0))
-            with self._hlock:
-                rec, cnt, ev, evc = self._handle(1).decode_batch(frame[None])
+            with self._live_lock:
+                rec, cnt, ev, evc = self._live_handle().decode_batch(frame[None])
             msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=1, table=self.call_hashes)
-            out += _m.message_dicts(msgs[0], mcnt[0], cyclestart_string=cs, band=self.band,
-                                    odd_even=int((t0 % (2 * T_CYC)) / T_CYC), on_message=self.on_message)
+            dicts = _m.message_dicts(msgs[0], mcnt[0], cyclestart_string=cs, band=self.band, odd_even=int((t0 % (2 * T_CYC)) / T_CYC))
+            seen = self._cycle_seen.setdefault(t0, set())
+            for k in [k for k in self._cycle_seen if k < t0 - 4 * T_CYC]:
+                del self._cycle_seen[k]
+            for i, d in enumerate(dicts):
+                # early pass: only candidates whose 79 symbols lie inside the hops received so far (the rest of the frame is padding)
+                if early and int(msgs[0, i]["h0_idx"]) + 4 * 79 + 4 > self.early_decode_hop:
+                    continue
+                text = " ".join(d["msg_tuple"])
+                if text in seen:                                       # the reference's per-cycle duplicate filter (receiver.py:52-54)
+                    continue
+                seen.add(text)
+                d["early"] = bool(early)
+                out.append(d)
+                if self.on_message is not None:
+                    self.on_message(d)
         return out
 
 

@@ -815,7 +815,7 @@ def test_streaming_audio_in_mode(H, ocfg):
     from pyft8_amd.receiver import Receiver
     vt = [0.0]
     got = []
-    rx = Receiver("x", got.append, time_source=lambda: vt[0])
+    rx = Receiver("x", got.append, time_source=lambda: vt[0], early_decode_hop=None)      # one decode per cycle: the golden's emit order
     wf = rx.audio_in.waterfall_data["data"]
     for cyc, name in enumerate(["test_09", "test_08"]):
         audio, gold, js = load_golden(name)
@@ -883,7 +883,8 @@ def test_streaming_receiver_runs_itself_like_the_stock_cli():
     def vsleep(dt):
         _t.sleep(0.002)
 
-    rx = Receiver("any,keywords", got.append, sync_score_min=85, max_cands=200, time_source=lambda: vt[0], sleep=vsleep, audio_source=hops())
+    rx = Receiver("any,keywords", got.append, sync_score_min=85, max_cands=200, time_source=lambda: vt[0], sleep=vsleep, audio_source=hops(),
+                  early_decode_hop=None)
     try:
         assert rx._thread is not None and rx._thread.is_alive()
         deadline = _t.time() + 120
@@ -905,6 +906,46 @@ def test_streaming_receiver_runs_itself_like_the_stock_cli():
     assert len({norm(t) for t in second} & {norm(t) for t in ref8}) >= len(ref8) - 1
     assert {m["cyclestart_string"] for m in got[:len(ref9)]} == {"700101_000000"}
     assert {m["their_tx_cycle"] for m in got[len(ref9):]} == {1}
+
+
+def test_streaming_early_decode_delivers_before_the_next_cycle():
+    """VERDICT r2 #6 (reference receiver.py:389-401: candidates decode as their signals complete, first messages at ~12.9 s,
+    tests/PyFT8.txt:1-19): the streaming receiver also decodes the partial cycle at hop 340 (13.6 s) -- every signal that
+    started by +0.8 s is complete -- and the rest at hop 375.  Under the virtual clock: the early pass's messages are delivered
+    before 13.8 s, they are a subset of the frame-complete decode set, together with the end-of-cycle pass they ARE that set (up
+    to at most one OSD decode that depends on the padded tail), nothing is delivered twice, and a hop that arrives while the
+    owner runs a two-pass decode_frames on the same Receiver does not disturb either (the live path has its own handle)."""
+    from pyft8_amd.receiver import Receiver
+    for name in ("test_09", "test_08"):
+        audio, gold, js = load_golden(name)
+        ref_txt = [" ".join(m["msg_tuple"]) for m in js["messages"]]
+        vt = [0.0]
+        got = []
+        rx = Receiver("x", lambda d: got.append((vt[0], d)), time_source=lambda: vt[0])
+        assert rx.early_decode_hop == 340
+        side = None
+        for k in range(375):
+            vt[0] = (k + 1) * 0.04
+            rx.audio_in._callback(audio[480 * k:480 * k + 480].tobytes(), 480, None, None)
+            if k == 200:                      # the owner uses the same Receiver for a batch job in the middle of the cycle
+                side = rx.decode_frames(np.stack([audio, audio]), passes=2)
+            rx.poll()
+        early = [(t, d) for t, d in got if d["early"]]
+        late = [(t, d) for t, d in got if not d["early"]]
+        assert early and all(t <= 13.6 + 1e-9 for t, _ in early) and all(abs(t - 15.0) < 1e-9 for t, _ in late)
+        e_txt = [" ".join(d["msg_tuple"]) for _, d in early]
+        all_txt = e_txt + [" ".join(d["msg_tuple"]) for _, d in late]
+        assert len(set(all_txt)) == len(all_txt)                                   # the per-cycle duplicate filter
+        assert set(e_txt) <= set(ref_txt), sorted(set(e_txt) - set(ref_txt))       # early messages are frame-complete messages
+        assert set(ref_txt) <= set(all_txt) and len(set(all_txt) - set(ref_txt)) <= 1, (sorted(set(all_txt) ^ set(ref_txt)))
+        assert len(e_txt) >= 0.6 * len(ref_txt)                                    # most of the cycle arrives early
+        assert all(d["tsec"] <= 0.9 for _, d in early)
+        assert {d["cyclestart_string"] for _, d in got} == {"700101_000000"}
+        # the mid-cycle batch job saw exactly what a fresh Receiver decodes, both frames alike
+        fresh = Receiver("x", None).decode_frames(np.stack([audio, audio]), passes=2)
+        assert [[" ".join(m["msg_tuple"]) for m in f] for f in side] == [[" ".join(m["msg_tuple"]) for m in f] for f in fresh]
+        print(f"{name}: {len(e_txt)} of {len(ref_txt)} messages delivered at 13.6 s, {len(late)} at 15.0 s")
+        rx.stop()
 
 
 def test_error_paths_and_lifecycle():
