@@ -136,9 +136,9 @@ int  ft8rx_sync(ft8rx_handle* h);
 int  ft8rx_fetch_results(ft8rx_handle* h, int n_frames, ft8rx_record* records, int32_t* counts,
                          ft8rx_event* events, int32_t* event_counts);
 /* Only events[f][0 .. min(event_counts[f], FT8RX_EVENT_CAP)) are written / valid -- here, in the view below and in
- * ft8rx_decode_batch; the rest of a frame's row is left as it was.  For batches whose event log exceeds 1 MB the log is packed on
- * the device (it is 12 KB per frame, a tenth of it used) and 80 entries per frame travel with the records; a batch that logged more
- * gets the rest in its fetch: eight ranks sharing the host links move 16 MB instead of 100 MB per 8192-frame shard. */
+ * ft8rx_decode_batch; the rest of a frame's row is left as it was.  For batches whose event log exceeds 1 MB the GPU packs the used
+ * entries (the log is 12 KB per frame, a tenth of it used) straight into page-locked host memory: eight ranks sharing the host
+ * links move ~8 MB instead of 100 MB per 8192-frame shard. */
 /* Zero-copy variant of ft8rx_fetch_results: waits for the same batch and returns pointers INTO the handle's page-locked result
  * buffers (records packed [n_frames][cfg.max_cands], events [n_frames][FT8RX_EVENT_CAP]).  They stay valid until two more
  * batches have been enqueued (the slot is then reused). */

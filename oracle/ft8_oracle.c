@@ -91,7 +91,7 @@ float ft8o_tanhf(float x) {
     return p / q;
 }
 
-static inline cpx cmul(cpx a, cpx w) { cpx r; r.re = a.re * w.re - a.im * w.im; r.im = a.re * w.im + a.im * w.re; return r; }
+static inline cpx cmul(cpx a, cpx w) { cpx r; r.re = fmaf(a.re, w.re, -(a.im * w.im)); r.im = fmaf(a.re, w.im, a.im * w.re); return r; }
 static inline cpx cadd(cpx a, cpx b) { cpx r = {a.re + b.re, a.im + b.im}; return r; }
 static inline cpx csub(cpx a, cpx b) { cpx r = {a.re - b.re, a.im - b.im}; return r; }
 static inline cpx mulnegi(cpx a) { cpx r = {a.im, -a.re}; return r; }       /* a * (-i) */

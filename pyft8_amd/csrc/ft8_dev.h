@@ -1,7 +1,7 @@
 // ft8_dev.h -- device-side building blocks for the gfx950 FT8 receive kernels.
 //
-// Arithmetic contract: plain IEEE-754 fp32/fp64, no FMA contraction (-ffp-contract=off), correctly
-// rounded divide/sqrt (hipcc default), operation order written out explicitly.  DESIGN.md lists the
+// Arithmetic contract: plain IEEE-754 fp32/fp64, no FMA *contraction* (-ffp-contract=off: an fma happens only where the contract
+// names one -- the twiddle multiply cmul below), correctly rounded divide/sqrt (hipcc default), operation order written out explicitly.  DESIGN.md lists the
 // contract; the CPU oracle states the same formulas independently, which is what makes the parity
 // tests bit-exact.
 #pragma once
@@ -77,7 +77,9 @@ FT8_DEV float ft8_tanhf(float x) {
 }
 
 // ------------------------------------------------------------------------------------ complex helpers / DFT primitives
-FT8_DEV cpx cmul(cpx a, cpx w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+// Twiddle multiply of the contract: two roundings per component -- the one product, then the fused multiply-add (C99 fmaf: exactly
+// specified, so the CPU oracle reproduces it bit for bit with or without hardware FMA).  6 -> 4 VALU instructions per multiply.
+FT8_DEV cpx cmul(cpx a, cpx w) { return make_float2(__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x)); }
 FT8_DEV cpx cadd(cpx a, cpx b) { return make_float2(a.x + b.x, a.y + b.y); }
 FT8_DEV cpx csub(cpx a, cpx b) { return make_float2(a.x - b.x, a.y - b.y); }
 

@@ -48,7 +48,6 @@
 
 // ====================================================================================== host side
 #define EV_EAGER_BYTES ((size_t)1 << 20)      /* event logs up to this size travel whole with the records (launch_batch) */
-#define EV_PREFIX 80                          /* larger ones: this many compacted entries per frame travel with the records; the rest, if any, on fetch */
 #define HIPCHK(h, x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_err(h, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); return -2; } } while (0)
 
 // OSD trial list in the reference's order (decoders.py:248-272): order 0; single flips i < S; the restricted double flips
@@ -79,7 +78,6 @@ struct ft8rx_handle {
     hipStream_t sub[8];
     hipEvent_t ev_fork, ev_join[8];
     hipStream_t copy_s;              // host-to-device chunk copies of ft8rx_decode_batch, in order, never queued behind kernels
-    hipStream_t evcopy_s;            // second step of a large batch's result copy: the used part of the event log (fetch_events)
     hipEvent_t ev_chunk[16];
     Tables T;
     std::vector<void*> allocs;
@@ -105,10 +103,11 @@ struct ft8rx_handle {
     ft8rx_record* h_rec[2]; int32_t* h_cnt[2]; ft8rx_event* h_ev[2]; int32_t* h_evc[2];
     hipEvent_t ev_comp[2], ev_done[2];
     int slot_enq, slot_fetch, inflight, last_slot, slot_B[2];
-    // Large batches (event log > EV_EAGER_BYTES): the log is compacted on the device (k_ev_scan / k_ev_compact), a fixed prefix of
-    // the compact buffer travels with the records, and the fetch scatters it into h_ev's [frame][cap] rows (fetch_events)
+    // Large batches (event log > EV_EAGER_BYTES): k_ev_scan / k_ev_compact pack the used entries of the log and write them straight
+    // into page-locked host memory (h_evpacked; d_evpacked = the same buffer's device address); the fetch spreads them over h_ev's
+    // [frame][cap] rows (fetch_events)
     bool slot_evpending[2];
-    ft8rx_event* d_evc[2]; int32_t* d_evoffs[2]; ft8rx_event* h_evc_compact[2];
+    int32_t* d_evoffs[2]; ft8rx_event* h_evpacked[2]; ft8rx_event* d_evpacked[2];
     // signal subtraction (extension, allocated on first use): float32 working copy, per-chunk partial sums, GFSK tables
     float* d_wf; double2* d_part; double* d_pulse; double* d_pc; ft8rx_subsig* d_sigs; int32_t* d_sigcnt; int sig_cap;
     float2 *d_zdec, *d_model, *d_adec; SubdCtx* d_subctx;      // decimated-baseband refinement (refine = 2), allocated on first use
@@ -217,7 +216,6 @@ void ft8rx_destroy(ft8rx_handle* h) {
     for (auto e : h->pev) hipEventDestroy(e);
     for (int i = 0; i < 8; i++) { if (h->sub[i]) hipStreamDestroy(h->sub[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     if (h->copy_s) hipStreamDestroy(h->copy_s);
-    if (h->evcopy_s) hipStreamDestroy(h->evcopy_s);
     if (h->h2d_s) hipStreamDestroy(h->h2d_s);
     for (int i = 0; i < 16; i++) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -228,7 +226,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
         if (h->h_cnt[k]) hipHostFree(h->h_cnt[k]);
         if (h->h_ev[k]) hipHostFree(h->h_ev[k]);
         if (h->h_evc[k]) hipHostFree(h->h_evc[k]);
-        if (h->h_evc_compact[k]) hipHostFree(h->h_evc_compact[k]);
+        if (h->h_evpacked[k]) hipHostFree(h->h_evpacked[k]);
     }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -248,8 +246,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     ft8rx_handle* h = new ft8rx_handle();
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
     h->n_streams = 2; h->ladder_mode = 0; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
-    h->copy_s = nullptr; h->evcopy_s = nullptr; h->slot_evpending[0] = h->slot_evpending[1] = false; h->h2d_s = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
-    for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->h_evc_compact[k] = nullptr; h->d_evc[k] = nullptr; h->d_evoffs[k] = nullptr; h->slot_B[k] = 0; }
+    h->copy_s = nullptr; h->slot_evpending[0] = h->slot_evpending[1] = false; h->h2d_s = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
+    for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->h_evpacked[k] = nullptr; h->d_evpacked[k] = nullptr; h->d_evoffs[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
     h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr;
@@ -280,13 +278,14 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     rc |= dalloc(h, &h->s_ev[1], B * FT8RX_EVENT_CAP);
     rc |= dalloc(h, &h->s_evcount[1], B);
     const bool ev_compact = B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES;
-    for (int k = 0; k < 2 && ev_compact; k++) { rc |= dalloc(h, &h->d_evc[k], B * FT8RX_EVENT_CAP); rc |= dalloc(h, &h->d_evoffs[k], B + 1); }
+    for (int k = 0; k < 2 && ev_compact; k++) rc |= dalloc(h, &h->d_evoffs[k], B + 1);
     for (int k = 0; k < 2 && !rc; k++) {
         bool okh = hipHostMalloc((void**)&h->h_rec[k], sizeof(ft8rx_record) * B * cfg->max_cands, hipHostMallocDefault) == hipSuccess;
         okh = okh && hipHostMalloc((void**)&h->h_cnt[k], sizeof(int32_t) * B, hipHostMallocDefault) == hipSuccess;
         okh = okh && hipHostMalloc((void**)&h->h_ev[k], sizeof(ft8rx_event) * B * FT8RX_EVENT_CAP, hipHostMallocDefault) == hipSuccess;
         okh = okh && hipHostMalloc((void**)&h->h_evc[k], sizeof(int32_t) * B, hipHostMallocDefault) == hipSuccess;
-        if (ev_compact) okh = okh && hipHostMalloc((void**)&h->h_evc_compact[k], sizeof(ft8rx_event) * B * FT8RX_EVENT_CAP, hipHostMallocDefault) == hipSuccess;
+        if (ev_compact) okh = okh && hipHostMalloc((void**)&h->h_evpacked[k], sizeof(ft8rx_event) * B * FT8RX_EVENT_CAP, hipHostMallocDefault) == hipSuccess
+                                  && hipHostGetDevicePointer((void**)&h->d_evpacked[k], h->h_evpacked[k], 0) == hipSuccess;
         if (!okh) { set_err(h, "ft8rx_create: page-locked result buffers (%zu frames) could not be allocated", B); rc = -2; }
     }
     if (rc) { g_create_err = h->err; ft8rx_destroy(h); return -2; }
@@ -361,7 +360,6 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
         okc = okc && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
     okc = okc && hipStreamCreateWithFlags(&h->copy_s, hipStreamNonBlocking) == hipSuccess;
-    okc = okc && hipStreamCreateWithFlags(&h->evcopy_s, hipStreamNonBlocking) == hipSuccess;
     okc = okc && hipStreamCreateWithFlags(&h->h2d_s, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 16; i++) okc = okc && hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
     okc = okc && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -511,9 +509,9 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     HIPCHK(h, hipGetLastError());
     // results -> page-locked host buffers on the copy stream (overlaps the next batch, which computes into the other slot)
     const int mc = h->cfg.max_cands;
-    if (h->d_evc[slot] && (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES) {      // pack the event log (see the copy below)
+    if (h->d_evpacked[slot] && (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES) {      // pack the event log (see the copy below)
         k_ev_scan<<<1, 1024, 0, h->stream>>>(h->s_evcount[slot], B, h->d_evoffs[slot]);
-        k_ev_compact<<<B, 64, 0, h->stream>>>(h->s_ev[slot], h->s_evcount[slot], h->d_evoffs[slot], h->d_evc[slot]);
+        k_ev_compact<<<B, 64, 0, h->stream>>>(h->s_ev[slot], h->s_evcount[slot], h->d_evoffs[slot], h->d_evpacked[slot]);
     }
     HIPCHK(h, hipEventRecord(h->ev_comp[slot], h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_comp[slot], 0));
@@ -522,37 +520,28 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
                                sizeof(ft8rx_record) * mc, B, hipMemcpyDeviceToHost, h->copy_s));
     HIPCHK(h, hipMemcpyAsync(h->h_evc[slot], h->s_evcount[slot], sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->copy_s));
     // The event log is [B][FT8RX_EVENT_CAP] x 24 B = 12 KB per frame of which a frame typically uses a tenth (config 1: ~40 events).
-    // Small batches copy it whole (the latency case).  Large ones were packed above (k_ev_scan / k_ev_compact) and B x EV_PREFIX
-    // entries of the packed run travel with the records: 100 MB -> 16 MB per 8192-frame shard on the host link.  A batch that
-    // logged more than that gets the remainder in its fetch (fetch_events).
-    h->slot_evpending[slot] = h->d_evc[slot] && (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES;
+    // Small batches copy it whole (the latency case).  Large ones were packed above: k_ev_compact has already written the used
+    // entries -- and nothing else -- into page-locked host memory: ~8 MB instead of 100 MB per 8192-frame shard on the host link.
+    // (A copy-engine transfer of the packed run is not an option: an asynchronous device-to-host copy of a few hundred KB takes the
+    // runtime's shader-copy path, which queued behind the next batch's kernels and cost 0.5 ms per 256-frame step.)
+    h->slot_evpending[slot] = h->d_evpacked[slot] && (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES;
     if (!h->slot_evpending[slot])
         HIPCHK(h, hipMemcpyAsync(h->h_ev[slot], h->s_ev[slot], sizeof(ft8rx_event) * (size_t)B * FT8RX_EVENT_CAP, hipMemcpyDeviceToHost, h->copy_s));
-    else
-        HIPCHK(h, hipMemcpyAsync(h->h_evc_compact[slot], h->d_evc[slot], sizeof(ft8rx_event) * (size_t)B * EV_PREFIX, hipMemcpyDeviceToHost, h->copy_s));
     HIPCHK(h, hipEventRecord(h->ev_done[slot], h->copy_s));
     h->slot_B[slot] = B; h->last_slot = slot; h->slot_enq ^= 1; h->inflight++;
     return 0;
 }
 
-// Large batches: the compacted event log (launch_batch) -> the [frame][FT8RX_EVENT_CAP] rows of h_ev that the fetch functions hand
-// out.  The per-frame counts have arrived, so the host knows each frame's offset in the compact run (the same prefix sum k_ev_scan
-// made); whatever lies beyond the prefix that travelled with the records is fetched now, on a stream of its own (the result-copy
-// stream may already be queued behind the next batch's kernels).  Rows beyond a frame's count are not written.
+// Large batches: the packed event log (k_ev_compact, written by the GPU into page-locked memory) -> the [frame][FT8RX_EVENT_CAP] rows
+// of h_ev that the fetch functions hand out.  The per-frame counts have arrived, so the host knows each frame's offset in the
+// packed run (the same prefix sum k_ev_scan made).  Rows beyond a frame's count are not written.
 static int fetch_events(ft8rx_handle* h, int slot) {
     if (!h->slot_evpending[slot]) return 0;
     const int B = h->slot_B[slot];
-    size_t total = 0;
-    for (int f = 0; f < B; f++) { int c = h->h_evc[slot][f]; total += (size_t)(c > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : (c < 0 ? 0 : c)); }
-    const size_t have = (size_t)B * EV_PREFIX;
-    if (total > have) {
-        HIPCHK(h, hipMemcpyAsync(h->h_evc_compact[slot] + have, h->d_evc[slot] + have, sizeof(ft8rx_event) * (total - have), hipMemcpyDeviceToHost, h->evcopy_s));
-        HIPCHK(h, hipStreamSynchronize(h->evcopy_s));
-    }
     size_t off = 0;
     for (int f = 0; f < B; f++) {
         int c = h->h_evc[slot][f]; c = c > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : (c < 0 ? 0 : c);
-        if (c) memcpy(h->h_ev[slot] + (size_t)f * FT8RX_EVENT_CAP, h->h_evc_compact[slot] + off, sizeof(ft8rx_event) * (size_t)c);
+        if (c) memcpy(h->h_ev[slot] + (size_t)f * FT8RX_EVENT_CAP, h->h_evpacked[slot] + off, sizeof(ft8rx_event) * (size_t)c);
         off += (size_t)c;
     }
     h->slot_evpending[slot] = false;
