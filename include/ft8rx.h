@@ -268,7 +268,11 @@ int  ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int n_frames, ft8rx_subsi
  * tsec/fHz follow the search grid's conventions and sit ~75 ms / ~1.9 Hz off the true start; cancellation needs a few ms.)
  * refine = 2 (extension): the same re-estimation on a copy of the residual that is mixed down to the signal's centre frequency and
  * decimated by 32 (time grid 2.67 ms): same accuracy and decode yield, a third of the time; the subtraction itself stays at full
- * rate with the exact model.  This is what Receiver's multi-pass decode uses. */
+ * rate with the exact model.  This is what Receiver's multi-pass decode uses.
+ * refine = 3: Candidate.refine_time_origin of the reference's experiment (receiver_sub.py:58-72) -- before each signal is subtracted
+ * its start time is re-estimated in 12 steps of 5 ms from tb_0 - 6 on the spectrum of the residual so far (untapered 1000-bin slice,
+ * score = max over the three Costas blocks), tsec = tb / 200, fHz = int(0.5 + 16 fHz) / 16 -- then subtract_signal as with refine = 0.
+ * `sigs` returns the re-estimated origins. */
 /* Multi-pass decoding: the signals a subtraction sweep removes = every message of a frame with snr > min_snr, in emit order, with the
  * tones of its codeword (ft8rx_encode_tones of the candidate's word) and the origin its message dict reports (receiver.py:166).
  * sigs: [n_frames][max_sigs]; returns the largest per-frame count (or < 0). */

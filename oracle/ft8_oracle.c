@@ -320,7 +320,16 @@ int ft8o_db_to_llr(const float* p, float* llr, float* sd_out, int32_t* snr_out) 
 }
 
 /* ------------------------------------------------------------------ cycle spectrum (receiver.py:280-286) */
+static void cycle_spectrum_f32(const float* audio, const ft8o_config* c, float* spec_out);
 void ft8o_cycle_spectrum(const int16_t* audio, const ft8o_config* c, float* spec_out) {
+    float* x = (float*)malloc(sizeof(float) * FT8O_NSAMP);
+    for (int i = 0; i < FT8O_NSAMP; i++) x[i] = (float)audio[i];          /* exact */
+    cycle_spectrum_f32(x, c, spec_out);
+    free(x);
+}
+/* the same transform of a float32 buffer (the subtraction experiment's ring holds float32 residuals, receiver_sub.py:266,273-276) */
+void ft8o_cycle_spectrum_f32(const float* audio, const ft8o_config* c, float* spec_out) { cycle_spectrum_f32(audio, c, spec_out); }
+static void cycle_spectrum_f32(const float* audio, const ft8o_config* c, float* spec_out) {
     const int N = 96000, N1 = 300, N2 = 320;
     const cpx* W = get_twiddle(N);
     const cpx* W1 = get_twiddle(N1);
@@ -331,8 +340,8 @@ void ft8o_cycle_spectrum(const int16_t* audio, const ft8o_config* c, float* spec
     for (int n2 = 0; n2 < N2; n2++) {
         for (int n1 = 0; n1 < N1; n1++) {
             int m = N2 * n1 + n2;
-            col[n1].re = (2 * m < FT8O_NSAMP) ? (float)audio[2 * m] : 0.0f;
-            col[n1].im = (2 * m + 1 < FT8O_NSAMP) ? (float)audio[2 * m + 1] : 0.0f;
+            col[n1].re = (2 * m < FT8O_NSAMP) ? audio[2 * m] : 0.0f;
+            col[n1].im = (2 * m + 1 < FT8O_NSAMP) ? audio[2 * m + 1] : 0.0f;
         }
         fft_core(col, scr, N1, c->plan300, W1);
         for (int k1 = 0; k1 < N1; k1++) {
@@ -373,7 +382,10 @@ static void make_taper(void) {
 }
 
 /* baseband series z[3200] @ 200 S/s for spectrum origin fb (receiver.py:180-186) */
-static void fine_zsig(const float* spec, const ft8o_config* c, int fb, cpx* z) {
+static void fine_zsig_t(const float* spec, const ft8o_config* c, int fb, cpx* z, int tapered);
+static void fine_zsig(const float* spec, const ft8o_config* c, int fb, cpx* z) { fine_zsig_t(spec, c, fb, z, 1); }
+/* tapered = 0: the slice as the subtraction experiment takes it (receiver_sub.py:188-190: no edge tapers) */
+static void fine_zsig_t(const float* spec, const ft8o_config* c, int fb, cpx* z, int tapered) {
     if (!g_taper_ok) make_taper();
     const cpx* S = (const cpx*)spec;
     const cpx* W = get_twiddle(3200);
@@ -381,12 +393,12 @@ static void fine_zsig(const float* spec, const ft8o_config* c, int fb, cpx* z) {
     for (int k = 0; k < 3200; k++) { z[k].re = 0.0f; z[k].im = 0.0f; }
     for (int k = 0; k < 850; k++) {
         cpx v = S[fb + k];
-        if (k >= 750) { double t = g_taper[k - 750]; v.re = (float)((double)v.re * t); v.im = (float)((double)v.im * t); }
+        if (tapered && k >= 750) { double t = g_taper[k - 750]; v.re = (float)((double)v.re * t); v.im = (float)((double)v.im * t); }
         z[k].re = v.re; z[k].im = -v.im;                           /* conj: inverse FFT = conj(FFT(conj)) */
     }
     for (int k = 0; k < 150; k++) {
         cpx v = S[fb - 150 + k];
-        if (k < 100) { double t = g_taper[k]; v.re = (float)((double)v.re * t); v.im = (float)((double)v.im * t); }
+        if (tapered && k < 100) { double t = g_taper[k]; v.re = (float)((double)v.re * t); v.im = (float)((double)v.im * t); }
         z[3050 + k].re = v.re; z[3050 + k].im = -v.im;
     }
     fft_core(z, scr, 3200, c->plan3200, W);
@@ -418,12 +430,14 @@ static void fine_symbol(const cpx* z, int tb, int s, float* g8) {
     }
 }
 
-static float fine_score(const cpx* z, int tb) {                    /* receiver.py:197-206: middle Costas only */
+static float fine_score_block(const cpx* z, int tb, int sym0);
+static float fine_score(const cpx* z, int tb) { return fine_score_block(z, tb, 36); }   /* receiver.py:197-206: middle Costas only */
+static float fine_score_block(const cpx* z, int tb, int sym0) {
     /* contract: per symbol a, on = g[a][costas[a]] and off_a = sum over the other six tones b < 7 (b ascending, fp64);
      * S1 = sum_a on_a, S2 = sum_a off_a (a ascending); score = (float)(S1 + w6 * S2) */
     double s1 = 0.0, s2 = 0.0;
     for (int a = 0; a < 7; a++) {
-        float g[8]; fine_symbol(z, tb, 36 + a, g);
+        float g[8]; fine_symbol(z, tb, sym0 + a, g);
         double off = 0.0;
         for (int b = 0; b < 7; b++) if (b != COSTAS[a]) off += (double)g[b];
         s1 += (double)g[COSTAS[a]];
@@ -1029,4 +1043,218 @@ int ft8o_subtract(float* audio, const uint8_t* tones, double fHz, double tsec) {
     }
     free(sr);
     return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * 77-bit word -> the 79 transmitted tones (PyFT8/transmitter.py:181-223 `encode_bits77`): CRC-14 appended, the 83 parity bits of
+ * the LDPC(174,91) code from the parity rows FT8_A, three codeword bits per symbol MSB first through the Gray map, Costas blocks
+ * at symbols 0, 36, 72.  Pinned by the tone sequences of tests/golden/messages.json (the reference transmitter's own output). */
+void ft8o_encode_tones(uint64_t lo, uint64_t hi, uint8_t* tones) {
+    static const uint8_t gray[8] = {0, 1, 3, 2, 5, 6, 4, 7};
+    hi &= 0x1FFFull;
+    const unsigned crc = crc14_of77(lo, hi);
+    uint8_t cw[174];
+    uint64_t m[2] = {0, 0};                                           /* message bit r (0 = first transmitted) at word r >> 6, bit r & 63 */
+    for (int r = 0; r < 91; r++) {
+        unsigned b;
+        if (r < 77) { const int pos = 76 - r; b = (unsigned)((pos >= 64 ? (hi >> (pos - 64)) : (lo >> pos)) & 1u); }
+        else b = (crc >> (13 - (r - 77))) & 1u;
+        cw[r] = (uint8_t)b;
+        if (b) m[r >> 6] |= 1ull << (r & 63);
+    }
+    for (int p = 0; p < 83; p++)
+        cw[91 + p] = (uint8_t)(__builtin_parityll(FT8_A[p][0] & m[0]) ^ __builtin_parityll(FT8_A[p][1] & m[1]));
+    for (int k = 0; k < 7; k++) { tones[k] = (uint8_t)COSTAS[k]; tones[36 + k] = (uint8_t)COSTAS[k]; tones[72 + k] = (uint8_t)COSTAS[k]; }
+    for (int i = 0; i < 58; i++)
+        tones[PAYLOAD_SYM[i]] = gray[(cw[3 * i] << 2) | (cw[3 * i + 1] << 1) | cw[3 * i + 2]];
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Candidate.refine_time_origin of the subtraction experiment (reference tests/pipeline/receiver_sub.py:58-72), which runs on every
+ * decode before it is subtracted (:434-436):
+ *   fb_0 = int(0.5 + fHz * 16);  tb_0 = int(0.5 + tsec * 200)
+ *   for fb in range(fb_0 - 2, fb_0 + 2):  for tb in range(tb_0 - 6, tb_0 + 6):      (the fb loop passes fb_0 every time: four identical sweeps)
+ *       _get_signal_grid_fine(fb_0, tb);  if score > best: best = score; tsec = tb / 200; fHz = fb_0 / 16
+ * with the EXPERIMENT's _get_signal_grid_fine (:186-211): the 1000-bin slice without edge tapers, 3200-point inverse FFT, 79 symbol
+ * DFTs at clip(tb + 32 s, 0, 3168), score = max over the three Costas blocks of the 7x7 correlation; spectrum = rfft of the float32
+ * ring zero-padded to 192000 (:273-276), i.e. of the residual after the subtractions made so far.
+ * Arithmetic: the build's contract (FFT plans, symbol DFT, fp64 score sums) -- bit-exact against the GPU's refine = 3; against the
+ * reference itself the scores agree to ~1e-5 relative and the chosen origins are compared in tests/test_oracle_golden.py. */
+void ft8o_refine_time_origin(const float* audio_f32, const ft8o_config* c, double* fHz, double* tsec, float* best_score) {
+    float* spec = (float*)malloc(sizeof(float) * 2 * FT8O_SPEC_BINS);
+    cycle_spectrum_f32(audio_f32, c, spec);
+    const int fb0 = (int)(0.5 + *fHz * 16.0);
+    const int tb0 = (int)(0.5 + *tsec * 200.0);
+    cpx* z = (cpx*)malloc(sizeof(cpx) * 3200);
+    fine_zsig_t(spec, c, fb0, z, 0);
+    float best = 0.0f; int have = 0, tbest = tb0;
+    for (int tb = tb0 - 6; tb < tb0 + 6; tb++) {
+        float s = fine_score_block(z, tb, 0);
+        const float s1 = fine_score_block(z, tb, 36), s2 = fine_score_block(z, tb, 72);
+        if (s1 > s) s = s1;
+        if (s2 > s) s = s2;
+        if (!have || s > best) { best = s; tbest = tb; have = 1; }              /* first strict maximum (the reference starts at -1e40) */
+    }
+    *tsec = (double)tbest / 200.0;
+    *fHz = (double)fb0 / 16.0;
+    if (best_score) *best_score = best;
+    free(z); free(spec);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The build's own origin re-estimation and subtraction on a decimated baseband copy (ft8rx_subtract refine = 2; EXTENSION, no
+ * reference counterpart): a plain double-precision statement of what pyft8_amd/csrc/kernels/subtract.hpp computes in float32 with
+ * hardware sin/cos -- tolerance stage (tests compare the chosen grid points and the residual, not bits).
+ *   fc = (fHz - 0.5) + 21.875;  s00 = int(12000 tsec)
+ *   z[m]   = sum_{|j| < 32} (32 - |j|) x[n_c + j] e^{-2 pi i fc (n_c + j) / 12000},  n_c = s00 + 32 (m - 64),  m < 4864      (mix + triangular decimator)
+ *   c[m]   = conj(sig[32 m] e^{-2 pi i fc (s0 + 32 m) / 12000}) / (1024 g(tone of sample 32 m)),  m < 4736                    (model for the current origin)
+ *   scan:   Y[z][ch] = sum_{m in chunk ch (37 samples)} z[64 + off + m + shift_z / 32] c[m],  off = (s0 - s00) / 32
+ *   pick:   argmax over (shift, df) of |sum_ch Y[z][ch] e^{-2 pi i df t_ch}|^2, t_ch = (ch + 1/2) 1184 / 12000; then
+ *           s0 += shift, tsec = (s0 + 1/2) / 12000, fHz += df - 1/2
+ *   coarse: shifts 32 (-52 + 4 i), i < 15; df = -1 + j / 16, j < 113;   fine: shifts 32 (-4 + i), i < 9; df = 0.4375 + j / 64, j < 9
+ *   amplitude: A_k = (32 / 192000) sum_m z[64 + off + m] c[m] e^{-2 pi i k 32 m / 192000}, k < 20;  a[m] = sum_k A_k e^{+2 pi i k 32 m / 192000}
+ *   subtract (full rate): x[s0 + n] -= 2 Re(a(n) sig[n]), a(n) interpolated linearly between a[n >> 5] and a[(n >> 5) + 1] */
+#define SUBD_D 32
+#define SUBD_CH 37
+#define SUBD_N (128 * SUBD_CH)
+#define SUBD_PAD 64
+#define SUBD_NZ (SUBD_PAD + SUBD_N + 64)
+typedef struct { double re, im; } dcpx;
+static double subd_droop(double f) {
+    const double x = M_PI * f / 12000.0;
+    if (fabs(x) < 1e-6) return 1.0;
+    const double r = sin(32.0 * x) / (32.0 * sin(x));
+    return r * r;
+}
+static void sub_sig(const uint8_t* tones, const double* cum, double f_base, int m, double* sr, double* si) {
+    const double phi = fmod(sub_phase(tones, cum, f_base, m), 2.0 * M_PI);
+    double amp = 1.0;
+    if (m < 240) amp = (1.0 - cos(M_PI * (double)m / 239.0)) / 2.0;
+    else if (m >= SUB_L - 240) amp = (1.0 + cos(M_PI * (double)(m - (SUB_L - 240)) / 239.0)) / 2.0;
+    *sr = amp * cos(phi); *si = amp * sin(phi);
+}
+static void subd_model(const uint8_t* tones, const double* cum, double fHz, double tsec, double fc, dcpx* cm) {
+    const int s0 = (int)(12000.0 * tsec);
+    for (int m = 0; m < SUBD_N; m++) {
+        const int n = SUBD_D * m;
+        double sr, si; sub_sig(tones, cum, fHz - 0.5, n, &sr, &si);
+        const double th = 2.0 * M_PI * fmod(fc * ((double)(s0 + n) / 12000.0), 1.0);
+        const double cr = cos(th), ci = sin(th);
+        int isym = n / SUB_SPS; if (isym > 78) isym = 78;
+        const double g = subd_droop(fHz - 0.5 + 6.25 * (double)tones[isym] - fc);
+        const double sc = 1.0 / (1024.0 * g);
+        cm[m].re = (sr * cr + si * ci) * sc; cm[m].im = (sr * ci - si * cr) * sc;       /* conj(sig e^{-i th}) */
+    }
+}
+static void subd_scan_pick(const dcpx* zd, const dcpx* cm, int s00, const int* shift, int nshift, double df_lo, double df_step, int ndf,
+                           double* fHz, double* tsec) {
+    const int s0 = (int)(12000.0 * *tsec);
+    const int off = (s0 - s00) / SUBD_D;
+    dcpx (*Y)[128] = (dcpx (*)[128])calloc((size_t)nshift * 128, sizeof(dcpx));
+    for (int z = 0; z < nshift; z++) {
+        const int b0 = s0 + shift[z];
+        if (!(b0 > 0 && b0 + SUB_L <= FT8O_NSAMP)) continue;
+        for (int ch = 0; ch < 128; ch++) {
+            double ar = 0.0, ai = 0.0;
+            for (int m = 0; m < SUBD_CH; m++) {
+                const int idx = SUBD_PAD + off + ch * SUBD_CH + m + shift[z] / SUBD_D;
+                if (idx < 0 || idx >= SUBD_NZ) continue;
+                const dcpx zv = zd[idx], wv = cm[ch * SUBD_CH + m];
+                ar += zv.re * wv.re - zv.im * wv.im; ai += zv.re * wv.im + zv.im * wv.re;
+            }
+            Y[z][ch].re = ar; Y[z][ch].im = ai;
+        }
+    }
+    double be = -1.0; int bz = 0, bj = 0;
+    for (int z = 0; z < nshift; z++) for (int j = 0; j < ndf; j++) {
+        const double df = df_lo + df_step * (double)j;
+        double er = 0.0, ei = 0.0;
+        for (int ch = 0; ch < 128; ch++) {
+            const double ang = -2.0 * M_PI * df * (((double)ch + 0.5) * (double)(SUBD_D * SUBD_CH) / 12000.0);
+            const double cr = cos(ang), ci = sin(ang);
+            er += Y[z][ch].re * cr - Y[z][ch].im * ci; ei += Y[z][ch].re * ci + Y[z][ch].im * cr;
+        }
+        const double e = er * er + ei * ei;
+        if (e > be) { be = e; bz = z; bj = j; }
+    }
+    if (be > 0.0) {
+        const int s0n = s0 + shift[bz];
+        *tsec = ((double)s0n + 0.5) / 12000.0;
+        *fHz += (df_lo + df_step * (double)bj) - 0.5;
+    }
+    free(Y);
+}
+/* refine = 2 for one signal: re-estimates (fHz, tsec) in place and, if `subtract`, removes the signal from audio (float32, in place).
+ * returns 1 if the signal was subtracted */
+int ft8o_refine2_subtract(float* audio, const uint8_t* tones, double* fHz, double* tsec, int subtract) {
+    sub_init();
+    double cum[80]; cum[0] = 0.0;
+    for (int i = 0; i < 79; i++) cum[i + 1] = cum[i] + (double)tones[i];
+    const double fc = *fHz - 0.5 + 21.875;
+    const int s00 = (int)(12000.0 * *tsec);
+    /* mixed-down samples over the span the decimator touches, then the triangular filter */
+    const int n_lo = s00 + SUBD_D * (0 - SUBD_PAD) - 31, n_hi = s00 + SUBD_D * (SUBD_NZ - 1 - SUBD_PAD) + 31;
+    const int span = n_hi - n_lo + 1;
+    dcpx* xb = (dcpx*)malloc(sizeof(dcpx) * (size_t)span);
+    for (int i = 0; i < span; i++) {
+        const int n = n_lo + i;
+        if (n < 0 || n >= FT8O_NSAMP) { xb[i].re = 0.0; xb[i].im = 0.0; continue; }
+        const double th = -2.0 * M_PI * fmod(fc * ((double)n / 12000.0), 1.0);
+        xb[i].re = (double)audio[n] * cos(th); xb[i].im = (double)audio[n] * sin(th);
+    }
+    dcpx* zd = (dcpx*)malloc(sizeof(dcpx) * SUBD_NZ);
+    for (int m = 0; m < SUBD_NZ; m++) {
+        const int ic = (s00 + SUBD_D * (m - SUBD_PAD)) - n_lo;
+        double ar = 0.0, ai = 0.0;
+        for (int j = -31; j <= 31; j++) { const double w = (double)(32 - (j < 0 ? -j : j)); ar += w * xb[ic + j].re; ai += w * xb[ic + j].im; }
+        zd[m].re = ar; zd[m].im = ai;
+    }
+    free(xb);
+    dcpx* cm = (dcpx*)malloc(sizeof(dcpx) * SUBD_N);
+    int coarse[15], fine[9];
+    for (int i = 0; i < 15; i++) coarse[i] = SUBD_D * (-52 + 4 * i);
+    for (int i = 0; i < 9; i++) fine[i] = SUBD_D * (-4 + i);
+    subd_model(tones, cum, *fHz, *tsec, fc, cm);
+    subd_scan_pick(zd, cm, s00, coarse, 15, -1.0, 0.0625, 113, fHz, tsec);
+    subd_model(tones, cum, *fHz, *tsec, fc, cm);
+    subd_scan_pick(zd, cm, s00, fine, 9, 0.4375, 0.015625, 9, fHz, tsec);
+    int done = 0;
+    const int s0 = (int)(12000.0 * *tsec);
+    if (subtract && s0 > 0 && s0 + SUB_L <= FT8O_NSAMP) {
+        subd_model(tones, cum, *fHz, *tsec, fc, cm);
+        const int off = (s0 - s00) / SUBD_D;
+        double Ar[20], Ai[20];
+        for (int k = 0; k < 20; k++) { Ar[k] = 0.0; Ai[k] = 0.0; }
+        for (int m = 0; m < SUBD_N; m++) {
+            const dcpx zv = zd[SUBD_PAD + off + m], wv = cm[m];
+            const double yr = zv.re * wv.re - zv.im * wv.im, yi = zv.re * wv.im + zv.im * wv.re;
+            for (int k = 0; k < 20; k++) {
+                const double ang = -2.0 * M_PI * (double)(((long long)k * SUBD_D * m) % 192000) / 192000.0;
+                const double cr = cos(ang), ci = sin(ang);
+                Ar[k] += yr * cr - yi * ci; Ai[k] += yr * ci + yi * cr;
+            }
+        }
+        for (int k = 0; k < 20; k++) { Ar[k] *= (double)SUBD_D / 192000.0; Ai[k] *= (double)SUBD_D / 192000.0; }
+        dcpx* ad = (dcpx*)malloc(sizeof(dcpx) * (SUBD_N + 1));
+        for (int m = 0; m <= SUBD_N; m++) {
+            double er = 0.0, ei = 0.0;
+            for (int k = 0; k < 20; k++) {
+                const double ang = 2.0 * M_PI * (double)(((long long)k * SUBD_D * m) % 192000) / 192000.0;
+                const double cr = cos(ang), ci = sin(ang);
+                er += Ar[k] * cr - Ai[k] * ci; ei += Ar[k] * ci + Ai[k] * cr;
+            }
+            ad[m].re = er; ad[m].im = ei;
+        }
+        for (int n = 0; n < SUB_L; n++) {
+            double sr, si; sub_sig(tones, cum, *fHz - 0.5, n, &sr, &si);
+            int md = n >> 5; if (md > SUBD_N - 1) md = SUBD_N - 1;
+            double fq = (double)(n - SUBD_D * md) / 32.0; if (fq > 1.0) fq = 1.0;
+            const double er = ad[md].re + fq * (ad[md + 1].re - ad[md].re), ei = ad[md].im + fq * (ad[md + 1].im - ad[md].im);
+            audio[s0 + n] = (float)((double)audio[s0 + n] - 2.0 * (er * sr - ei * si));
+        }
+        free(ad);
+        done = 1;
+    }
+    free(cm); free(zd);
+    return done;
 }

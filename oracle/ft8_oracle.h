@@ -110,6 +110,15 @@ int   ft8o_decode_frame(const int16_t* audio, const ft8o_config* c, ft8o_cand* c
  * symbols_to_complex_audio (PyFT8/transmitter.py:41-70).  audio = the receiver's float32 ring (180000 samples), modified in
  * place; returns 1 if the signal was subtracted, 0 if the reference's guard (sig_s0 > 0, whole signal inside the buffer) fails. */
 int   ft8o_subtract(float* audio /*[180000]*/, const uint8_t* tones79, double fHz, double tsec);
+/* 77-bit word -> 79 tones (PyFT8/transmitter.py:181-223 encode_bits77) */
+void  ft8o_encode_tones(uint64_t lo, uint64_t hi, uint8_t* tones79);
+/* AudioIn.get_cycle_spectrum of the subtraction experiment (receiver_sub.py:273-276): the float32 ring, i.e. the residual */
+void  ft8o_cycle_spectrum_f32(const float* audio /*[180000]*/, const ft8o_config* c, float* spec /*[SPEC_BINS][2]*/);
+/* Candidate.refine_time_origin (receiver_sub.py:58-72) on the float32 residual: updates (fHz, tsec) = ft8rx_subtract refine = 3 */
+void  ft8o_refine_time_origin(const float* audio_f32, const ft8o_config* c, double* fHz, double* tsec, float* best_score);
+/* the build's own re-estimation on a decimated baseband copy + subtraction (ft8rx_subtract refine = 2; extension): updates
+ * (fHz, tsec); subtracts in place if `subtract`; returns 1 if subtracted */
+int   ft8o_refine2_subtract(float* audio /*[180000]*/, const uint8_t* tones79, double* fHz, double* tsec, int subtract);
 
 #ifdef __cplusplus
 }

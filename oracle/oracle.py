@@ -260,3 +260,111 @@ def notes_of(m):
     meth = {0: "GOOD91 ", 1: "LDPC5", 2: "LDPC20", 3: "OSD", 4: "LDPC20_OSD"}[m["method"]]
     tw = (" " if m["fine"] else "") + f"t:{m['ttweak']:+03d} f:{m['ftweak']:+03d}"
     return f"{src}_{ap}_{meth}" + tw
+
+
+# ---- signal subtraction / multi-pass decode ---------------------------------------------------------------------
+def encode_tones(bits77):
+    """77-bit word -> uint8[79] tones (transmitter.py:181-223 encode_bits77)."""
+    t = np.zeros(79, np.uint8)
+    f = lib().ft8o_encode_tones
+    f.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+    f.restype = None
+    f(C.c_uint64(bits77 & (2 ** 64 - 1)), C.c_uint64(bits77 >> 64), t.ctypes.data)
+    return t
+
+
+def cycle_spectrum_f32(audio_f32, cfg=None):
+    cfg = cfg or default_config()
+    a = np.ascontiguousarray(audio_f32, np.float32)
+    assert a.shape == (NSAMP,)
+    s = np.empty(SPEC_BINS_WIDE if _wide(cfg) else SPEC_BINS, np.complex64)
+    lib(_wide(cfg)).ft8o_cycle_spectrum_f32(_p(a), C.byref(cfg), _p(s.view(np.float32)))
+    return s
+
+
+def refine_time_origin(audio_f32, fHz, tsec, cfg=None):
+    """Candidate.refine_time_origin (receiver_sub.py:58-72) on the float32 residual -> (fHz, tsec, score)."""
+    cfg = cfg or default_config()
+    a = np.ascontiguousarray(audio_f32, np.float32)
+    assert a.shape == (NSAMP,)
+    f, t, sc = C.c_double(float(fHz)), C.c_double(float(tsec)), C.c_float()
+    fn = lib(_wide(cfg)).ft8o_refine_time_origin
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.restype = None
+    fn(a.ctypes.data, C.byref(cfg), C.byref(f), C.byref(t), C.byref(sc))
+    return f.value, t.value, sc.value
+
+
+def refine2_subtract(audio_f32, tones79, fHz, tsec, subtract=True):
+    """The build's refine = 2 (decimated baseband) for one signal, in place on a float32 buffer -> (subtracted, fHz, tsec)."""
+    assert audio_f32.dtype == np.float32 and audio_f32.shape == (NSAMP,) and audio_f32.flags.c_contiguous
+    t = np.ascontiguousarray(tones79, np.uint8)
+    f, ts = C.c_double(float(fHz)), C.c_double(float(tsec))
+    fn = lib().ft8o_refine2_subtract
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    done = fn(audio_f32.ctypes.data, t.ctypes.data, C.byref(f), C.byref(ts), int(bool(subtract)))
+    return bool(done), f.value, ts.value
+
+
+def subtraction_list(res, min_snr=-10):
+    """The signals a subtraction sweep removes (ft8rx_subtraction_list): every message of the frame with snr > min_snr, in emit order,
+    as (tones, fHz, tsec) with the origin the message dict reports (receiver.py:166)."""
+    out = []
+    for m in res["msgs"]:
+        if m["snr"] <= int(np.floor(min_snr)):
+            continue
+        c = res["cands"][m["cand"]]
+        fHz = 3.125 * c.f0_idx + (m["ftweak"] / 16.0 if m["fine"] else 0.0)
+        tsec = c.h0_idx / 25.0 + (m["ttweak"] / 200.0 if m["fine"] else 0.0)
+        out.append((encode_tones(msg_int(c.msg_lo, c.msg_hi)), fHz, tsec))
+    return out
+
+
+def to_int16(audio_f32):
+    """k_sub_to_i16: round half to even, saturate."""
+    return np.clip(np.rint(audio_f32), -32768, 32767).astype(np.int16)
+
+
+def decode_frame_passes(audio, cfg=None, passes=2, min_snr=-10, refine=2, drop_osd=False):
+    """Multi-pass decode of one frame as pyft8_amd.Receiver.decode_frames_arrays(passes=...) composes it (extension):
+    decode; subtract every new message with snr > min_snr, in emit order, from a float32 copy (refine = 2: origin re-estimated on the
+    decimated baseband copy; 3: the reference experiment's refine_time_origin then its subtract_signal; 0: subtract_signal as is);
+    round to int16; decode the residual; append the messages whose text the frame does not have yet.
+    -> dict(msgs = [(pass, msg dict)], origins = per sweep the refined (fHz, tsec) list, residual = int16 audio after the last sweep)"""
+    cfg = cfg or default_config()
+    audio = np.ascontiguousarray(audio, np.int16)
+    res = decode_frame(audio, cfg)
+    out = [(0, m) for m in res["msgs"]]
+    fresh = res
+    origins = []
+    cur = audio
+    for p in range(1, int(passes)):
+        sigs = subtraction_list(fresh, min_snr)
+        if not sigs:
+            break
+        wf = cur.astype(np.float32)
+        sweep = []
+        for tones, fHz, tsec in sigs:
+            if refine == 2:
+                _, fHz, tsec = refine2_subtract(wf, tones, fHz, tsec, True)
+            elif refine == 3:
+                fHz, tsec, _ = refine_time_origin(wf, fHz, tsec, cfg)
+                subtract(wf, tones, fHz, tsec)
+            else:
+                subtract(wf, tones, fHz, tsec)
+            sweep.append((fHz, tsec))
+        origins.append(sweep)
+        cur = to_int16(wf)
+        r2 = decode_frame(cur, cfg)
+        have = {m["msg_tuple"] for _, m in out}
+        new = []
+        for m in r2["msgs"]:
+            if drop_osd and m["method"] in (3, 4):
+                continue
+            if m["msg_tuple"] in have:
+                continue
+            have.add(m["msg_tuple"])
+            new.append(m)
+            out.append((p, m))
+        fresh = dict(cands=r2["cands"], msgs=new)
+    return dict(msgs=out, origins=origins, residual=cur)

@@ -111,6 +111,7 @@ struct ft8rx_handle {
     // signal subtraction (extension, allocated on first use): float32 working copy, per-chunk partial sums, GFSK tables
     float* d_wf; double2* d_part; double* d_pulse; double* d_pc; ft8rx_subsig* d_sigs; int32_t* d_sigcnt; int sig_cap;
     float2 *d_zdec, *d_model, *d_adec; SubdCtx* d_subctx;      // decimated-baseband refinement (refine = 2), allocated on first use
+    double* d_ones;                                             // refine = 3: an all-ones taper table
     std::string err;
     bool profiling;
     std::vector<hipEvent_t> pev;
@@ -250,7 +251,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->h_evpacked[k] = nullptr; h->d_evpacked[k] = nullptr; h->d_evoffs[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
-    h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr;
+    h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr; h->d_ones = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
     int rc = 0;
@@ -860,7 +861,7 @@ int ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t b
 int ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int B, ft8rx_subsig* sigs, const int32_t* counts, int max_sigs,
                    int refine, float* audio_f32_out) {
     if (!h || !d_audio || !sigs || !counts) return -1;
-    if (B < 1 || B > h->max_frames || max_sigs < 1 || max_sigs > 256 || refine < 0 || refine > 2) { set_err(h, "ft8rx_subtract: bad n_frames / max_sigs / refine"); return -1; }
+    if (B < 1 || B > h->max_frames || max_sigs < 1 || max_sigs > 256 || refine < 0 || refine > 3) { set_err(h, "ft8rx_subtract: bad n_frames / max_sigs / refine"); return -1; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!h->d_wf) {              // first use: working buffers for max_frames frames and the GFSK pulse tables (transmitter.py:41-50)
@@ -920,7 +921,25 @@ int ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int B, ft8rx_subsig* sigs,
     dfine.n = 9;    for (int i = 0; i < 9; i++) dfine.shift[i] = SUBD_D * (-4 + i);                // -10.7 .. +10.7 ms in 2.67 ms steps
     for (int i = 9; i < SUB_MAXSHIFT; i++) dfine.shift[i] = 0;
     const dim3 gmodel((SUBD_N + 255) / 256, B);
+    Tables Tones = h->T;                                     // refine = 3: the experiment's slices have no edge tapers
+    if (refine == 3) {
+        if (!h->d_ones) {
+            if (dalloc(h, &h->d_ones, (size_t)100)) return -2;
+            double ones[100]; for (int i = 0; i < 100; i++) ones[i] = 1.0;
+            HIPCHK(h, hipMemcpy(h->d_ones, ones, sizeof(ones), hipMemcpyHostToDevice));
+        }
+        Tones.taper = h->d_ones;
+    }
     for (int s = 0; s < nmax; s++) {
+        if (refine == 3) {
+            // Candidate.refine_time_origin (receiver_sub.py:58-72) on the spectrum of the residual so far, then subtract_signal as is
+            k_cyc_a_f32<<<dim3(40, B), 256, 0, h->stream>>>(h->d_wf, h->d_A, h->T);
+            k_cyc_bc<<<dim3(CYC_BC_GRID, B), 256, 0, h->stream>>>(h->d_A, h->d_spec, h->T);
+            k_refine3<<<B, FINE_NT, 0, h->stream>>>(h->d_spec, h->d_sigs, h->d_sigcnt, max_sigs, s, Tones);
+            k_sub_accum<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);
+            k_sub_apply<<<dim3(SUB_GRIDX, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_part);
+            continue;
+        }
         if (refine == 2) {
             k_subd_mix<<<dim3(SUBD_NZ / 256, B), 256, 0, h->stream>>>(h->d_wf, h->d_sigs, h->d_sigcnt, max_sigs, s, h->d_zdec, h->d_subctx);
             k_subd_model<<<gmodel, 256, 0, h->stream>>>(h->d_sigs, h->d_sigcnt, max_sigs, s, T, h->d_subctx, h->d_model);

@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256) void k_subd_model(const ft8rx_subsig* __restri
     const float cr = __builtin_amdgcn_cosf(fr), ci = __builtin_amdgcn_sinf(fr);
     // conj(sig e^{-i th}) = conj(sig) e^{+i th}
     const float mr = sr * cr + si * ci, mi = sr * ci - si * cr;
-    int ih = (n + 1920) / 1920; if (ih > 78) ih = 78;
-    const float g = subd_droop((float)(S.fHz - 0.5 + 6.25 * (double)S.tones[ih] - fc));
+    int isym = n / 1920; if (isym > 78) isym = 78;                     // the symbol sample n lies in (r02 used the NEXT symbol's tone here: ~1 % amplitude error at the edge tones)
+    const float g = subd_droop((float)(S.fHz - 0.5 + 6.25 * (double)S.tones[isym] - fc));
     const float sc = 1.0f / (1024.0f * g);
     model[(size_t)frame * SUBD_N + m] = make_float2(mr * sc, mi * sc);
 }
@@ -444,6 +444,103 @@ __global__ __launch_bounds__(256) void k_subd_apply(float* __restrict__ wf, cons
             const float er = a0.x + fq * (a1.x - a0.x), ei = a0.y + fq * (a1.y - a0.y);
             x[m] = x[m] - 2.0f * (er * sr - ei * si);
         }
+    }
+}
+
+// ---- refine = 3: Candidate.refine_time_origin of the reference's subtraction experiment (tests/pipeline/receiver_sub.py:58-72) ----
+// Before a decode is subtracted the experiment re-estimates its START TIME only: tb scans 12 steps of 5 ms from tb_0 - 6, every step
+// scored by the experiment's own _get_signal_grid_fine (:186-211) -- the 1000-bin slice around fb_0 WITHOUT edge tapers, 3200-point
+// inverse FFT, symbol DFTs, score = max over the three Costas blocks of the 7x7 correlation -- on the spectrum of the float32 ring,
+// i.e. of the residual the earlier subtractions left (:273-276; the fb loop of :64 passes fb_0 every time).  First strict maximum;
+// tsec = tb / 200, fHz = fb_0 / 16.  Per signal index s and batch: k_cyc_a_f32 + k_cyc_bc (spectrum of the working copy), then
+// k_refine3 (one block per frame).  Same FFT plans, symbol DFT and fp64 score sums as k_fine: bit-exact against ft8o_refine_time_origin.
+FT8_DEV void cyc_a_load_f32(const float* __restrict__ a, int n2b, int tid, float2 (&raw)[10]) {
+#pragma unroll
+    for (int q = 0; q < 10; q++) {
+        const int i = tid + 256 * q, ic = i < 2400 ? i : 0;
+        const int c = ic & 7, n1 = ic >> 3;
+        const int m = 320 * n1 + n2b + c;
+        const int inb = (2 * m < FT8RX_NSAMP) ? -1 : 0;                     // zero padding by masking a clamped load (cyc_a_load)
+        const float2 v = *reinterpret_cast<const float2*>(a + ((2 * m) & inb));
+        raw[q] = make_float2(__uint_as_float(__float_as_uint(v.x) & (uint32_t)inb), __uint_as_float(__float_as_uint(v.y) & (uint32_t)inb));
+    }
+}
+__global__ __launch_bounds__(256) void k_cyc_a_f32(const float* __restrict__ audio, cpx* __restrict__ A, Tables T) {
+    __shared__ cpx bufA[8 * 300];
+    __shared__ cpx bufB[8 * 300];
+    const int tile = (blockIdx.x & 7) * 5 + (blockIdx.x >> 3);
+    const int f = blockIdx.y, tid = threadIdx.x, n2b = 8 * tile;
+    float2 raw[10];
+    cyc_a_load_f32(audio + (size_t)f * FT8RX_NSAMP, n2b, tid, raw);
+#pragma unroll
+    for (int q = 0; q < 10; q++) { const int i = tid + 256 * q; if (i < 2400) bufA[(i & 7) * 300 + (i >> 3)] = raw[q]; }
+    cpx w[10];
+#pragma unroll
+    for (int q = 0; q < 10; q++) { const int i = tid + 256 * q, ic = i < 2400 ? i : 0; w[q] = T.W96000[(n2b + (ic & 7)) * (ic >> 3)]; }
+    __syncthreads();
+    cpx* r = lds_fft<300, 5, 5, 4, 3>(bufA, bufB, T.W300, 8, tid, 256);
+    cpx* out = A + (size_t)f * 96000;
+#pragma unroll
+    for (int q = 0; q < 10; q++) {
+        const int i = tid + 256 * q;
+        if (i < 2400) { const int c = i & 7, k1 = i >> 3; out[k1 * 320 + n2b + c] = cmul(r[c * 300 + k1], w[q]); }
+    }
+}
+
+// one block of FINE_NT threads per frame; T.taper must point at 100 ones (the experiment's slice has no tapers)
+__global__ __launch_bounds__(FINE_NT) void k_refine3(const cpx* __restrict__ spec, ft8rx_subsig* __restrict__ sigs, const int32_t* __restrict__ counts,
+                                                     int max_sigs, int s, Tables T) {
+    __shared__ cpx z[3200];
+    __shared__ cpx slice[FINE_SLICE];
+    __shared__ cpx w400[400];
+    __shared__ cpx w32[32];
+    __shared__ __attribute__((aligned(8))) double dsum[12 * 21 * 2];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    if (s >= counts[frame]) return;
+    ft8rx_subsig& S = sigs[(size_t)frame * max_sigs + s];
+    const int fb0 = (int)(0.5 + S.fHz * 16.0);                       // receiver_sub.py:59
+    const int tb0 = (int)(0.5 + S.tsec * 200.0);                     // :60
+    if (fb0 - 182 < 0 || fb0 - 182 + FINE_SLICE > FT8RX_SPEC_BINS) return;        // outside the kept spectrum: the origin stays as it is
+    const cpx* Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
+    for (int i = tid; i < FINE_SLICE; i += FINE_NT) slice[i] = Sg[i];
+    for (int i = tid; i < 400; i += FINE_NT) w400[i] = T.W3200[8 * i];
+    if (tid < 32) w32[tid] = T.W32[tid];
+    __syncthreads();
+    cpx wq[8];
+    sym32_twiddles(w32, tid & 3, wq);
+    fine_fft(slice, 182, z, w400, T, tid, 0, 3200);
+    // 12 time steps x 21 Costas symbols, four lanes each: (on, off) sums per symbol in fp64, as in k_fine's scoring
+#pragma unroll 1
+    for (int r = 0; r < (12 * 21 * 4 + FINE_NT - 1) / FINE_NT; r++) {
+        const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
+        const bool valid = qd < 12 * 21;
+        const int ti = valid ? qd / 21 : 0, sy = valid ? qd - 21 * ti : 0;
+        const int blk = sy / 7, a = sy - 7 * blk;
+        float mag[8];
+        fine_sym_quad<7>(z, tb0 - 6 + ti + 32 * (36 * blk + a), n2, wq, mag);
+        if (valid && n2 == 0) {
+            const int c = d_COSTAS[a];
+            double off = 0.0, on = 0.0;
+#pragma unroll
+            for (int b = 0; b < 7; b++) { const double m = (double)mag[b]; on = (b == c) ? m : on; off += (b == c) ? 0.0 : m; }
+            dsum[(ti * 21 + sy) * 2] = on; dsum[(ti * 21 + sy) * 2 + 1] = off;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float best = 0.0f; int tbest = tb0 - 6;
+        for (int ti = 0; ti < 12; ti++) {
+            float sc = 0.0f;
+            for (int blk = 0; blk < 3; blk++) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int a = 0; a < 7; a++) { s1 += dsum[(ti * 21 + 7 * blk + a) * 2]; s2 += dsum[(ti * 21 + 7 * blk + a) * 2 + 1]; }
+                const float sb = (float)(s1 + W6 * s2);
+                if (blk == 0 || sb > sc) sc = sb;                          // np.max over the three blocks (:210)
+            }
+            if (ti == 0 || sc > best) { best = sc; tbest = tb0 - 6 + ti; }   // first strict maximum (:66)
+        }
+        S.tsec = (double)tbest / 200.0;                                   // :68
+        S.fHz = (double)fb0 / 16.0;                                       // :69
     }
 }
 

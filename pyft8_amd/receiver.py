@@ -570,8 +570,11 @@ class Receiver:
             for k in [k for k in self._cycle_seen if k < t0 - 4 * T_CYC]:
                 del self._cycle_seen[k]
             for i, d in enumerate(dicts):
-                # early pass: only candidates whose 79 symbols lie inside the hops received so far (the rest of the frame is padding)
-                if early and int(msgs[0, i]["h0_idx"]) + 4 * 79 + 4 > self.early_decode_hop:
+                # early pass: only candidates whose 79 symbols lie inside the hops received so far (the rest of the frame is padding),
+                # and no OSD decodes -- first-CRC-valid-wins on a frame whose tail is padding produces false decodes that the
+                # complete frame does not; what OSD finds is delivered by the end-of-cycle pass
+                if early and (int(msgs[0, i]["h0_idx"]) + 4 * 79 + 4 > self.early_decode_hop or
+                              int(msgs[0, i]["method"]) in (_lib.M_OSD, _lib.M_LDPC_B_OSD)):
                     continue
                 text = " ".join(d["msg_tuple"])
                 if text in seen:                                       # the reference's per-cycle duplicate filter (receiver.py:52-54)

