@@ -249,7 +249,7 @@ class AudioIn:
                 self._ready.append((self._audio, self._rx.time_source(), False))
         elif early and self.search_grid_ptr % self.search_hops_per_cycle == early:
             # early pass (reference receiver.py:389-401 decodes candidates as their signals complete, first messages at ~12.9 s): the
-            # cycle so far, silence after it -- every signal that started by +0.8 s is complete at hop 340 (13.6 s)
+            # cycle so far, silence after it -- the payload of every signal that started by +1.6 s has arrived at hop 340 (13.6 s)
             part = np.zeros(_lib.NSAMP, np.int16)
             n_have = early * self.samples_perhop
             part[:n_have] = self.audio_buffer[-n_have:]
@@ -570,10 +570,11 @@ class Receiver:
             for k in [k for k in self._cycle_seen if k < t0 - 4 * T_CYC]:
                 del self._cycle_seen[k]
             for i, d in enumerate(dicts):
-                # early pass: only candidates whose 79 symbols lie inside the hops received so far (the rest of the frame is padding),
-                # and no OSD decodes -- first-CRC-valid-wins on a frame whose tail is padding produces false decodes that the
-                # complete frame does not; what OSD finds is delivered by the end-of-cycle pass
-                if early and (int(msgs[0, i]["h0_idx"]) + 4 * 79 + 4 > self.early_decode_hop or
+                # early pass: only candidates whose PAYLOAD symbols (7..71) lie inside the hops received so far -- the reference's own
+                # criterion for starting on a candidate (its search_grid_bounds, receiver.py:355,389; the last Costas block only
+                # counts towards the sync gate) -- and no OSD decodes: first-CRC-valid-wins on a frame whose tail is padding
+                # produces false decodes that the complete frame does not; what OSD finds is delivered by the end-of-cycle pass
+                if early and (int(msgs[0, i]["h0_idx"]) + 4 + 4 * 72 + 4 > self.early_decode_hop or
                               int(msgs[0, i]["method"]) in (_lib.M_OSD, _lib.M_LDPC_B_OSD)):
                     continue
                 text = " ".join(d["msg_tuple"])

@@ -983,7 +983,7 @@ def test_streaming_receiver_runs_itself_like_the_stock_cli():
 def test_streaming_early_decode_delivers_before_the_next_cycle():
     """VERDICT r2 #6 (reference receiver.py:389-401: candidates decode as their signals complete, first messages at ~12.9 s,
     tests/PyFT8.txt:1-19): the streaming receiver also decodes the partial cycle at hop 340 (13.6 s) -- every signal that
-    started by +0.8 s is complete -- and the rest at hop 375.  Under the virtual clock: the early pass's messages are delivered
+    whose payload symbols have arrived (start <= +1.6 s), OSD decodes excepted -- and the rest at hop 375.  Under the virtual clock: the early pass's messages are delivered
     before 13.8 s, they are a subset of the frame-complete decode set, together with the end-of-cycle pass they ARE that set (up
     to at most one OSD decode that depends on the padded tail), nothing is delivered twice, and a hop that arrives while the
     owner runs a two-pass decode_frames on the same Receiver does not disturb either (the live path has its own handle)."""
@@ -1013,7 +1013,7 @@ def test_streaming_early_decode_delivers_before_the_next_cycle():
         assert set(ref_txt) <= set(all_txt) and len(set(all_txt) - set(ref_txt)) <= 1, (sorted(set(all_txt) ^ set(ref_txt)))
         assert len(e_txt) >= 0.5 * len(ref_txt)                                    # most of the cycle arrives early
         assert all("OSD" not in d["decode_notes"] for _, d in early)
-        assert all(d["tsec"] <= 0.9 for _, d in early)
+        assert all(d["tsec"] <= 1.7 for _, d in early)
         assert {d["cyclestart_string"] for _, d in got} == {"700101_000000"}
         # the mid-cycle batch job saw exactly what a fresh Receiver decodes, both frames alike
         fresh = Receiver("x", None).decode_frames(np.stack([audio, audio]), passes=2)
@@ -1149,6 +1149,56 @@ def test_full_size_batch_properties():
     rec, cnt, ev, evc = h.fetch(8)
     assert _lib.package_batch(rec, cnt, ev, evc)[1].sum() <= 1           # (an OSD false decode on pure noise is possible, not several)
     h.close()
+    # BASELINE config 2 AS STATED: the same 4096 frames with LDPC BP 30 iterations + OSD depth 2
+    kw = dict(bp_iters_b=30, osd_single=30, osd_double=2)
+    h2 = _lib.Handle(_lib.default_config(**kw), max_frames=B)
+    ptr2 = h2.staging_ptr()
+    h2.synth_frames(ptr2, 9000000, B, n_signals=50, snr_range=(-10.0, 10.0))
+    h2.set_streams(4)
+    h2.enqueue(ptr2, B)
+    big30 = h2.fetch(B)
+    d30 = digest(big30, B)
+    assert d30 != d4                                                      # ten more iterations do change some outcomes
+    h2.set_streams(1)
+    h2.enqueue(ptr2, B)
+    assert digest(h2.fetch(B), B) == d30
+    n30 = int(sum((big30[0][f][:big30[1][f]]["status"] == 1).sum() for f in range(B)))
+    n20 = int(sum((big[0][f][:big[1][f]]["status"] == 1).sum() for f in range(B)))
+    assert n30 >= n20                                                     # (BP 30 decodes at ipass 4 what BP 20 left to OSD or lost)
+    import oracle as O
+    ocfg30 = O.default_config(**_lib.fft_plans(), **kw)
+    sample = [0, 777, 1500, 2048, 3333, 4095]
+    audio30 = {f: h2.download_audio(ptr2 + f * _lib.NSAMP * 2, 1)[0] for f in sample}
+    from pyft8_amd import messages as M
+    for f in sample:                                                      # six frames against the oracle run with the same knobs
+        r = O.decode_frame(audio30[f], ocfg30)
+        rec, cnt, ev, evc = (a[f] for a in big30)
+        assert int(cnt) == len(r["cands"])
+        for i, c in enumerate(r["cands"]):
+            g = rec[i]
+            assert (int(g["status"]), int(g["f0_idx"]), int(g["h0_idx"])) == (c.status, c.f0_idx, c.h0_idx), (f, i)
+            if c.status == 1:
+                assert (int(g["ipass"]), int(g["ap"]), int(g["method"]), int(g["n_its"]), int(g["msg_lo"]), int(g["msg_hi"])) == \
+                       (c.ipass, c.ap, c.method, c.n_its, c.msg_lo, c.msg_hi), (f, i)
+        assert [" ".join(m["msg_tuple"]) for m in M.package_frame(rec, int(cnt), ev, int(evc))] == [" ".join(m["msg_tuple"]) for m in r["msgs"]], f
+    h2.close()
+
+
+def test_randomised_parity_sweep():
+    """the randomised GPU-vs-oracle sweep (tools/parity_sweep.py) as a driver-run test: 96 never-seen frames with random
+    recipes (0..70 signals, -24..+25 dB) over six kwargs / knob sets -- defaults, a tighter threshold, a narrow window, the wide
+    build (to 5900 Hz), the extension knobs (BP 30, OSD 40/4), order-3 OSD with the distance gate -- random stream counts and ladder
+    modes: every candidate record, every natively rendered message and every Python-rendered message identical to the oracle."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("parity_sweep", os.path.join(ROOT, "tools", "parity_sweep.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    kws = [ps.KW[i] for i in (0, 2, 3, 4, 6, 7)]
+    tot = ps.run_sweep(nb=6, fpb=16, seed=20261002, kw_list=kws, first_index=9500000, verbose=False)
+    assert tot["frames"] == 96 and tot["kwargs_sets"] == 6 and tot["cands"] > 3000 and tot["msgs"] > 500, tot
+    assert tot["bad"] == 0, tot
+    print(f"parity sweep: {tot['frames']} frames, {tot['cands']} records, {tot['msgs']} messages identical to the oracle in {tot['seconds']:.0f} s")
 
 
 def test_bench_contract_line():

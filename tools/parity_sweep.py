@@ -30,22 +30,24 @@ def oracle_frame(args):
     return recs, [" ".join(m["msg_tuple"]) for m in r["msgs"]]
 
 
-def main():
-    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    fpb = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-    rng = np.random.default_rng(20260102)
+def run_sweep(nb=20, fpb=16, seed=20260102, kw_list=None, first_index=9000000, verbose=True):
+    """nb batches of fpb random frames, batch b decoded with kw_list[b % len(kw_list)] (default: the nine sets of KW) and random
+    stream counts / ladder modes; -> dict(frames, cands, msgs, bad, seconds, kwargs_sets).  Used by the command line below and by the
+    driver-run test tests/test_gpu_parity.py::test_randomised_parity_sweep."""
+    kw_list = KW if kw_list is None else kw_list
+    rng = np.random.default_rng(seed)
     tot = dict(frames=0, cands=0, msgs=0, bad=0)
     t0 = time.time()
     with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as pool:
         for b in range(nb):
-            kw = KW[b % len(KW)]
+            kw = kw_list[b % len(kw_list)]
             cfg = config_from_kwargs(**kw)
             wide = cfg.f0_hi > 960
             frames = []
             for k in range(fpb):
                 ns = int(rng.choice([0, 1, 5, 20, 50, 70]))
                 lo = float(rng.choice([-24.0, -18.0, -10.0, 0.0]))
-                frames.append(synth.make_frame(9000000 + 1000 * b + k, n_signals=ns, snr_range=(lo, lo + float(rng.choice([6.0, 14.0, 25.0]))),
+                frames.append(synth.make_frame(first_index + 1000 * b + k, n_signals=ns, snr_range=(lo, lo + float(rng.choice([6.0, 14.0, 25.0]))),
                                                freq_range=(150.0, 5650.0) if wide else (200.0, 2800.0)))
             audio = np.stack(frames)
             h = _lib.Handle(cfg, max_frames=fpb)
@@ -69,9 +71,19 @@ def main():
                 bad += not ok
                 tot["cands"] += n; tot["msgs"] += len(otxt)
             tot["frames"] += fpb; tot["bad"] += bad
-            print(f"batch {b:3d} kwargs {kw}: {fpb} frames, {'IDENTICAL' if not bad else f'{bad} FRAMES DIFFER'}", flush=True)
+            if verbose:
+                print(f"batch {b:3d} kwargs {kw}: {fpb} frames, {'IDENTICAL' if not bad else f'{bad} FRAMES DIFFER'}", flush=True)
+    tot["seconds"] = time.time() - t0
+    tot["kwargs_sets"] = min(nb, len(kw_list))
+    return tot
+
+
+def main():
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    fpb = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    tot = run_sweep(nb, fpb)
     print(f"{tot['frames']} frames, {tot['cands']} candidate records, {tot['msgs']} messages: {tot['bad']} frames differ from the oracle "
-          f"({time.time() - t0:.0f} s)")
+          f"({tot['seconds']:.0f} s)")
     sys.exit(1 if tot["bad"] else 0)
 
 
