@@ -356,10 +356,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: init kernel failed"); ft8rx_destroy(h); return -2; }
     bool okc = true;
     for (int i = 0; i < 24; i++) { hipEvent_t e = nullptr; okc = okc && hipEventCreate(&e) == hipSuccess; if (e) h->pev.push_back(e); }
-    for (int i = 0; i < 8; i++) {
-        okc = okc && hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking) == hipSuccess;
-        okc = okc && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
-    }
+    // (the chunk streams h->sub[] are created on first use, launch_batch: every stream that exists competes for one of the
+    // runtime's four hardware queues, see the note there)
     okc = okc && hipStreamCreateWithFlags(&h->copy_s, hipStreamNonBlocking) == hipSuccess;
     okc = okc && hipStreamCreateWithFlags(&h->h2d_s, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 16; i++) okc = okc && hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
@@ -482,19 +480,51 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     // already overlap the previous batch, so it keeps the 4 larger chunks of the device-resident path
     int nc = h->profiling ? 1 : ((host_audio && !pipelined) ? 2 * h->n_streams : h->n_streams);
     if (nc > B / 8) nc = B / 8;
+    // Chunk k runs on stream k % n_streams, where stream 0 IS the handle's main stream and streams 1.. are the (lazily created)
+    // sub-streams.  The HIP runtime maps all streams of a process onto four hardware queues, and commands of streams that share
+    // one execute in submission order: with a main stream that only forks and joins plus two chunk streams plus the two copy
+    // streams (five), the H2D stream shared a queue with a chunk stream and its event markers waited behind that chunk's kernels --
+    // in the rocprofv3 trace the second H2D chunk of the pipelined host entry started only when the previous batch's last kernel
+    // had finished (profiles/r03_notes.md).  Four streams in use = a queue each.
+    const int ns = h->n_streams;
+    for (int i = 1; i < ns && nc > 1; i++) if (!h->sub[i - 1]) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->sub[i - 1], hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[i - 1], hipEventDisableTiming));
+    }
+    auto chunk_stream = [&](int k) { const int i = k % ns; return i == 0 ? h->stream : h->sub[i - 1]; };
     if (nc <= 1) {
         if (host_audio) HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
         enqueue_chain(h, d_audio, 0, B, h->stream, h->profiling, slot, 0);
     } else {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         if (host_audio && !pipelined) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_fork, 0));
-        for (int i = 0; i < h->n_streams; i++) HIPCHK(h, hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
+        for (int i = 1; i < ns; i++) HIPCHK(h, hipStreamWaitEvent(h->sub[i - 1], h->ev_fork, 0));
         const int per = (B + nc - 1) / nc;
+        // chunk boundaries: equal parts, except for the synchronous host entry, whose first kernels can only start when the first
+        // chunk's audio has crossed PCIe -- there the chunks grow geometrically (B/8, B/8, B/4, B/2 for four): the first copy is
+        // half as long and the large chunks, which run most efficiently, come last (38.8 k -> 40.5 k frames/s for 256-frame calls;
+        // other layouts -- 16/48/64/128, three streams, five or six chunks -- all land between 38 k and 41.5 k)
+        int cb[17];
+        for (int k = 0; k <= nc; k++) cb[k] = (k * per < B) ? k * per : B;
+        if (host_audio && !pipelined && nc >= 3 && B >= 8 * nc) {
+            int left = B;
+            for (int k = nc - 1; k >= 1; k--) { const int n = left / 2; cb[k] = left - n; left -= n; }
+            cb[0] = 0; cb[nc] = B;
+        }
+        if (pipelined) {
+            // ONE copy for the whole batch and one event: it has the whole previous batch to hide behind, and a copy stream with
+            // event markers BETWEEN its copies can stall on them (markers are queue packets: in a hardware queue shared with a
+            // chunk stream they wait their turn behind that chunk's kernels -- the second of two chunk copies then started only
+            // at the end of the previous batch, rocprofv3 trace in profiles/r03_notes.md)
+            HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, cs));
+            HIPCHK(h, hipEventRecord(h->ev_chunk[0], cs));
+            for (int i = 0; i < ns; i++) HIPCHK(h, hipStreamWaitEvent(chunk_stream(i), h->ev_chunk[0], 0));
+        }
         for (int k = 0; k < nc; k++) {
-            const int f0 = k * per, n = (f0 + per <= B) ? per : B - f0;
-            if (n <= 0) break;
-            hipStream_t s = h->sub[k % h->n_streams];
-            if (host_audio) {
+            const int f0 = cb[k], n = cb[k + 1] - cb[k];
+            if (n <= 0) continue;
+            hipStream_t s = chunk_stream(k);
+            if (host_audio && !pipelined) {
                 HIPCHK(h, hipMemcpyAsync(stage + (size_t)f0 * FT8RX_NSAMP, host_audio + (size_t)f0 * FT8RX_NSAMP,
                                          sizeof(int16_t) * (size_t)n * FT8RX_NSAMP, hipMemcpyHostToDevice, cs));
                 HIPCHK(h, hipEventRecord(h->ev_chunk[k], cs));
@@ -502,9 +532,9 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
             }
             enqueue_chain(h, d_audio, f0, n, s, false, slot, k);
         }
-        for (int i = 0; i < h->n_streams; i++) {
-            HIPCHK(h, hipEventRecord(h->ev_join[i], h->sub[i]));
-            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+        for (int i = 1; i < ns; i++) {
+            HIPCHK(h, hipEventRecord(h->ev_join[i - 1], h->sub[i - 1]));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i - 1], 0));
         }
     }
     HIPCHK(h, hipGetLastError());
