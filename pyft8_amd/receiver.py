@@ -69,14 +69,131 @@ def frames_from_ragged(frames):
     return out
 
 
-class Candidate:
-    """Read-only view of one sync candidate (reference receiver.py:29-50 `Candidate.origin`)."""
+# AP masks of the reference (receiver.py:21-27), as data: (name, first bit, forced bit values); 'CQ' also forces bits 74, 75 -> 0,
+# 76 -> 1 and 57, 58 -> 0 (:113-116).  The 'RR73' mask is the reference's, quirk included.
+AP_PATTERNS = (("NoAP", 0, ""), ("CQ", 0, "00000000000000000000000000100"), ("RR73", 58, "0111111001110101001"),
+               ("73", 58, "0111111010010100001"), ("RRR", 58, "0111111010010010001"))
+# the ipass ladder (receiver.py:68-107): step -> (attempt, AP variants, arguments)
+_LADDER = {0: ("good91+ldpc", range(5), (35, 5, False)), 2: ("good91", range(2), None), 3: ("ldpc", range(2), (35, 5, False)),
+           4: ("ldpc", range(5), (90, 20, True)), 5: ("osd", range(5), None)}
 
-    def __init__(self, origin, search_grid_bounds, record=None):
+
+class Candidate:
+    """One sync candidate (reference receiver.py:29-135): `origin`, `search_grid_bounds`, and -- for candidates returned by
+    Receiver.search -- the reference's per-candidate state machine: decode(current_max_ipass) advances ONE ladder step per call
+    (:68-107) and check_and_package(duplicate_filter) emits the message dict (:51-66).  Every step runs on the GPU through the
+    stage entry points (ft8rx_llr_grid, ft8rx_fine, ft8rx_ldpc, ft8rx_osd, ft8rx_crc_valid); batched decoding
+    (Receiver.decode_frames) does not go through this class -- it exists so that code written against the reference's
+    Candidate API (the manage_cycle loop, tests/pipeline scripts) runs unchanged."""
+
+    def __init__(self, origin, search_grid_bounds, record=None, rx=None, grid=None, llr_sd_min=5):
         self.origin = origin
         self.search_grid_bounds = search_grid_bounds
         self.record = record
         self.decode_result = None
+        self._rx, self._grid = rx, grid
+        self.on_message = rx.on_message if rx is not None else None
+        self.llr_sd, self.llr_sd_min = 0, llr_sd_min
+        self.ipass = 0
+        self.source = None
+        self.tweaks = "t:%+03d f:%+03d" % (0, 0)
+        self.saved_llrs = []
+        self.n_sync_matches = 100
+        self.decode_notes = ""
+        self.snr = 0
+
+    # ---- receiver.py:51-66
+    def check_and_package(self, duplicate_filter):
+        self.msg_text = " ".join(self.decode_result)
+        o = self.origin
+        key = o["cyclestart_string"] + self.msg_text
+        if key not in duplicate_filter:
+            duplicate_filter.add(key)
+            snr = "%+03d" % self.snr
+            message = {"band": o["band"], "tsec": o["tsec"], "fHz": o["fHz"], "msg_tuple": self.decode_result, "their_snr": snr,
+                       "their_tx_cycle": o["odd_even"],
+                       "all_txt_format": f"{o['cyclestart_string']} {snr} {(o['tsec'] - 0.6):4.1f} {o['fHz']:4.0f} ~ {self.msg_text}",
+                       "cyclestart_string": o["cyclestart_string"], "decode_completed": self._rx.time_source() if self._rx else _time.time(),
+                       "tweaks": self.tweaks, "decode_notes": self.decode_notes + self.tweaks}
+            if self.on_message is not None:
+                self.on_message(message)
+        self.decode_result = "stop"
+
+    def _take_llr(self, llr, sd, snr, source):                       # the tail of _dB_to_llr (receiver.py:208-222)
+        self.llr, self.llr_sd, self.snr, self.source = np.array(llr, np.float32), float(sd), int(snr), source
+        if self.llr_sd <= self.llr_sd_min:
+            self.decode_result = "stop"
+
+    def _set_AP(self, k):                                            # receiver.py:109-117
+        self.pat_name, b0, bits = AP_PATTERNS[k]
+        self.llr = self.llr0.copy()
+        for i, c in enumerate(bits):
+            self.llr[b0 + i] = 5.0 if c == "1" else -5.0
+        if self.pat_name == "CQ":
+            self.llr[74:76] = -5.0
+            self.llr[76] = 5.0
+            self.llr[57:59] = -5.0
+
+    def _attempt(self, what, args):                                  # _decode_good91 / _decode_ldpc / _decode_osd (receiver.py:119-135)
+        from . import decoders as D
+        if self.decode_result:
+            return
+        if what == "good91":
+            self.decode_notes = f"{self.source}_{self.pat_name}_GOOD91 "
+            self.decode_result = D.crc_unpack91(self.llr[:91])
+        elif what == "ldpc":
+            max_nc0, max_its, save = args
+            self.decode_notes = f"{self.source}_{self.pat_name}_LDPC{max_its}"
+            self.decode_result, self.n_its, out = D.ldpc_decode(self.llr, max_nc0, max_its)
+            if save and not self.decode_result and len(out) == 174:
+                self.saved_llrs.append((f"{self.pat_name}_LDPC{max_its}", out))
+        else:
+            self.decode_notes = f"{self.source}_{self.pat_name}_OSD"
+            self.decode_result = D.osd_012(self.llr)
+
+    def decode(self, current_max_ipass):
+        """One step of the ipass ladder per call (reference receiver.py:68-107)."""
+        if self._rx is None:
+            raise _lib.Ft8rxError("this Candidate is a plain record view; Receiver.search() returns decodable ones")
+        if self.ipass > current_max_ipass or self.decode_result == "stop":
+            return
+        rx, o = self._rx, self.origin
+        step = self.ipass
+        if step == 0:
+            with rx._hlock:
+                llr, sd, snr = rx._handle(1).llr_grid(self._grid, [0], [o["f0_idx"]], [o["h0_idx"]])
+            self._take_llr(llr[0], sd[0], snr[0], "grid")
+            self.llr0 = self.llr.copy()
+        elif step == 1:                                              # _get_llr_fine (receiver.py:140-173)
+            spec = rx.audio_in.get_cycle_spectrum()
+            with rx._hlock:
+                f = rx._handle(1).fine(spec[None], [0], [o["f0_idx"]], [o["h0_idx"]])
+            tt, ft = int(f["ttweak"][0]), int(f["ftweak"][0])
+            self.tweaks = " t:%+03d f:%+03d" % (tt, ft)
+            self.n_sync_matches = int(f["nsync"][0])
+            if self.n_sync_matches > 6:
+                o.update({"tsec": float(o["tsec"] + tt / 200), "fHz": float(o["fHz"] + ft / 16)})
+                self._take_llr(f["llr"][0], f["sd"][0], f["snr"][0], "fine")
+            else:
+                self.source = "fine"
+                self.decode_result = "stop"
+        elif step == 6:
+            for self.pat_name, self.llr in self.saved_llrs:
+                self._attempt("osd", None)
+        elif step == 7:
+            self.decode_result = "stop"
+        if step == 2:
+            self.llr0 = self.llr.copy()
+        if step in _LADDER:
+            what, variants, args = _LADDER[step]
+            for k in variants:
+                self._set_AP(k)
+                if what == "good91+ldpc":
+                    self._attempt("good91", None)
+                    self._attempt("ldpc", args)
+                else:
+                    self._attempt(what, args)
+        self.ipass += 1
 
 
 def _pyaudio_device(audio_in, keywords):
@@ -425,7 +542,7 @@ class Receiver:
         for f0i, h0i, sci in found:
             origin = {"h0_idx": h0i, "f0_idx": f0i, "tsec": h0i / 25.0, "fHz": 3.125 * f0i, "score": sci,
                       "cyclestart_string": cyclestart_string, "band": self.band, "odd_even": odd_even}
-            cands.append(Candidate(origin, [r0 + h0i + 4, r0 + h0i + 4 * 71]))
+            cands.append(Candidate(origin, [r0 + h0i + 4, r0 + h0i + 4 * 71], rx=self, grid=grid))
         self.candidates = cands
         return cands
 
