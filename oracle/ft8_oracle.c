@@ -220,8 +220,12 @@ void ft8o_spectrogram(const int16_t* audio, const ft8o_config* c, float* grid) {
             cpx w = WR[k];
             float xr = er + (w.re * orr - w.im * oi);
             float xi = ei + (w.re * oi + w.im * orr);
-            float mag = sqrtf(xr * xr + xi * xi);
-            out[k] = 20.0f * ft8o_log10f(mag + 1e-12f);
+            /* 20 log10(|X| + 1e-12) (receiver.py:292) as 10 log10(max(|X|^2, 1e-24)): the same value to well below a float ulp wherever
+             * |X| > 1e-6 (any frame that is not digital silence), exactly -240 dB for |X| = 0 as in the reference, and no square
+             * root in the kernel's epilogue */
+            float pw = xr * xr + xi * xi;
+            if (!(pw > 1e-24f)) pw = 1e-24f;
+            out[k] = 10.0f * ft8o_log10f(pw);
         }
     }
     free(z);
