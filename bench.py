@@ -52,17 +52,18 @@ VALU_PEAK_TFLOPS = 157.3
 # final IFFT 160 k, a 32-point symbol DFT on a lane quad 0.6 k; final grid: 21 Costas symbols always, the 58 payload symbols for the
 # 41 % of candidates that pass the gate (45 symbols on average): 140 k + 56 x 0.6 k + 8 x (140 k + 7 x 0.6 k) + 160 k + 45 x 0.6 k
 EXEC_FLOP_FINE_CAND = 140e3 + 56 * 0.6e3 + 8 * (140e3 + 7 * 0.6e3) + 160e3 + 45 * 0.6e3
-PMC_PROFILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-                                                                  # command (tools/pmc_summary.py), B = 256
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py, collected by tools/collect_profiles.sh),
+# by frames per launch: B = 256 (config 1) and B = 4096 (config 2 as stated: BP 30 iterations)
+PMC_PROFILES = {256: os.path.join(ROOT, "profiles", "pmc_latest.json"), 4096: os.path.join(ROOT, "profiles", "pmc_config2_latest.json")}
 
 
 def pmc_traffic(kernel_stage, B):
     """HBM bytes per launch of the stage's kernels from the committed PMC profile (collected at B=256), or None."""
     names = {"spectrogram": ["k_spectrogram"], "sync": ["k_sync"], "fine": ["k_fine"], "osd": ["k_osd"],
              "cycle_fft": ["k_cyc_a", "k_cyc_b", "k_cyc_c"], "grid_llr": ["k_grid_llr"], "topk": ["k_topk"]}.get(kernel_stage)
-    if not names or not os.path.exists(PMC_PROFILE) or B != 256:
+    if not names or B not in PMC_PROFILES or not os.path.exists(PMC_PROFILES[B]):
         return None
-    prof = json.load(open(PMC_PROFILE))
+    prof = json.load(open(PMC_PROFILES[B]))
     if not all(n in prof for n in names):
         return None
     return sum(prof[n]["hbm_bytes"] for n in names)
@@ -70,9 +71,9 @@ def pmc_traffic(kernel_stage, B):
 
 def per_kernel_hbm(acc, B):
     """Measured HBM GB/s of every stage that has PMC traffic on file (B = 256 only): bytes per launch / HIP-event duration."""
-    if not os.path.exists(PMC_PROFILE) or B != 256:
+    if B not in PMC_PROFILES or not os.path.exists(PMC_PROFILES[B]):
         return None
-    prof = json.load(open(PMC_PROFILE))
+    prof = json.load(open(PMC_PROFILES[B]))
     groups = {"spectrogram": ["k_spectrogram"], "sync": ["k_sync"], "grid_llr": ["k_grid_llr"], "cycle_fft": ["k_cyc_a", "k_cyc_b", "k_cyc_c"],
               "fine": ["k_fine"], "osd": ["k_osd"]}
     out = {}
@@ -152,6 +153,37 @@ def _cpulist(text):
     return out
 
 
+def _fmt_cpus(cpus):
+    """[0,1,2,3,8,9] -> "0-3,8-9"."""
+    out, i = [], 0
+    cpus = sorted(cpus)
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(f"{cpus[i]}-{cpus[j]}" if j > i else f"{cpus[i]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def _split_whole_cores(cpus, k, n):
+    """Part k of n of a CPU list, keeping the hardware threads of one core together (so that two ranks never share a physical core)."""
+    groups, seen = [], set()
+    for c in sorted(cpus):
+        if c in seen:
+            continue
+        try:
+            sib = [x for x in _cpulist(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()) if x in cpus]
+        except OSError:
+            sib = [c]
+        sib = sib or [c]
+        seen.update(sib)
+        groups.append(sorted(sib))
+    per = max(1, len(groups) // n)
+    mine = groups[k * per:(k + 1) * per] or groups
+    return sorted(c for g in mine for c in g)
+
+
 def place_rank(local_rank, world, bus_id_of):
     """Pin this rank (and every thread it starts later: the packaging pool, RCCL's and HIP's helper threads) to its own slice of host
     cores -- on the NUMA node of its GPU when sysfs says which one that is -- so that eight ranks do not float over both sockets and
@@ -175,15 +207,13 @@ def place_rank(local_rank, world, bus_id_of):
         if node_cpus:
             peers = [r for r in range(world) if nodes[r] == node]          # ranks whose GPUs hang off the same node share its cores
             k, n = peers.index(local_rank), len(peers)
-            per = max(1, len(node_cpus) // n)
-            mine = node_cpus[k * per:(k + 1) * per] or node_cpus
-            info.update(numa_node=node, how=f"slice {k + 1}/{n} of NUMA node {node}")
+            mine = _split_whole_cores(node_cpus, k, n)
+            info.update(numa_node=node, how=f"slice {k + 1}/{n} of NUMA node {node} (whole cores)")
         else:
-            per = max(1, len(allowed) // max(1, world))
-            mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
-            info.update(how=f"slice {local_rank + 1}/{world} of the {len(allowed)} allowed cores (no NUMA node known for the GPU)")
+            mine = _split_whole_cores(allowed, local_rank, max(1, world))
+            info.update(how=f"slice {local_rank + 1}/{world} of the {len(allowed)} allowed CPUs (whole cores; no NUMA node known for the GPU)")
         os.sched_setaffinity(0, mine)
-        info["cpus"] = f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else ",".join(map(str, mine))
+        info["cpus"] = _fmt_cpus(mine)
         info["n_cpus"] = len(mine)
     except Exception as e:                                   # placement is an optimisation
         info["how"] = f"unpinned ({type(e).__name__}: {e})"
@@ -470,8 +500,8 @@ def main():
                        "host_pointer_pipelined_entry_frames_per_s_pinned": pcie_pinned, "parallelism": f"frames sharded over {world} GPU(s), no collective on the decode path", "gather": gather_note},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
-                         "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of this command at B = 256, "
-                                           "collected by tools/collect_profiles.sh; not measured in this run)" if pmc_traffic(dom, B) is not None else None,
+                         "traffic_source": f"profiles/{os.path.basename(PMC_PROFILES[B])} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of this "
+                                           f"command at B = {B}, collected by tools/collect_profiles.sh; not measured in this run)" if pmc_traffic(dom, B) is not None else None,
                          "kernel_ms": dom_ms, "alg_bytes_per_launch": ALG_BYTES[dom] * B,
                          "whole_path_frac": value / world * ALG_BYTES_FRAME / 1e9 / HBM_PEAK_GBS,
                          # measured HBM rate of each stage (PMC bytes / event time): the memory-bound stages sit near the roofline

@@ -47,10 +47,23 @@ AP_NAMES = ["NoAP", "CQ", "RR73", "73", "RRR"]
 _libs = {}
 
 
+def _cpu_has_fma():
+    try:
+        return any(" fma " in (l + " ") for l in open("/proc/cpuinfo") if l.startswith("flags"))
+    except OSError:
+        return False
+
+
 def build(force=False):
-    src = max(os.path.getmtime(os.path.join(HERE, f)) for f in ("ft8_oracle.c", "ft8_oracle.h", "ft8_tables.h"))
+    src = max(os.path.getmtime(os.path.join(HERE, f)) for f in ("ft8_oracle.c", "ft8_oracle.h", "ft8_tables.h", "Makefile"))
+    # the Makefile adds -mfma where the CPU has it (same results, faster fmaf); a library built on another machine with the flag must
+    # not be loaded on a CPU without the instruction
+    flags_file = os.path.join(HERE, "_build", ".flags")
+    built_fma = os.path.exists(flags_file) and "-mfma" in open(flags_file).read()
+    if built_fma and not _cpu_has_fma():
+        force = True
     if force or any(not os.path.exists(p) or os.path.getmtime(p) < src for p in (LIB_PATH, LIB_PATH_WIDE)):
-        subprocess.check_call(["make", "-s", "-C", HERE])
+        subprocess.check_call(["make", "-s", "-B" if force else "-s", "-C", HERE])
     return LIB_PATH
 
 

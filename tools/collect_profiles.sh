@@ -4,7 +4,7 @@
 # rocprofv3 passes are separate runs (kernel trace + stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE), each with the
 # program itself after `--`.  Everything is bounded by `timeout`.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -46,6 +46,9 @@ timeout 900 python3 bench.py --config 4 --no-cpu-baseline > "$OUT/${TAG}_bench_c
 timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline --signals 8 --snr -24 -14 > "$OUT/${TAG}_bench_b4096_lowsnr.json" 2>> "$OUT/${TAG}_big.err"
 # two ranks on this one GPU over gloo: the N > 1 flow of bench.py (sharding, barriers, gather) -- not a scaling number
 timeout 900 python3 bench.py --gpus 2 --backend gloo --no-host-entry > "$OUT/${TAG}_bench_2ranks_1gpu_gloo.json" 2>> "$OUT/${TAG}_big.err"
+# the RCCL gather path in a one-rank nccl group on this one GPU (config-3 shard): device-resident buffers, per-rank figures, placement
+timeout 900 python3 bench.py --gpus 1 --backend nccl --force-gather --config 3 --no-cpu-baseline --no-host-entry > "$OUT/${TAG}_bench_config3_forced_rccl_gather.json" 2>> "$OUT/${TAG}_big.err"
+timeout 300 python3 tools/host_breakdown.py > "$OUT/${TAG}_host_breakdown.txt" 2>> "$OUT/${TAG}_big.err"
 # SQ counters per kernel (three --pmc passes)
 timeout 1500 tools/pmc_sq.sh "${TAG}" > /dev/null 2>&1
 timeout 1500 python3 tools/sensitivity.py 2048 -24 -20 > "$OUT/${TAG}_config4_sensitivity.txt" 2>> "$OUT/${TAG}_big.err"
