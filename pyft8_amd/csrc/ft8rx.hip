@@ -103,6 +103,10 @@ struct ft8rx_handle {
     ft8rx_record* h_rec[2]; int32_t* h_cnt[2]; ft8rx_event* h_ev[2]; int32_t* h_evc[2];
     hipEvent_t ev_comp[2], ev_done[2];
     int slot_enq, slot_fetch, inflight, last_slot, slot_B[2];
+    // free-running chunk streams (launch_batch): the chunk chains of consecutive batches follow each other on their own streams
+    // without a per-batch fork / join; need_barrier = something else has used the shared workspaces (or the partition changed) since
+    hipEvent_t ev_cdone[2][8];
+    bool free_running, need_barrier; int part_B, part_n;
     // Large batches (event log > EV_EAGER_BYTES): k_ev_scan / k_ev_compact pack the used entries of the log and write them straight
     // into page-locked host memory (h_evpacked; d_evpacked = the same buffer's device address); the fetch spreads them over h_ev's
     // [frame][cap] rows (fetch_events)
@@ -174,6 +178,19 @@ struct Scratch {
     template <typename T> T* put(const T* src, size_t n) { T* q = get<T>(n); if (q && hipMemcpy(q, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr; return q; }
 };
 
+// Everything that is not a pipelined batch (stage entry points, the synchronous host entry, subtraction, profiling passes) uses the
+// handle's shared workspaces from the main stream; while the chunk streams run free (launch_batch) their work is not ordered
+// against the main stream, so such calls first wait until the batches in flight are complete.
+static int quiesce(ft8rx_handle* h) {
+    if (h->free_running) {
+        HIPCHK(h, hipStreamSynchronize(h->copy_s));           // the result copy of the last batch waits for every chunk stream
+        h->free_running = false;
+    }
+    h->need_barrier = true;
+    return 0;
+}
+#define ENTER(h) do { HIPCHK(h, hipSetDevice((h)->device)); { const int _q = quiesce(h); if (_q) return _q; } } while (0)
+
 extern "C" {
 
 int ft8rx_default_config(ft8rx_config* c) {
@@ -216,6 +233,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
     for (auto& c : h->arena) hipFree(c.p);
     for (auto e : h->pev) hipEventDestroy(e);
     for (int i = 0; i < 8; i++) { if (h->sub[i]) hipStreamDestroy(h->sub[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
+    for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) if (h->ev_cdone[k][i]) hipEventDestroy(h->ev_cdone[k][i]);
     if (h->copy_s) hipStreamDestroy(h->copy_s);
     if (h->h2d_s) hipStreamDestroy(h->h2d_s);
     for (int i = 0; i < 16; i++) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
@@ -250,6 +268,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     h->copy_s = nullptr; h->slot_evpending[0] = h->slot_evpending[1] = false; h->h2d_s = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
     for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->h_evpacked[k] = nullptr; h->d_evpacked[k] = nullptr; h->d_evoffs[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
+    for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) h->ev_cdone[k][i] = nullptr;
+    h->free_running = false; h->need_barrier = true; h->part_B = h->part_n = 0;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
     h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr; h->d_ones = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
@@ -475,7 +495,6 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
         cs = h->h2d_s;
         HIPCHK(h, hipStreamWaitEvent(cs, h->ev_comp[slot], 0));             // the kernels that last read this staging buffer are done
     }
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));          // the slot's previous results have left the device
     // synchronous host entry: twice as many chunks, so that the first kernels start after 1/8 of the copy; the pipelined entry's copies
     // already overlap the previous batch, so it keeps the 4 larger chunks of the device-resident path
     int nc = h->profiling ? 1 : ((host_audio && !pipelined) ? 2 * h->n_streams : h->n_streams);
@@ -492,6 +511,42 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[i - 1], hipEventDisableTiming));
     }
     auto chunk_stream = [&](int k) { const int i = k % ns; return i == 0 ? h->stream : h->sub[i - 1]; };
+    // Free-running chunk streams: with the audio resident (or staged by the pipelined host entry) and one chunk per stream, chunk i of
+    // batch k+1 simply follows chunk i of batch k on stream i.  Every workspace is indexed by frame, so a stream only ever touches
+    // its own frame range and in-stream order is all the ordering the chains need; only the result copy waits for all of them.
+    // Without the per-batch fork / join a stream that finishes its half early starts on the next batch while the other one is still
+    // in its tail.  Anything else that uses the workspaces (stage entry points, the synchronous entry, a different partition)
+    // goes through quiesce() / need_barrier.
+    // (A/B on one box, profiles/r03_notes.md: 48 498 -> 49 001 frames/s end to end, 48 167 -> 48 894 including H2D.)
+    const bool free_run = !h->profiling && nc > 1 && nc == ns && !(host_audio && !pipelined);
+    if (free_run) {
+        for (int i = 0; i < ns; i++) for (int k = 0; k < 2; k++)
+            if (!h->ev_cdone[k][i]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_cdone[k][i], hipEventDisableTiming));
+        const int per = (B + nc - 1) / nc;
+        if (h->need_barrier || h->part_B != B || h->part_n != nc) {
+            // first batch of a run (or another partition): everything issued so far, on any stream of this handle, first
+            if (h->free_running) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comp[h->last_slot], 0));
+            HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+            for (int i = 1; i < ns; i++) HIPCHK(h, hipStreamWaitEvent(h->sub[i - 1], h->ev_fork, 0));
+            h->need_barrier = false; h->part_B = B; h->part_n = nc;
+        }
+        if (pipelined) {
+            HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, cs));
+            HIPCHK(h, hipEventRecord(h->ev_chunk[0], cs));
+        }
+        for (int k = 0; k < nc; k++) {
+            const int f0 = k * per, n = (f0 + per <= B) ? per : B - f0;
+            hipStream_t s = chunk_stream(k);
+            HIPCHK(h, hipStreamWaitEvent(s, h->ev_done[slot], 0));          // the slot's previous results have left the device
+            if (pipelined) HIPCHK(h, hipStreamWaitEvent(s, h->ev_chunk[0], 0));
+            if (n > 0) enqueue_chain(h, d_audio, f0, n, s, false, slot, k);
+            HIPCHK(h, hipEventRecord(h->ev_cdone[slot][k], s));
+            HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_cdone[slot][k], 0));
+        }
+        h->free_running = true;
+    } else {
+    { const int q = quiesce(h); if (q) return q; }
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));          // the slot's previous results have left the device
     if (nc <= 1) {
         if (host_audio) HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
         enqueue_chain(h, d_audio, 0, B, h->stream, h->profiling, slot, 0);
@@ -537,15 +592,19 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i - 1], 0));
         }
     }
-    HIPCHK(h, hipGetLastError());
-    // results -> page-locked host buffers on the copy stream (overlaps the next batch, which computes into the other slot)
-    const int mc = h->cfg.max_cands;
-    if (h->d_evpacked[slot] && (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES) {      // pack the event log (see the copy below)
-        k_ev_scan<<<1, 1024, 0, h->stream>>>(h->s_evcount[slot], B, h->d_evoffs[slot]);
-        k_ev_compact<<<B, 64, 0, h->stream>>>(h->s_ev[slot], h->s_evcount[slot], h->d_evoffs[slot], h->d_evpacked[slot]);
     }
-    HIPCHK(h, hipEventRecord(h->ev_comp[slot], h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_comp[slot], 0));
+    HIPCHK(h, hipGetLastError());
+    // results -> page-locked host buffers on the copy stream (overlaps the next batch, which computes into the other slot).
+    // fin = the stream on which "all kernels of this batch are done" is known: the main stream after its joins, or -- free-running
+    // chunks -- the copy stream, which has just been made to wait for every chunk
+    const int mc = h->cfg.max_cands;
+    hipStream_t fin = free_run ? h->copy_s : h->stream;
+    if (h->d_evpacked[slot] && (size_t)B * FT8RX_EVENT_CAP * sizeof(ft8rx_event) > EV_EAGER_BYTES) {      // pack the event log (see the copy below)
+        k_ev_scan<<<1, 1024, 0, fin>>>(h->s_evcount[slot], B, h->d_evoffs[slot]);
+        k_ev_compact<<<B, 64, 0, fin>>>(h->s_ev[slot], h->s_evcount[slot], h->d_evoffs[slot], h->d_evpacked[slot]);
+    }
+    HIPCHK(h, hipEventRecord(h->ev_comp[slot], fin));
+    if (!free_run) HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_comp[slot], 0));
     HIPCHK(h, hipMemcpyAsync(h->h_cnt[slot], h->s_ncand[slot], sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->copy_s));
     HIPCHK(h, hipMemcpy2DAsync(h->h_rec[slot], sizeof(ft8rx_record) * mc, h->s_rec[slot], sizeof(ft8rx_record) * MAXC,
                                sizeof(ft8rx_record) * mc, B, hipMemcpyDeviceToHost, h->copy_s));
@@ -649,7 +708,8 @@ int ft8rx_results_to_device(ft8rx_handle* h, int B, ft8rx_record* d_records, int
     HIPCHK(h, hipSetDevice(h->device));
     const int slot = h->last_slot;
     if (B > h->slot_B[slot]) { set_err(h, "ft8rx_results_to_device: %d frames requested, the batch had %d", B, h->slot_B[slot]); return -1; }
-    HIPCHK(h, hipStreamSynchronize(h->stream));                      // the batch's kernels are done (results sit in s_*[slot])
+    HIPCHK(h, hipEventSynchronize(h->ev_comp[slot]));                // the batch's kernels are done on every chunk stream (results sit in s_*[slot])
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     const int mc = h->cfg.max_cands;
     if (d_counts) HIPCHK(h, hipMemcpyAsync(d_counts, h->s_ncand[slot], sizeof(int32_t) * B, hipMemcpyDeviceToDevice, h->stream));
     if (d_records) HIPCHK(h, hipMemcpy2DAsync(d_records, sizeof(ft8rx_record) * mc, h->s_rec[slot], sizeof(ft8rx_record) * MAXC,
@@ -690,7 +750,7 @@ int ft8rx_decode_messages(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_me
 
 int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid) {
     if (!h || !audio || !grid || B < 1 || B > h->max_frames) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
     k_spectrogram<<<dim3(376, B), SPEC_NT, 0, h->stream>>>(h->d_audio, h->d_grid, h->T);
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -700,7 +760,7 @@ int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid)
 
 int ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row) {
     if (!h || !window3840 || !row) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     float* d_row = h->d_best_score;                      // any scratch of FT8RX_GRID_COLS floats (NF0MAX >= that): not in use between batches
     HIPCHK(h, hipMemcpyAsync(h->d_audio, window3840, sizeof(int16_t) * 3840, hipMemcpyHostToDevice, h->stream));
     k_hop_spectrum<<<1, SPEC_NT, 0, h->stream>>>(h->d_audio, d_row, h->T);
@@ -711,7 +771,7 @@ int ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row) {
 
 int ft8rx_sync_search(ft8rx_handle* h, const float* grid, int B, int32_t* f0_idx, int32_t* h0_idx, float* score, int32_t* counts) {
     if (!h || !grid || B < 1 || B > h->max_frames) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     const ft8rx_config& c = h->cfg;
     HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
     const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
@@ -734,7 +794,7 @@ int ft8rx_sync_scores(ft8rx_handle* h, const float* grid, int B, int f0_lo, int 
     if (!h || !grid || !score || !h0_idx || B < 1 || B > h->max_frames) return -1;
     if (f0_lo < 4 || f0_hi <= f0_lo || f0_hi > FT8RX_GRID_COLS - 15 || f0_hi - f0_lo > NF0MAX) {
         set_err(h, "ft8rx_sync_scores: f0 range [%d, %d) outside [4, %d]", f0_lo, f0_hi, FT8RX_GRID_COLS - 15); return -1; }
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     ft8rx_config c = h->cfg;
     c.f0_lo = f0_lo; c.f0_hi = f0_hi;
     HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
@@ -750,7 +810,7 @@ int ft8rx_sync_scores(ft8rx_handle* h, const float* grid, int B, int f0_lo, int 
 int ft8rx_llr_grid(ft8rx_handle* h, const float* grid, int B, int n, const int32_t* frame, const int32_t* f0_idx,
                    const int32_t* h0_idx, float* llr, float* sd, int32_t* snr) {
     if (!h || !grid || B < 1 || B > h->max_frames || n < 1) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
     std::vector<int32_t> trip(3 * (size_t)n);
     for (int i = 0; i < n; i++) { trip[3 * i] = frame[i]; trip[3 * i + 1] = f0_idx[i]; trip[3 * i + 2] = h0_idx[i]; }
@@ -769,7 +829,7 @@ int ft8rx_llr_grid(ft8rx_handle* h, const float* grid, int B, int n, const int32
 
 int ft8rx_cycle_spectrum(ft8rx_handle* h, const int16_t* audio, int B, float* spec) {
     if (!h || !audio || !spec || B < 1 || B > h->max_frames) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
     k_cyc_a<<<dim3(40, B), 256, 0, h->stream>>>(h->d_audio, h->d_A, h->T);
     k_cyc_bc<<<dim3(CYC_BC_GRID, B), 256, 0, h->stream>>>(h->d_A, h->d_spec, h->T);
@@ -781,7 +841,7 @@ int ft8rx_cycle_spectrum(ft8rx_handle* h, const int16_t* audio, int B, float* sp
 int ft8rx_fine(ft8rx_handle* h, const float* spec, int B, int n, const int32_t* frame, const int32_t* f0_idx, const int32_t* h0_idx,
                int32_t* ret, int32_t* ttweak, int32_t* ftweak, int32_t* nsync, float* llr, float* sd, int32_t* snr, float* sgrid) {
     if (!h || !spec || B < 1 || B > h->max_frames || n < 1) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     HIPCHK(h, hipMemcpy(h->d_spec, spec, sizeof(cpx) * (size_t)B * FT8RX_SPEC_BINS, hipMemcpyHostToDevice));
     std::vector<int32_t> trip(3 * (size_t)n);
     for (int i = 0; i < n; i++) { trip[3 * i] = frame[i]; trip[3 * i + 1] = f0_idx[i]; trip[3 * i + 2] = h0_idx[i]; }
@@ -806,7 +866,7 @@ int ft8rx_fine(ft8rx_handle* h, const float* spec, int B, int n, const int32_t* 
 int ft8rx_ldpc(ft8rx_handle* h, const float* llr, int n, int max_ncheck0, int max_iters, int32_t* ok, uint64_t* msg_lo,
                uint64_t* msg_hi, int32_t* n_its, int32_t* has_out, float* llr_out) {
     if (!h || !llr || n < 1) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     Scratch S{h};
     float* d_in = S.put(llr, (size_t)n * 174); NEED(d_in);
     float* d_out = S.get<float>((size_t)n * 174); NEED(d_out);
@@ -828,7 +888,7 @@ int ft8rx_osd_ext(ft8rx_handle* h, const float* llr, int n, int singleflips, int
         max_hd < 0 || max_hd > 174) { set_err(h, "ft8rx_osd: flip counts out of range"); return -1; }
     const std::vector<uint32_t> tr = osd_trial_table(singleflips, doubleflips, tripleflips);
     if (tr.size() > OSD_MAXTRIALS) { set_err(h, "ft8rx_osd: %zu trials exceed %d", tr.size(), OSD_MAXTRIALS); return -1; }
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     Scratch S{h};
     float* d_in = S.put(llr, (size_t)n * 174); NEED(d_in);
     uint32_t* d_tr = S.put(tr.data(), tr.size()); NEED(d_tr);
@@ -852,7 +912,7 @@ int ft8rx_osd(ft8rx_handle* h, const float* llr, int n, int singleflips, int dou
 
 int ft8rx_crc_valid(ft8rx_handle* h, const float* cw91, int n, int32_t* res, uint64_t* msg_lo, uint64_t* msg_hi) {
     if (!h || !cw91 || n < 1) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     Scratch S{h};
     float* d_in = S.put(cw91, (size_t)n * 91); NEED(d_in);
     int32_t* d_res = S.get<int32_t>(n); NEED(d_res);
@@ -868,7 +928,7 @@ int ft8rx_crc_valid(ft8rx_handle* h, const float* cw91, int n, int32_t* res, uin
 
 int ft8rx_valid77(ft8rx_handle* h, const uint64_t* msg_lo, const uint64_t* msg_hi, int n, int32_t* valid) {
     if (!h || !msg_lo || !msg_hi || n < 1) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     Scratch S{h};
     uint64_t* d_lo = S.put(msg_lo, n); NEED(d_lo);
     uint64_t* d_hi = S.put(msg_hi, n); NEED(d_hi);
@@ -883,7 +943,7 @@ int16_t* ft8rx_staging_audio(ft8rx_handle* h) { return h ? h->d_audio : nullptr;
 
 int ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes) {
     if (!h || !dst || !d_src) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     HIPCHK(h, hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -892,7 +952,7 @@ int ft8rx_subtract(ft8rx_handle* h, int16_t* d_audio, int B, ft8rx_subsig* sigs,
                    int refine, float* audio_f32_out) {
     if (!h || !d_audio || !sigs || !counts) return -1;
     if (B < 1 || B > h->max_frames || max_sigs < 1 || max_sigs > 256 || refine < 0 || refine > 3) { set_err(h, "ft8rx_subtract: bad n_frames / max_sigs / refine"); return -1; }
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!h->d_wf) {              // first use: working buffers for max_frames frames and the GFSK pulse tables (transmitter.py:41-50)
         const size_t MB = (size_t)h->max_frames;
@@ -1027,7 +1087,7 @@ int ft8rx_synth_frames_ex(ft8rx_handle* h, uint64_t seed, int first_index, int n
                           const void* signal_table, int signal_bytes, const double* pulse_cumsum, int16_t* d_audio, int no_noise) {
     if (!h || !signal_table || !pulse_cumsum || !d_audio || n_frames < 1 || n_signals < 0 || n_signals > 64) return -1;
     if (signal_bytes != (int)sizeof(SynthSig)) { set_err(h, "ft8rx_synth_frames: signal record is %d bytes, expected %d", signal_bytes, (int)sizeof(SynthSig)); return -1; }
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     Scratch S{h};
     SynthSig* d_s = S.put((const SynthSig*)signal_table, (size_t)n_frames * (n_signals ? n_signals : 1)); NEED(d_s);
     double* d_q = S.put(pulse_cumsum, 5761); NEED(d_q);
@@ -1072,7 +1132,7 @@ int ft8rx_set_reject_log(const char* path) { hostmsg::set_reject_log(path); retu
 #ifdef FINE_TIMING
 int ft8rx_debug_fine_times(ft8rx_handle* h, unsigned long long* out32, int reset) {      // timing-only builds (tools/fine_timing.sh)
     if (!h) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     HIPCHK(h, hipDeviceSynchronize());
     if (out32) HIPCHK(h, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_fine_t), sizeof(unsigned long long) * 32));
     if (reset) { unsigned long long z[32] = {0}; HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_fine_t), z, sizeof(z))); }
@@ -1082,7 +1142,7 @@ int ft8rx_debug_fine_times(ft8rx_handle* h, unsigned long long* out32, int reset
 
 int ft8rx_math_probe(ft8rx_handle* h, int which, const float* x, int n, float* y) {
     if (!h || !x || !y || n < 1) return -1;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     Scratch S{h};
     if (which == 0 || which == 1) {
         float* d_x = S.put(x, n); NEED(d_x);
