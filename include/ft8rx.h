@@ -127,6 +127,10 @@ int  ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int n_frames,
  * all have been fetched); at most two batches are retained -- a third enqueue drops the oldest.  Steady state:
  *   enqueue(0); for k = 1..: enqueue(k); fetch(k-1); <host message layer of k-1>   -- the GPU never waits for the host. */
 int  ft8rx_enqueue_batch(ft8rx_handle* h, const int16_t* d_audio, int n_frames);
+/* Ordering: consecutive enqueued batches of the same size run as free-running chunk streams (chunk i of batch k+1 follows chunk i of
+ * batch k on its own HIP stream, no per-batch fork / join; only the result copy waits for all chunks).  Every other entry point of
+ * the handle -- stage functions, ft8rx_decode_batch, ft8rx_subtract, profiling passes -- first waits until the batches in flight are
+ * complete, so mixing them with enqueue / fetch is safe (and costs that wait). */
 /* The same pipeline fed from HOST memory: the audio of batch k+1 is copied (in chunks, on a dedicated stream, into the second of two
  * device staging buffers) while batch k computes, so in steady state  enqueue_host(k+1); fetch(k); <host layer of k>  hides the PCIe
  * transfer behind the kernels.  `audio` must stay valid until the batch has been fetched; page-locked memory (ft8rx_alloc_host) makes

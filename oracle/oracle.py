@@ -49,7 +49,8 @@ _libs = {}
 
 def _cpu_has_fma():
     try:
-        return any(" fma " in (l + " ") for l in open("/proc/cpuinfo") if l.startswith("flags"))
+        with open("/proc/cpuinfo") as f:
+            return any(" fma " in (ln.rstrip() + " ") for ln in f if ln.startswith("flags"))
     except OSError:
         return False
 
@@ -59,7 +60,10 @@ def build(force=False):
     # the Makefile adds -mfma where the CPU has it (same results, faster fmaf); a library built on another machine with the flag must
     # not be loaded on a CPU without the instruction
     flags_file = os.path.join(HERE, "_build", ".flags")
-    built_fma = os.path.exists(flags_file) and "-mfma" in open(flags_file).read()
+    built_fma = False
+    if os.path.exists(flags_file):
+        with open(flags_file) as f:
+            built_fma = "-mfma" in f.read()
     if built_fma and not _cpu_has_fma():
         force = True
     if force or any(not os.path.exists(p) or os.path.getmtime(p) < src for p in (LIB_PATH, LIB_PATH_WIDE)):

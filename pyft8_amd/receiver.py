@@ -78,6 +78,22 @@ _LADDER = {0: ("good91+ldpc", range(5), (35, 5, False)), 2: ("good91", range(2),
            4: ("ldpc", range(5), (90, 20, True)), 5: ("osd", range(5), None)}
 
 
+def frames_from_wav(path, cycle_offset_s=0.0):
+    """A mono 16-bit 12 kHz .wav (what the reference's pipeline scripts read with the `wave` module, tests/pipeline/*.py; its two
+    fixture recordings) -> int16 [n_frames, 180000]: the recording cut into consecutive 15-s cycles from `cycle_offset_s` on, the
+    last one padded with digital silence (frames_from_ragged).  Anything else than mono / 16 bit / 12 kHz is rejected -- resampling
+    is not this package's business."""
+    import wave
+    with wave.open(path, "rb") as w:
+        if (w.getnchannels(), w.getsampwidth(), w.getframerate()) != (1, 2, SAMP_RATE):
+            raise _lib.Ft8rxError(f"{path}: need mono 16-bit {SAMP_RATE} Hz, got {w.getnchannels()} ch / {8 * w.getsampwidth()} bit / {w.getframerate()} Hz")
+        x = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    x = x[int(round(cycle_offset_s * SAMP_RATE)):]
+    if len(x) == 0:
+        return np.zeros((0, _lib.NSAMP), np.int16)
+    return frames_from_ragged([x[i:i + _lib.NSAMP] for i in range(0, len(x), _lib.NSAMP)])
+
+
 class Candidate:
     """One sync candidate (reference receiver.py:29-135): `origin`, `search_grid_bounds`, and -- for candidates returned by
     Receiver.search -- the reference's per-candidate state machine: decode(current_max_ipass) advances ONE ladder step per call

@@ -366,3 +366,47 @@ def test_oracle_subtract_matches_reference_golden():
         assert all(done) == (ci != 3)
         assert np.abs(audio[g["pos"]] - g[f"c{ci}_after"]).max() < 1e-5 * g[f"c{ci}_stats"][0]
         assert abs(audio.astype(np.float64).std() - g[f"c{ci}_stats"][1]) < 1e-3
+
+
+def test_frames_from_wav_reads_the_reference_fixture_recordings(tmp_path):
+    """receiver.frames_from_wav: the reference's two fixture recordings (mono int16 12 kHz, 15 s) come back as the golden's samples;
+    longer recordings are cut into cycles, the last one zero-padded; other formats are rejected."""
+    import wave
+    from conftest import load_golden
+    from pyft8_amd import _lib
+    from pyft8_amd.receiver import frames_from_wav
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    for name in ("test_08", "test_09"):
+        fr = frames_from_wav(os.path.join(gdir, name + ".wav"))
+        assert fr.shape == (1, 180000) and fr.dtype == np.int16 and np.array_equal(fr[0], load_golden(name)[0])
+    long = np.arange(400000, dtype=np.int32).astype(np.int16)
+    p = str(tmp_path / "long.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(12000); w.writeframes(long.tobytes())
+    fr = frames_from_wav(p)
+    assert fr.shape == (3, 180000) and np.array_equal(fr[1], long[180000:360000]) and np.array_equal(fr[2, :40000], long[360000:]) and not fr[2, 40000:].any()
+    assert frames_from_wav(p, cycle_offset_s=30.0).shape == (1, 180000)
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(12000); w.writeframes(long[:1000].tobytes())
+    with pytest.raises(_lib.Ft8rxError, match="mono"):
+        frames_from_wav(p)
+
+
+def test_bench_rank_placement_helpers():
+    """bench.py's per-rank CPU placement (VERDICT r2 #12): whole cores per rank, disjoint slices, readable ranges; never fatal."""
+    import bench
+    assert bench._fmt_cpus([0, 1, 2, 3, 8, 9, 11]) == "0-3,8-9,11"
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    cpus = sorted(os.sched_getaffinity(0))
+    parts = [bench._split_whole_cores(cpus, k, 2) for k in range(2)]
+    assert all(parts) and (len(cpus) < 2 or not set(parts[0]) & set(parts[1]))
+    keep = os.sched_getaffinity(0)
+    try:
+        info = bench.place_rank(0, 2, lambda r: None)                       # no PCI address known: slices of the allowed CPUs
+        assert info["n_cpus"] >= 1 and "slice 1/2" in info["how"] and os.sched_getaffinity(0) == set(parts[0])
+        info = bench.place_rank(1, 2, lambda r: "0000:ff:1f.7")             # an address sysfs does not know: same fallback
+        assert "slice 2/2" in info["how"]
+        bad = bench.place_rank(0, 1, lambda r: 1 / 0)                       # placement is an optimisation: errors are reported, not raised
+        assert bad["how"].startswith("unpinned (ZeroDivisionError")
+    finally:
+        os.sched_setaffinity(0, keep)
