@@ -179,8 +179,9 @@ class Handle:
         return self._run(audio, B)
 
     def _alloc_out(self, B):
+        # records / counts are written in full by the library; of the event rows only the used entries are (the rest must read as zero)
         mc = self.cfg.max_cands
-        return (np.zeros((B, mc), RECORD_DTYPE), np.zeros(B, np.int32), np.zeros((B, EVENT_CAP), EVENT_DTYPE), np.zeros(B, np.int32))
+        return (np.empty((B, mc), RECORD_DTYPE), np.empty(B, np.int32), np.zeros((B, EVENT_CAP), EVENT_DTYPE), np.empty(B, np.int32))
 
     def _run(self, audio, B):
         rec, cnt, ev, evc = self._alloc_out(B)
