@@ -587,6 +587,53 @@ def test_result_slots_pipeline_order():
     store.close()
 
 
+def test_free_running_chunks_with_other_calls_in_flight(ocfg):
+    """Round 3: consecutive enqueued batches run as free-running chunk streams (no per-batch fork / join; include/ft8rx.h).  Every
+    other entry point first waits for the batches in flight, and a change of batch size or stream count re-synchronises the streams:
+    stage calls, the synchronous entry, subtraction and size / stream changes issued BETWEEN an enqueue and its fetch leave every
+    batch's results exactly what a quiet handle produces."""
+    import hashlib
+    from pyft8_amd import _lib
+    B = 64
+    store = _lib.Handle(max_frames=2 * B)
+    base = store.staging_ptr()
+    store.synth_frames(base, 93000, 2 * B, n_signals=30, snr_range=(-10.0, 8.0))
+    host = store.download_audio(base, 2 * B)
+
+    def digest(res, n):
+        rec, cnt, ev, evc = res
+        hsh = hashlib.sha256()
+        for f in range(n):
+            hsh.update(rec[f, :cnt[f]].tobytes())
+            hsh.update(np.sort(ev[f, :min(int(evc[f]), _lib.EVENT_CAP)], order=["cand", "ipass", "slot", "seq"]).tobytes())
+        return hsh.hexdigest()
+    h = _lib.Handle(max_frames=B)
+    want = [digest(h.decode_batch(host[k * B:(k + 1) * B]), B) for k in range(2)]
+    want_half = digest(h.decode_batch(host[:B // 2]), B // 2)
+    ptr = [base, base + B * _lib.NSAMP * 2]
+    grid_want = O.spectrogram(host[5], ocfg)
+    for rnd in range(3):
+        h.enqueue(ptr[0], B)
+        h.enqueue(ptr[1], B)                                           # two batches in flight on free-running streams
+        g = h.spectrogram(host[5])[0]                                  # a stage call: waits for them, then uses the shared workspaces
+        assert bits_equal(g[1:376], grid_want[1:376])
+        assert digest(h.fetch(B), B) == want[0] and digest(h.fetch(B), B) == want[1], rnd
+        h.enqueue(ptr[0], B)
+        h.enqueue(ptr[0], B // 2)                                      # another partition right behind it
+        assert digest(h.fetch(B), B) == want[0] and digest(h.fetch(B // 2), B // 2) == want_half, rnd
+        h.enqueue(ptr[1], B)
+        h.set_streams(4 if rnd % 2 == 0 else 2)                         # takes effect with the next batch
+        h.enqueue(ptr[0], B)
+        assert digest(h.fetch(B), B) == want[1] and digest(h.fetch(B), B) == want[0], rnd
+        h.enqueue(ptr[1], B)
+        assert digest(h.decode_batch(host[:B]), B) == want[0]          # the synchronous entry in between drops the batch in flight ...
+        h.enqueue(ptr[1], B)
+        ok, lo, hi, nits, has, out = h.ldpc(np.zeros((3, 174), np.float32) + 1.0, 35, 5)       # ... and so may any stage call
+        assert digest(h.fetch(B), B) == want[1], rnd
+    h.close()
+    store.close()
+
+
 def test_pipelined_host_entry_matches_synchronous_decode():
     """ft8rx_enqueue_batch_host (H2D of batch k+1 overlapping the kernels of batch k, two device staging buffers): a stream of
     different batches from page-locked and from pageable host memory gives exactly the results of ft8rx_decode_batch, in order."""
