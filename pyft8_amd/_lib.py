@@ -12,6 +12,10 @@ LIB_PATH = os.environ.get("FT8RX_LIB", os.path.join(HERE, "libft8rx.so"))   # FT
 # the same source with the wide layouts (-DFT8RX_WIDE, include/ft8rx.h): search_freq_range up to 5900 Hz; loaded only when a config asks for it
 LIB_PATH_WIDE = os.environ.get("FT8RX_LIB_WIDE", os.path.join(HERE, "libft8rx_wide.so"))
 SRC = os.path.join(HERE, "csrc", "ft8rx.hip")
+# second translation unit: the FFT kernels (k_fine, k_spectrogram), compiled with the ILP scheduling strategy -- 3.9 % / 3 % faster for
+# them, 56 % slower for k_bp, and the strategy is a per-translation-unit choice (csrc/ft8rx_ilp.hip, profiles/r03_notes.md)
+SRC_ILP = os.path.join(HERE, "csrc", "ft8rx_ilp.hip")
+ILP_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 # -fno-slp-vectorize: on gfx950 a v_pk_add/mul_f32 issues at exactly the cost of the two scalar ops it replaces (tools/ubench/valu_rate.hip,
 # profiles/r02_valu_rate.txt) while the packing costs ~1000 extra v_mov in k_fine: scalar code is 7 % faster there, bit-identical.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-result",
@@ -61,14 +65,40 @@ def build(force=False, verbose=False):
     jobs = []
     for path, extra in ((LIB_PATH, []), (LIB_PATH_WIDE, ["-DFT8RX_WIDE"])):
         if force or not os.path.exists(path) or os.path.getmtime(path) < newest:
-            cmd = ["hipcc"] + HIPCC_FLAGS + extra + ["-o", path, SRC]
+            # two objects (different scheduling strategies), one shared library
+            flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+            objs = [path[:-3] + ".main.o", path[:-3] + ".ilp.o"]
+            cmds = [["hipcc"] + flags + extra + ["-c", "-o", objs[0], SRC],
+                    ["hipcc"] + flags + ILP_FLAGS + extra + ["-c", "-o", objs[1], SRC_ILP]]
+            link = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", path] + objs
             if verbose:
-                print(" ".join(cmd))
-            jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, j in jobs:
-        if j.wait() != 0:
-            raise subprocess.CalledProcessError(j.returncode, cmd)
+                for c in cmds + [link]:
+                    print(" ".join(c))
+            jobs.append((cmds, [subprocess.Popen(c) for c in cmds], link, objs))
+    for cmds, procs, link, objs in jobs:
+        for c, j in zip(cmds, procs):
+            if j.wait() != 0:
+                raise subprocess.CalledProcessError(j.returncode, c)
+        subprocess.check_call(link)
+        for o in objs:
+            os.remove(o)
     return LIB_PATH
+
+
+def build_variant(path, extra=(), ilp_flags=None):
+    """An alternative build of the library (same two-unit recipe) at `path`, e.g. build_variant("build/ab/x.so", ["-DFINE_TIMING"]) for
+    A/B timing through FT8RX_LIB (tools/ab_full.sh) -- never the product path."""
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    objs = [path[:-3] + ".main.o", path[:-3] + ".ilp.o"]
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    procs = [subprocess.Popen(["hipcc"] + flags + list(extra) + ["-c", "-o", objs[0], SRC]),
+             subprocess.Popen(["hipcc"] + flags + list(ILP_FLAGS if ilp_flags is None else ilp_flags) + list(extra) + ["-c", "-o", objs[1], SRC_ILP])]
+    if any(p.wait() != 0 for p in procs):
+        raise Ft8rxError(f"build_variant({path}) failed")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", path] + objs)
+    for o in objs:
+        os.remove(o)
+    return path
 
 
 def lib(wide=False):

@@ -13,9 +13,12 @@
 //   k_bp           (candidate, AP)      GOOD91 + BP(90,20) with saved outputs
 //   k_select1, k_osd (candidate, slot) one wavefront: rank sort, register-resident GF(2) Gauss-Jordan
 //                                       with ballot pivoting, lane-per-trial CRC-14 + validity, k_select2
-// A batch is cut into chunks whose chains run on separate HIP streams; results land in one of two result slots and are copied to
-// page-locked host buffers by a copy stream while the next batch computes (launch_batch / ft8rx_fetch_results).
-// Extension: k_sub_scan / k_sub_pick / k_sub_accum / k_sub_apply subtract decoded signals (ft8rx_subtract).
+// A batch is cut into chunks whose chains run on separate HIP streams -- free-running: chunk i of batch k+1 follows chunk i of batch k
+// on stream i, no per-batch fork / join; results land in one of two result slots and are copied to page-locked host buffers by a copy
+// stream while the next batch computes; the used part of the event log is packed by k_ev_scan / k_ev_compact straight into
+// page-locked host memory (launch_batch / ft8rx_fetch_results).
+// k_sub_* / k_subd_* subtract decoded signals (ft8rx_subtract; refine 0 = the reference experiment's subtract_signal,
+// 3 = its refine_time_origin first: k_cyc_a_f32 + k_refine3; 1 / 2 = the build's own origin re-estimation).
 // Reference line citations are to PyFT8/receiver.py and PyFT8/decoders.py (see include/ft8rx.h).
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -45,6 +48,7 @@
 #include "kernels/subtract.hpp"
 #include "kernels/probes.hpp"
 #include "host_messages.hpp"
+#include "ilp_launch.hpp"       // k_fine, k_spectrogram and k_hop_spectrum are launched from the second translation unit (ft8rx_ilp.hip)
 
 // ====================================================================================== host side
 #define EV_EAGER_BYTES ((size_t)1 << 20)      /* event logs up to this size travel whole with the records (launch_batch) */
@@ -426,7 +430,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     WorkList wl[WL_N];
     for (int i = 0; i < WL_N; i++) { wl[i].items = h->d_work[i] + F * MAXC * (i == WL_BP0 ? 5 : 1); wl[i].count = wc + i; }
     STAGE("spectrogram");
-    k_spectrogram<<<dim3(376, B), SPEC_NT, 0, s>>>(audio, grid, h->T);
+    ft8rx_ilp_spectrogram(B, s, audio, grid, h->T);
     STAGE("sync");
     const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
     k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, c);
@@ -443,7 +447,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     k_cyc_a<<<dim3(40, B), 256, 0, s>>>(audio, A, h->T);
     k_cyc_bc<<<dim3(CYC_BC_GRID, B), 256, 0, s>>>(A, spec, h->T);
     STAGE("fine");
-    k_fine<<<ladder_grid(B * MAXC), FINE_NT, 0, s>>>(spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
+    ft8rx_ilp_fine(ladder_grid(B * MAXC), s, spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
     k_worklist<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, B, wl[WL_BP1]);
     STAGE("bp_fine");
     // fine-stage BP: in ladder order (three launches; decided candidates drop out), or -- ft8rx_set_ladder_mode(h, 1), for small
@@ -752,7 +756,7 @@ int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid)
     if (!h || !audio || !grid || B < 1 || B > h->max_frames) return -1;
     ENTER(h);
     HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
-    k_spectrogram<<<dim3(376, B), SPEC_NT, 0, h->stream>>>(h->d_audio, h->d_grid, h->T);
+    ft8rx_ilp_spectrogram(B, h->stream, h->d_audio, h->d_grid, h->T);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(grid, h->d_grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyDeviceToHost));
     return 0;
@@ -763,7 +767,7 @@ int ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row) {
     ENTER(h);
     float* d_row = h->d_best_score;                      // any scratch of FT8RX_GRID_COLS floats (NF0MAX >= that): not in use between batches
     HIPCHK(h, hipMemcpyAsync(h->d_audio, window3840, sizeof(int16_t) * 3840, hipMemcpyHostToDevice, h->stream));
-    k_hop_spectrum<<<1, SPEC_NT, 0, h->stream>>>(h->d_audio, d_row, h->T);
+    ft8rx_ilp_hop_spectrum(h->stream, h->d_audio, d_row, h->T);
     HIPCHK(h, hipMemcpyAsync(row, d_row, sizeof(float) * FT8RX_GRID_COLS, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -852,7 +856,7 @@ int ft8rx_fine(ft8rx_handle* h, const float* spec, int B, int n, const int32_t* 
     float* d_sd = S.get<float>(n); NEED(d_sd);
     int32_t* d_out = S.get<int32_t>((size_t)n * 5); NEED(d_out);
     float* d_sg = sgrid ? S.get<float>((size_t)n * 632) : nullptr; if (sgrid) NEED(d_sg);
-    k_fine<<<n, FINE_NT, 0, h->stream>>>(h->d_spec, nullptr, nullptr, d_llr, h->T, h->cfg, d_trip, d_out, d_sd, d_sg, WorkList{nullptr, nullptr});
+    ft8rx_ilp_fine(n, h->stream, h->d_spec, nullptr, nullptr, d_llr, h->T, h->cfg, d_trip, d_out, d_sd, d_sg, WorkList{nullptr, nullptr});
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<int32_t> o((size_t)n * 5);
     HIPCHK(h, hipMemcpy(o.data(), d_out, sizeof(int32_t) * o.size(), hipMemcpyDeviceToHost));
@@ -1133,10 +1137,7 @@ int ft8rx_set_reject_log(const char* path) { hostmsg::set_reject_log(path); retu
 int ft8rx_debug_fine_times(ft8rx_handle* h, unsigned long long* out32, int reset) {      // timing-only builds (tools/fine_timing.sh)
     if (!h) return -1;
     ENTER(h);
-    HIPCHK(h, hipDeviceSynchronize());
-    if (out32) HIPCHK(h, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_fine_t), sizeof(unsigned long long) * 32));
-    if (reset) { unsigned long long z[32] = {0}; HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_fine_t), z, sizeof(z))); }
-    return 0;
+    return ft8rx_ilp_fine_times(out32, reset);          // the instrumented kernel lives in the second translation unit
 }
 #endif
 

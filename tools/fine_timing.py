@@ -1,6 +1,7 @@
 """Where the cycles of one fine-sync IFFT go (timing-only build of libft8rx.so with -DFINE_TIMING, see kernels/fine_sync.hpp):
 wave 0 of every k_fine block accumulates shader cycles between marks.  Usage on the GPU box:
-    FT8RX_LIB=build/variants/fine_timing.so python tools/fine_timing.py"""
+    python -c "from pyft8_amd import _lib; _lib.build_variant('build/ab/fine_timing.so', ['-DFINE_TIMING'])"
+    FT8RX_LIB=build/ab/fine_timing.so python tools/fine_timing.py"""
 import ctypes as C
 import os
 import sys
