@@ -508,7 +508,8 @@ __global__ __launch_bounds__(FINE_NT) void k_refine3(const cpx* __restrict__ spe
     __syncthreads();
     cpx wq[8];
     sym32_twiddles(w32, tid & 3, wq);
-    fine_fft(slice, 182, z, w400, T, tid, 0, 3200);
+    FT_DECL                                                           // (timing-only builds: fine_fft takes the mark table)
+    fine_fft(slice, 182, z, w400, T, tid, 0, 3200 FT_PASS);
     // 12 time steps x 21 Costas symbols, four lanes each: (on, off) sums per symbol in fp64, as in k_fine's scoring
 #pragma unroll 1
     for (int r = 0; r < (12 * 21 * 4 + FINE_NT - 1) / FINE_NT; r++) {
