@@ -68,6 +68,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
     // the edge tables are only needed once BP really iterates: most ipass-0 attempts stop at the initial
     // unsatisfied-check test (decoders.py:159), so they are loaded lazily below
     int ev_[9], ec_[9];
+    uint32_t ve_[3] = {0u, 0u, 0u};          // the three edges of this lane's variables (lane, 64 + lane, 128 + lane), 10 bits each
     int n0 = 0, e00 = 0, n1 = 0, e01 = 0;
     bool tables = false;
     float mc[9];
@@ -100,6 +101,12 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
             for (int i = 0; i < 9; i++) { int e = lane + 64 * i; ev_[i] = (e < 522) ? d_EDGE_V[e] : 174; ec_[i] = (e < 522) ? d_EDGE_C[e] : 83; }
             n0 = d_CHK_N[c0]; e00 = d_CHK_E0[c0];
             n1 = (c1 < 83) ? d_CHK_N[c1] : 0; e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
+            // (these used to be read from the global table in EVERY iteration: three dependent global loads in front of the LDS reads)
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int v = lane + 64 * q, vc = v < 174 ? v : 0;
+                ve_[q] = (uint32_t)d_VAR_E[vc][0] | ((uint32_t)d_VAR_E[vc][1] << 10) | ((uint32_t)d_VAR_E[vc][2] << 20);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -133,10 +140,14 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
             mc[i] = nm;
         }
         __syncthreads();
-        for (int v = lane; v < 174; v += 64) {
-            float col = 0.0f;
-            col += dl[d_VAR_E[v][0]]; col += dl[d_VAR_E[v][1]]; col += dl[d_VAR_E[v][2]];
-            llr[v] += col;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int v = lane + 64 * q;
+            if (v < 174) {
+                float col = 0.0f;
+                col += dl[ve_[q] & 1023u]; col += dl[(ve_[q] >> 10) & 1023u]; col += dl[ve_[q] >> 20];
+                llr[v] += col;
+            }
         }
         __syncthreads();
     }
