@@ -57,14 +57,15 @@ float ft8o_log10f(float x) {
     if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
     float s = (m - 1.0f) / (m + 1.0f);
     float s2 = s * s;
+    /* contract (round 3): the Horner steps and the final combination are fused multiply-adds (C99 fmaf: one rounding each) */
     float p = 0.11111111f;
-    p = p * s2 + 0.14285715f;
-    p = p * s2 + 0.2f;
-    p = p * s2 + 0.33333334f;
-    p = p * s2 + 1.0f;
+    p = fmaf(p, s2, 0.14285715f);
+    p = fmaf(p, s2, 0.2f);
+    p = fmaf(p, s2, 0.33333334f);
+    p = fmaf(p, s2, 1.0f);
     float lnm = (2.0f * s) * p;
     float fe = (float)e;
-    return fe * 0.301025390625f + (fe * 4.6050390e-6f + lnm * 0.4342945f);
+    return fmaf(fe, 0.301025390625f, fmaf(fe, 4.6050390e-6f, lnm * 0.4342945f));
 }
 
 /* tanh: single-branch clamped rational x P(x^2) / Q(x^2) (odd degree 13 over even degree 6, the classic fast-tanh
@@ -76,18 +77,19 @@ float ft8o_tanhf(float x) {
     if (xc > 7.90531111f) xc = 7.90531111f;
     if (xc < -7.90531111f) xc = -7.90531111f;
     const float x2 = xc * xc;
+    /* contract (round 3): Horner steps as fused multiply-adds (C99 fmaf) */
     float p = -2.76076847742355e-16f;
-    p = p * x2 + 2.00018790482477e-13f;
-    p = p * x2 + -8.60467152213735e-11f;
-    p = p * x2 + 5.12229709037114e-08f;
-    p = p * x2 + 1.48572235717979e-05f;
-    p = p * x2 + 6.37261928875436e-04f;
-    p = p * x2 + 4.89352455891786e-03f;
+    p = fmaf(p, x2, 2.00018790482477e-13f);
+    p = fmaf(p, x2, -8.60467152213735e-11f);
+    p = fmaf(p, x2, 5.12229709037114e-08f);
+    p = fmaf(p, x2, 1.48572235717979e-05f);
+    p = fmaf(p, x2, 6.37261928875436e-04f);
+    p = fmaf(p, x2, 4.89352455891786e-03f);
     p = p * xc;
     float q = 1.19825839466702e-06f;
-    q = q * x2 + 1.18534705686654e-04f;
-    q = q * x2 + 2.26843463243900e-03f;
-    q = q * x2 + 4.89352518554385e-03f;
+    q = fmaf(q, x2, 1.18534705686654e-04f);
+    q = fmaf(q, x2, 2.26843463243900e-03f);
+    q = fmaf(q, x2, 4.89352518554385e-03f);
     return p / q;
 }
 
@@ -100,7 +102,7 @@ static inline cpx mulnegi(cpx a) { cpx r = {a.im, -a.re}; return r; }       /* a
 static inline void dft2(cpx* a) { cpx t = a[0]; a[0] = cadd(t, a[1]); a[1] = csub(t, a[1]); }
 static inline void dft3(cpx* a) {
     cpx t1 = cadd(a[1], a[2]), t2 = csub(a[1], a[2]);
-    cpx m = {a[0].re + (-0.5f) * t1.re, a[0].im + (-0.5f) * t1.im};
+    cpx m = {fmaf(-0.5f, t1.re, a[0].re), fmaf(-0.5f, t1.im, a[0].im)};           /* contract (round 3): named fmas */
     cpx n = {0.86602540f * t2.re, 0.86602540f * t2.im};
     a[0] = cadd(a[0], t1);
     a[1].re = m.re + n.im; a[1].im = m.im - n.re;
@@ -115,10 +117,11 @@ static inline void dft4(cpx* a) {
 static inline void dft5(cpx* a) {
     const float c1 = 0.30901699f, c2 = -0.80901699f, s1 = 0.95105652f, s2 = 0.58778525f;
     cpx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
-    cpx m1 = {(a[0].re + c1 * t1.re) + c2 * t2.re, (a[0].im + c1 * t1.im) + c2 * t2.im};
-    cpx m2 = {(a[0].re + c2 * t1.re) + c1 * t2.re, (a[0].im + c2 * t1.im) + c1 * t2.im};
-    cpx n1 = {s1 * t3.re + s2 * t4.re, s1 * t3.im + s2 * t4.im};
-    cpx n2 = {s2 * t3.re - s1 * t4.re, s2 * t3.im - s1 * t4.im};
+    /* contract (round 3): the constant multiplies of the radix-5 butterfly as named fmas (12 of its 48 operations go away) */
+    cpx m1 = {fmaf(c2, t2.re, fmaf(c1, t1.re, a[0].re)), fmaf(c2, t2.im, fmaf(c1, t1.im, a[0].im))};
+    cpx m2 = {fmaf(c1, t2.re, fmaf(c2, t1.re, a[0].re)), fmaf(c1, t2.im, fmaf(c2, t1.im, a[0].im))};
+    cpx n1 = {fmaf(s1, t3.re, s2 * t4.re), fmaf(s1, t3.im, s2 * t4.im)};
+    cpx n2 = {fmaf(s2, t3.re, -(s1 * t4.re)), fmaf(s2, t3.im, -(s1 * t4.im))};
     cpx t5 = cadd(t1, t2);
     a[0] = cadd(a[0], t5);
     a[1].re = m1.re + n1.im; a[1].im = m1.im - n1.re;
@@ -714,8 +717,8 @@ static int ldpc_core(float* llr, int max_nc0, int max_iters, accept_fn acc, void
             for (int j = 0; j < n; j++) {
                 /* reference: e = P/t; m = e/((e-1.18)(1.18+e)) (decoders.py:146-149).  Contract: the same quantity with
                  * numerator and denominator multiplied by t^2 -- one division; t == 0 (=> P == 0) still gives 0/0 = NaN */
-                float u = 1.18f * t[j];
-                float nm = (P * t[j]) / ((P - u) * (u + P));
+                /* (round 3: P -+ 1.18 t as fused multiply-adds) */
+                float nm = (P * t[j]) / (fmaf(-1.18f, t[j], P) * fmaf(1.18f, t[j], P));
                 newm[e0 + j] = nm;
                 delta[e0 + j] = nm - mc2v[e0 + j];
             }

@@ -25,14 +25,14 @@ FT8_DEV float ft8_log10f(float x) {
     if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
     float s = (m - 1.0f) / (m + 1.0f);
     float s2 = s * s;
-    float p = 0.11111111f;
-    p = p * s2 + 0.14285715f;
-    p = p * s2 + 0.2f;
-    p = p * s2 + 0.33333334f;
-    p = p * s2 + 1.0f;
+    float p = 0.11111111f;                              // contract: Horner steps and the final combination as named fmas
+    p = __builtin_fmaf(p, s2, 0.14285715f);
+    p = __builtin_fmaf(p, s2, 0.2f);
+    p = __builtin_fmaf(p, s2, 0.33333334f);
+    p = __builtin_fmaf(p, s2, 1.0f);
     float lnm = (2.0f * s) * p;
     float fe = (float)e;
-    return fe * 0.301025390625f + (fe * 4.6050390e-6f + lnm * 0.4342945f);
+    return __builtin_fmaf(fe, 0.301025390625f, __builtin_fmaf(fe, 4.6050390e-6f, lnm * 0.4342945f));
 }
 
 // The same function for arguments known to be positive, normal and finite (2^-126 <= x <= 3e38): the three range checks above are
@@ -45,14 +45,14 @@ FT8_DEV float ft8_log10f_normal(float x) {
     m = big ? m * 0.5f : m; e += big ? 1 : 0;
     float s = (m - 1.0f) / (m + 1.0f);
     float s2 = s * s;
-    float p = 0.11111111f;
-    p = p * s2 + 0.14285715f;
-    p = p * s2 + 0.2f;
-    p = p * s2 + 0.33333334f;
-    p = p * s2 + 1.0f;
+    float p = 0.11111111f;                              // contract: Horner steps and the final combination as named fmas
+    p = __builtin_fmaf(p, s2, 0.14285715f);
+    p = __builtin_fmaf(p, s2, 0.2f);
+    p = __builtin_fmaf(p, s2, 0.33333334f);
+    p = __builtin_fmaf(p, s2, 1.0f);
     float lnm = (2.0f * s) * p;
     float fe = (float)e;
-    return fe * 0.301025390625f + (fe * 4.6050390e-6f + lnm * 0.4342945f);
+    return __builtin_fmaf(fe, 0.301025390625f, __builtin_fmaf(fe, 4.6050390e-6f, lnm * 0.4342945f));
 }
 
 // single-branch clamped rational (no divergence inside a wavefront): x P(x^2) / Q(x^2), one IEEE division
@@ -61,18 +61,18 @@ FT8_DEV float ft8_tanhf(float x) {
     if (xc > 7.90531111f) xc = 7.90531111f;
     if (xc < -7.90531111f) xc = -7.90531111f;
     const float x2 = xc * xc;
-    float p = -2.76076847742355e-16f;
-    p = p * x2 + 2.00018790482477e-13f;
-    p = p * x2 + -8.60467152213735e-11f;
-    p = p * x2 + 5.12229709037114e-08f;
-    p = p * x2 + 1.48572235717979e-05f;
-    p = p * x2 + 6.37261928875436e-04f;
-    p = p * x2 + 4.89352455891786e-03f;
+    float p = -2.76076847742355e-16f;                   // contract: Horner steps as named fmas
+    p = __builtin_fmaf(p, x2, 2.00018790482477e-13f);
+    p = __builtin_fmaf(p, x2, -8.60467152213735e-11f);
+    p = __builtin_fmaf(p, x2, 5.12229709037114e-08f);
+    p = __builtin_fmaf(p, x2, 1.48572235717979e-05f);
+    p = __builtin_fmaf(p, x2, 6.37261928875436e-04f);
+    p = __builtin_fmaf(p, x2, 4.89352455891786e-03f);
     p = p * xc;
     float q = 1.19825839466702e-06f;
-    q = q * x2 + 1.18534705686654e-04f;
-    q = q * x2 + 2.26843463243900e-03f;
-    q = q * x2 + 4.89352518554385e-03f;
+    q = __builtin_fmaf(q, x2, 1.18534705686654e-04f);
+    q = __builtin_fmaf(q, x2, 2.26843463243900e-03f);
+    q = __builtin_fmaf(q, x2, 4.89352518554385e-03f);
     return p / q;
 }
 
@@ -87,7 +87,7 @@ template <int R> FT8_DEV void dft(cpx* a);
 template <> FT8_DEV void dft<2>(cpx* a) { cpx t = a[0]; a[0] = cadd(t, a[1]); a[1] = csub(t, a[1]); }
 template <> FT8_DEV void dft<3>(cpx* a) {
     cpx t1 = cadd(a[1], a[2]), t2 = csub(a[1], a[2]);
-    cpx m = make_float2(a[0].x + (-0.5f) * t1.x, a[0].y + (-0.5f) * t1.y);
+    cpx m = make_float2(__builtin_fmaf(-0.5f, t1.x, a[0].x), __builtin_fmaf(-0.5f, t1.y, a[0].y));       // contract: named fmas
     cpx n = make_float2(0.86602540f * t2.x, 0.86602540f * t2.y);
     a[0] = cadd(a[0], t1);
     a[1] = make_float2(m.x + n.y, m.y - n.x);
@@ -102,10 +102,11 @@ template <> FT8_DEV void dft<4>(cpx* a) {
 template <> FT8_DEV void dft<5>(cpx* a) {
     const float c1 = 0.30901699f, c2 = -0.80901699f, s1 = 0.95105652f, s2 = 0.58778525f;
     cpx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
-    cpx m1 = make_float2((a[0].x + c1 * t1.x) + c2 * t2.x, (a[0].y + c1 * t1.y) + c2 * t2.y);
-    cpx m2 = make_float2((a[0].x + c2 * t1.x) + c1 * t2.x, (a[0].y + c2 * t1.y) + c1 * t2.y);
-    cpx n1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
-    cpx n2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    // contract: the constant multiplies as named fmas (48 -> 36 instructions per butterfly)
+    cpx m1 = make_float2(__builtin_fmaf(c2, t2.x, __builtin_fmaf(c1, t1.x, a[0].x)), __builtin_fmaf(c2, t2.y, __builtin_fmaf(c1, t1.y, a[0].y)));
+    cpx m2 = make_float2(__builtin_fmaf(c1, t2.x, __builtin_fmaf(c2, t1.x, a[0].x)), __builtin_fmaf(c1, t2.y, __builtin_fmaf(c2, t1.y, a[0].y)));
+    cpx n1 = make_float2(__builtin_fmaf(s1, t3.x, s2 * t4.x), __builtin_fmaf(s1, t3.y, s2 * t4.y));
+    cpx n2 = make_float2(__builtin_fmaf(s2, t3.x, -(s1 * t4.x)), __builtin_fmaf(s2, t3.y, -(s1 * t4.y)));
     cpx t5 = cadd(t1, t2);
     a[0] = cadd(a[0], t5);
     a[1] = make_float2(m1.x + n1.y, m1.y - n1.x);

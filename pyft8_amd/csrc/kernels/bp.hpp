@@ -134,8 +134,8 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
         for (int i = 0; i < 9; i++) {
             const int e = lane + 64 * i;
             const float tti = tl[e];          // own slot, re-read: keeping tt[] in registers across the barriers spilled 24 B per thread at 72 VGPRs
-            const float Pc = P[ec_[i]], u = 1.18f * tti;
-            const float nm = (Pc * tti) / ((Pc - u) * (u + Pc));     // = e/((e-1.18)(1.18+e)), e = P/t, in one division
+            const float Pc = P[ec_[i]];
+            const float nm = (Pc * tti) / (__builtin_fmaf(-1.18f, tti, Pc) * __builtin_fmaf(1.18f, tti, Pc));     // = e/((e-1.18)(1.18+e)), e = P/t, in one division
             dl[e] = nm - mc[i];
             mc[i] = nm;
         }
