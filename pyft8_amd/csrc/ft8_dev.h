@@ -261,7 +261,7 @@ FT8_DEV void sym32_quad(cpx* x, int n2, const cpx* wq, float* mag) {
 #pragma unroll
     for (int k = 0; k < NT; k++) {
         cpx t = x[k];
-        if (k != 0) t = (n2 != 0) ? cmul(t, wq[k]) : t;        // (select, not a branch: the quad leader's W^0 term is used as is)
+        if (k != 0) t = cmul(t, wq[k]);                        // the quad leader's factor is W^0 = (1, -0): an exact identity, no select needed
         cpx acc = t;                                   // quad leader: its own term is u0
         acc = cadd(acc, make_float2(quad_lane<1>(t.x), quad_lane<1>(t.y)));
         acc = cadd(acc, make_float2(quad_lane<2>(t.x), quad_lane<2>(t.y)));
