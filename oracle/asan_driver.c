@@ -20,11 +20,32 @@ static int load(const char* path, int16_t* out) {
     return (int)n;
 }
 
+static ft8o_cand cands[256]; static ft8o_event evlog[4096]; static ft8o_msg msgs[256];
 static int run(const int16_t* audio, const ft8o_config* cfg) {
-    static ft8o_cand cands[256]; static ft8o_event log[4096]; static ft8o_msg msgs[256];
     int32_t nc = 0, nl = 0, nm = 0;
-    ft8o_decode_frame(audio, cfg, cands, &nc, log, 4096, &nl, msgs, 256, &nm);
+    ft8o_decode_frame(audio, cfg, cands, &nc, evlog, 4096, &nl, msgs, 256, &nm);
     return nm;
+}
+/* the subtraction functions on the first decodes of the frame: tone encoder, the experiment's refine_time_origin, the
+ * build's decimated-baseband re-estimation + subtraction, the reference-style subtraction; incl. origins at the edges of the buffer */
+static int run_sub(const int16_t* audio, const ft8o_config* cfg) {
+    static float wf[FT8O_NSAMP];
+    int32_t nc = 0, nl = 0, nm = 0, done = 0;
+    ft8o_decode_frame(audio, cfg, cands, &nc, evlog, 4096, &nl, msgs, 256, &nm);
+    for (int i = 0; i < FT8O_NSAMP; i++) wf[i] = (float)audio[i];
+    for (int i = 0; i < nm && i < 3; i++) {
+        uint8_t tones[79];
+        const ft8o_cand* c = &cands[msgs[i].cand];
+        ft8o_encode_tones(c->msg_lo, c->msg_hi, tones);
+        double f = msgs[i].fHz, t = msgs[i].tsec; float sc;
+        ft8o_refine_time_origin(wf, cfg, &f, &t, &sc);
+        f = msgs[i].fHz; t = msgs[i].tsec;
+        done += ft8o_refine2_subtract(wf, tones, &f, &t, 1);
+        done += ft8o_subtract(wf, tones, msgs[i].fHz + 3.0, msgs[i].tsec);
+        f = msgs[i].fHz; t = (i == 0) ? 0.0001 : 2.45;            /* start sample 1; a signal that runs off the end of the buffer */
+        done += ft8o_refine2_subtract(wf, tones, &f, &t, 1);
+    }
+    return done;
 }
 
 int main(int argc, char** argv) {
@@ -38,6 +59,7 @@ int main(int argc, char** argv) {
         int n = load(argv[i], audio);
         if (n < 0) { fprintf(stderr, "cannot read %s\n", argv[i]); return 2; }
         printf("%s: %d samples, %d messages (reference knobs), %d (extension knobs)\n", argv[i], n, run(audio, &ref), run(audio, &ext));
+        printf("%s: %d subtractions\n", argv[i], run_sub(audio, &ref));
     }
     return 0;
 }
