@@ -194,7 +194,7 @@ int  ft8rx_fine(ft8rx_handle* h, const float* spec, int n_frames, int n, const i
  * ok[i]=1 => msg; has_out[i]=1 => llr_out[i] holds the mutated llr (the reference's third return) */
 int  ft8rx_ldpc(ft8rx_handle* h, const float* llr, int n, int max_ncheck0, int max_iters,
                 int32_t* ok, uint64_t* msg_lo, uint64_t* msg_hi, int32_t* n_its, int32_t* has_out, float* llr_out);
-/* osd_012(llr, singleflips, doubleflips) (decoders.py:223-272) on n vectors */
+/* osd_012(llr, singleflips, doubleflips) (decoders.py:223-272) on n vectors; 0 <= singleflips, doubleflips <= 91 (all basis positions) */
 int  ft8rx_osd(ft8rx_handle* h, const float* llr, int n, int singleflips, int doubleflips,
                int32_t* ok, uint64_t* msg_lo, uint64_t* msg_hi, int32_t* trial);
 /* same with the build's extension knobs: tripleflips = order-3 depth, max_hd = acceptance gate (0 = off); hd[i] (optional) = the

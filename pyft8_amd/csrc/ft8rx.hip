@@ -467,8 +467,8 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
         k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(3, rec, ncand, attG, attB, B, c, wl[WL_OSD]);
     }
     STAGE("osd");
-    k_osd<<<ladder_grid(B * MAXC * 10), 64, 0, s>>>(0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials,
-                                                    osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd, wl[WL_OSD]);
+    (osd_nflip(c.osd_single, c.osd_triple) > OSD_FLIPS_A ? k_osd_wide : k_osd)<<<ladder_grid(B * MAXC * 10), 64, 0, s>>>(
+        0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials, osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd, wl[WL_OSD]);
     STAGE("select2");
     k_select2<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attO, B);
     if (prof) hipEventRecord(h->pev[h->pnames.size()], s);
@@ -897,8 +897,9 @@ int ft8rx_osd_ext(ft8rx_handle* h, const float* llr, int n, int singleflips, int
     float* d_in = S.put(llr, (size_t)n * 174); NEED(d_in);
     uint32_t* d_tr = S.put(tr.data(), tr.size()); NEED(d_tr);
     Att* d_att = S.get<Att>(n); NEED(d_att);
-    k_osd<<<n, 64, 0, h->stream>>>(2, d_in, nullptr, nullptr, nullptr, nullptr, d_att, nullptr, nullptr, d_tr, (int)tr.size(),
-                                   osd_nflip(singleflips, tripleflips), max_hd, WorkList{nullptr, nullptr});
+    (osd_nflip(singleflips, tripleflips) > OSD_FLIPS_A ? k_osd_wide : k_osd)<<<n, 64, 0, h->stream>>>(
+        2, d_in, nullptr, nullptr, nullptr, nullptr, d_att, nullptr, nullptr, d_tr, (int)tr.size(), osd_nflip(singleflips, tripleflips), max_hd,
+        WorkList{nullptr, nullptr});
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<Att> a(n);
     HIPCHK(h, hipMemcpy(a.data(), d_att, sizeof(Att) * n, hipMemcpyDeviceToHost));

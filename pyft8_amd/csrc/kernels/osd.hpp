@@ -20,7 +20,9 @@ FT8_DEV uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-#define OSD_MAXFLIP 62            /* flip rows kept per attempt (singles / doubles / order-3 depth <= 62: one bit each in a 64-bit word) */
+#define OSD_MAXFLIP 91            /* flip rows kept per attempt = all 91 basis positions (decoders.py:244-246 takes any count up to the basis size) */
+#define OSD_FLIPS_A 62            /* flips 0..61: one bit each in the column's 64-bit word (bit 63 = order-0 codeword bit); flips 62..90: a second, 32-bit word
+                                     that only exists for attempts with more than 62 flip rows (the reference's own callers use 30 / 40) */
 #define OSD_MAXTRIALS 16384       /* trial index must fit the 16-bit seq of the event log */
 #define OSD_NONE 0xFFu            /* "no flip" in a packed trial entry (i | j << 8 | k << 16) */
 
@@ -31,7 +33,10 @@ __device__ __constant__ uint32_t d_SYNM[14][3];
 __device__ uint32_t d_G0T[192][3];       // column v of G0 = [I | A^T]: row bits 0..31, 32..63, 64..90 (columns >= 174 are zero)
 FT8_DEV unsigned osd_syndrome(uint64_t w0, uint64_t w1) { return ft8_crc_syndrome(w0, w1); }     // table d_CRC_T: ft8_dev.h
 
-// mode 0: pipeline (work = (candidate, slot 0..9)); mode 2: raw vectors
+// mode 0: pipeline (work = (candidate, slot 0..9)); mode 2: raw vectors.  WIDE: more than 62 flip rows (k_osd_wide) -- a kernel of its
+// own, because the second flip word costs 13 VGPRs = two of the seven waves per SIMD that hide this kernel's scalar-pipe latency
+// (one kernel with a run-time switch: 0.737 -> 0.791 ms per 256 frames at the reference's 30 / 2)
+template <bool WIDE>
 FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ llr_in, const float* __restrict__ saved,
                          const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,
                          const int32_t* __restrict__ ncand, Att* __restrict__ attO,
@@ -39,7 +44,10 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
                          int nflip, int max_hd) {
     __shared__ float llr[176];
     __shared__ uint64_t skey[256];
-    __shared__ uint64_t ftab[192];                         // per column (natural order): bit i = flip i covers it, bit 63 = order-0 codeword bit
+    __shared__ uint64_t ftab[192];                         // per column (natural order): bit i = flip i covers it (i < 62), bit 63 = order-0 codeword bit
+    uint32_t* ftabB = reinterpret_cast<uint32_t*>(skey);  // [192] bit i - 62 = flip i covers it (62 <= i < 91); the sort keys are dead by then
+    constexpr bool wide = WIDE;                            // nflip > OSD_FLIPS_A (the launcher picks the kernel)
+    const int nflipA = wide ? OSD_FLIPS_A : nflip;
     __shared__ uint32_t frow[3 * (OSD_MAXFLIP + 1)];       // unit vectors of the flip columns (their pivot rows)
     __shared__ uint32_t hmw[3];
     __shared__ uint16_t fsyn[OSD_MAXFLIP + 2];             // [i] flip i, [OSD_MAXFLIP] = 0 ("no flip"), [OSD_MAXFLIP + 1] order-0 codeword
@@ -156,6 +164,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     if (64 + lane < 3 * (OSD_MAXFLIP + 1)) frow[64 + lane] = 0u;
     if (128 + lane < 3 * (OSD_MAXFLIP + 1)) frow[128 + lane] = 0u;
     if (192 + lane < 3 * (OSD_MAXFLIP + 1)) frow[192 + lane] = 0u;
+    if (256 + lane < 3 * (OSD_MAXFLIP + 1)) frow[256 + lane] = 0u;
     __syncthreads();
     { const int i = 90 - kk0; if (in0 && i >= 0 && i < nflip) { frow[3 * i] = x00; frow[3 * i + 1] = x01; frow[3 * i + 2] = x02; } }
     { const int i = 90 - kk1; if (in1 && i >= 0 && i < nflip) { frow[3 * i] = x10; frow[3 * i + 1] = x11; frow[3 * i + 2] = x12; } }
@@ -173,11 +182,11 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     }
     __syncthreads();
     const uint32_t hm0 = hmw[0], hm1 = hmw[1], hm2 = hmw[2];
-    // per column: bit i = flip i has a 1 in this column (i < nflip <= 62), bit 63 = the order-0 codeword bit
+    // per column: bit i = flip i has a 1 in this column (i < 62), bit 63 = the order-0 codeword bit
     uint64_t f0 = (uint64_t)((__popc(x00 & hm0) + __popc(x01 & hm1) + __popc(x02 & hm2)) & 1) << 63,
              f1 = (uint64_t)((__popc(x10 & hm0) + __popc(x11 & hm1) + __popc(x12 & hm2)) & 1) << 63,
              f2 = (uint64_t)((__popc(x20 & hm0) + __popc(x21 & hm1) + __popc(x22 & hm2)) & 1) << 63;
-    for (int i = 0; i < nflip; i++) {
+    for (int i = 0; i < nflipA; i++) {
         const uint32_t r0 = frow[3 * i], r1 = frow[3 * i + 1], r2 = frow[3 * i + 2];      // broadcast reads (a unit vector, or 0 if absent)
         f0 |= (uint64_t)(((x00 & r0) | (x01 & r1) | (x02 & r2)) != 0) << i;
         f1 |= (uint64_t)(((x10 & r0) | (x11 & r1) | (x12 & r2)) != 0) << i;
@@ -185,11 +194,21 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     }
     // back to natural column order: ftab[column]
     ftab[ord0] = f0; ftab[ord1] = f1; if (has2) ftab[ord2] = f2;
+    if (wide) {                                            // flips 62 .. nflip - 1 into the second word
+        uint32_t g0 = 0, g1 = 0, g2 = 0;
+        for (int i = OSD_FLIPS_A; i < nflip; i++) {
+            const uint32_t r0 = frow[3 * i], r1 = frow[3 * i + 1], r2 = frow[3 * i + 2];
+            g0 |= (uint32_t)(((x00 & r0) | (x01 & r1) | (x02 & r2)) != 0) << (i - OSD_FLIPS_A);
+            g1 |= (uint32_t)(((x10 & r0) | (x11 & r1) | (x12 & r2)) != 0) << (i - OSD_FLIPS_A);
+            g2 |= (uint32_t)(((x20 & r0) | (x21 & r1) | (x22 & r2)) != 0) << (i - OSD_FLIPS_A);
+        }
+        ftabB[ord0] = g0; ftabB[ord1] = g1; if (has2) ftabB[ord2] = g2;
+    }
     __syncthreads();
-    // CRC syndromes (the CRC is linear): lane i < nflip takes flip i, lane 63 the order-0 codeword.  The lane gathers its word as a
+    // CRC syndromes (the CRC is linear): lane i < min(nflip, 62) takes flip i, lane 63 the order-0 codeword (flips 62.. in a second round).  The lane gathers its word as a
     // 91-bit column set (bit `bitsel` of every ftab entry), then each of the 14 syndrome bits is a masked parity (d_SYNM)
     {
-        const int bitsel = (lane < nflip) ? lane : 63;
+        const int bitsel = (lane < nflipA) ? lane : 63;
         const bool up = bitsel >= 32;
         const int sh = bitsel & 31;
         uint32_t ra = 0, rb = 0, rc = 0;
@@ -205,9 +224,25 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 14; k++)
             sy |= (unsigned)((__popc(ra & d_SYNM[k][0]) + __popc(rb & d_SYNM[k][1]) + __popc(rc & d_SYNM[k][2])) & 1) << k;
-        if (lane < nflip) fsyn[lane] = (uint16_t)sy;
+        if (lane < nflipA) fsyn[lane] = (uint16_t)sy;
         if (lane == 63) fsyn[OSD_MAXFLIP + 1] = (uint16_t)sy;
         if (lane == 0) fsyn[OSD_MAXFLIP] = 0;
+    }
+    if (wide) {                                            // lane l takes flip 62 + l: bit l of the second word of every column
+        const int sh = lane & 31;
+        uint32_t ra = 0, rb = 0, rc = 0;
+#pragma unroll 8
+        for (int v = 0; v < 32; v++) {
+            ra |= ((ftabB[v] >> sh) & 1u) << v;
+            rb |= ((ftabB[32 + v] >> sh) & 1u) << v;
+            rc |= ((ftabB[64 + (v < 27 ? v : 0)] >> sh) & 1u) << v;
+        }
+        rc &= (1u << 27) - 1;
+        unsigned sy = 0;
+#pragma unroll
+        for (int k = 0; k < 14; k++)
+            sy |= (unsigned)((__popc(ra & d_SYNM[k][0]) + __popc(rb & d_SYNM[k][1]) + __popc(rc & d_SYNM[k][2])) & 1) << k;
+        if (OSD_FLIPS_A + lane < nflip) fsyn[OSD_FLIPS_A + lane] = (uint16_t)sy;
     }
     __syncthreads();
     const unsigned syn_c = fsyn[OSD_MAXFLIP + 1];
@@ -237,10 +272,16 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
             const int hl = __builtin_ctzll(hits);
             hits &= hits - 1;
             const int hi_ = __shfl(i, hl), hj = __shfl(j, hl), hq = __shfl(q, hl);
-            const uint64_t msk = (1ull << 63) | ((hi_ < OSD_MAXFLIP) ? (1ull << hi_) : 0ull) | ((hj < OSD_MAXFLIP) ? (1ull << hj) : 0ull) |
-                                 ((hq < OSD_MAXFLIP) ? (1ull << hq) : 0ull);
-            const uint64_t w0 = __ballot(__popcll(ftab[lane] & msk) & 1), w1 = __ballot(__popcll(ftab[64 + lane] & msk) & 1),
-                           w2 = __ballot(has2 && (__popcll(ftab[128 + (has2 ? lane : 0)] & msk) & 1));
+            const uint64_t msk = (1ull << 63) | ((hi_ < OSD_FLIPS_A) ? (1ull << hi_) : 0ull) | ((hj < OSD_FLIPS_A) ? (1ull << hj) : 0ull) |
+                                 ((hq < OSD_FLIPS_A) ? (1ull << hq) : 0ull);
+            uint32_t mskB = 0;                                // flips 62..90 (the "no flip" index 91 sets nothing)
+            if (wide) mskB = ((hi_ >= OSD_FLIPS_A && hi_ < OSD_MAXFLIP) ? (1u << (hi_ - OSD_FLIPS_A)) : 0u) |
+                             ((hj >= OSD_FLIPS_A && hj < OSD_MAXFLIP) ? (1u << (hj - OSD_FLIPS_A)) : 0u) |
+                             ((hq >= OSD_FLIPS_A && hq < OSD_MAXFLIP) ? (1u << (hq - OSD_FLIPS_A)) : 0u);
+            const int l2 = 128 + (has2 ? lane : 0);
+            const int pb0 = wide ? __popc(ftabB[lane] & mskB) : 0, pb1 = wide ? __popc(ftabB[64 + lane] & mskB) : 0, pb2 = wide ? __popc(ftabB[l2] & mskB) : 0;
+            const uint64_t w0 = __ballot((__popcll(ftab[lane] & msk) + pb0) & 1), w1 = __ballot((__popcll(ftab[64 + lane] & msk) + pb1) & 1),
+                           w2 = __ballot(has2 && ((__popcll(ftab[l2] & msk) + pb2) & 1));
             const int hd = __popcll(w0 ^ hard0) + __popcll(w1 ^ hard1) + __popcll((w2 ^ hard2) & M2);
             if (max_hd > 0 && hd > max_hd) continue;          // gate (extension): no unpack() call beyond max_hd
             uint64_t lo = 0, hi = 0;
@@ -262,20 +303,24 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
 
 // mode 2 (test entry): one block per vector.  Pipeline: blocks stride over OSD work list x 10 attempts (5 AP variants of the fine
 // LLRs, then the 5 saved BP outputs).
-__global__ __launch_bounds__(64) void k_osd(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,
-                                            const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,
-                                            const int32_t* __restrict__ ncand, Att* __restrict__ attO,
-                                            ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,
-                                            int nflip, int max_hd, WorkList work) {
-    if (mode == 2) { osd_attempt(threadIdx.x, 2, blockIdx.x, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd); return; }
-    const int n = *work.count * 10;
-#pragma unroll 1
-    for (int item = blockIdx.x; item < n; item += gridDim.x) {
-        int lane = threadIdx.x;
-        asm volatile("" : "+v"(lane));                              // opaque per item: nothing lane-specific is hoisted across attempts (register pressure)
-        osd_attempt(lane, 0, work.items[item / 10] * 10 + item % 10, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd);
-        __syncthreads();                                            // the LDS arrays are reused by the next attempt
-    }
+#define OSD_KERNEL(NAME, WIDE)                                                                                                       \
+__global__ __launch_bounds__(64) void NAME(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,             \
+                                           const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,                            \
+                                           const int32_t* __restrict__ ncand, Att* __restrict__ attO,                               \
+                                           ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,        \
+                                           int nflip, int max_hd, WorkList work) {                                                  \
+    if (mode == 2) { osd_attempt<WIDE>(threadIdx.x, 2, blockIdx.x, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd); return; } \
+    const int n = *work.count * 10;                                                                                                 \
+    _Pragma("unroll 1")                                                                                                             \
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {                                                                      \
+        int lane = threadIdx.x;                                                                                                     \
+        asm volatile("" : "+v"(lane));       /* opaque per item: nothing lane-specific is hoisted across attempts (register pressure) */ \
+        osd_attempt<WIDE>(lane, 0, work.items[item / 10] * 10 + item % 10, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd); \
+        __syncthreads();                     /* the LDS arrays are reused by the next attempt */                                   \
+    }                                                                                                                               \
 }
+OSD_KERNEL(k_osd, false)
+OSD_KERNEL(k_osd_wide, true)        /* more than OSD_FLIPS_A flip rows */
+#undef OSD_KERNEL
 
 #endif

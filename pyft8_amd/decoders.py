@@ -56,9 +56,8 @@ def osd_012_batch(llr, singleflips=30, doubleflips=2):
 
 
 def osd_012(llr, singleflips=30, doubleflips=2):
-    """reference decoders.py:223-272.  The reference accepts any singleflips / doubleflips up to the 91 basis positions; the kernel
-    keeps one coverage bit per flip row in a 64-bit word, so both are limited to 62 here (the reference's own callers use 30 / 2,
-    its subtraction experiment 40 / 1) -- larger values raise Ft8rxError instead of silently doing less."""
+    """reference decoders.py:223-272.  Like the reference, any singleflips / doubleflips up to the 91 basis positions (its own callers
+    use 30 / 2, its subtraction experiment 40 / 1); beyond 91 the reference indexes past its flip list, here Ft8rxError."""
     ok, lo, hi, trial = osd_012_batch(np.asarray(llr, np.float32)[None], singleflips, doubleflips)
     if ok[0]:
         return unpack(_msg(lo[0], hi[0]))

@@ -162,7 +162,9 @@ def test_osd_exact(H):
     for name in GOLDEN_FRAMES:
         audio, gold, js = load_golden(name)
         x = gold["osd_llr_in"]
-        for s, d in [(30, 2), (40, 3), (0, 0)]:
+        # (62, 2) / (63, 5) straddle the one-word / two-word flip storage of the kernel, (91, 91) is every trial the reference's
+        # signature allows (decoders.py:244-272: all 91 basis positions singly, then all 4095 pairs)
+        for s, d in [(30, 2), (40, 3), (0, 0)] + ([(62, 2), (63, 5), (91, 3), (91, 91)] if name == GOLDEN_FRAMES[0] else []):
             ok, lo, hi, trial = H.osd(x, s, d)
             for k in range(len(x)):
                 w_ok, w_bits, w_trial, _ = O.osd(x[k], s, d)
@@ -180,10 +182,11 @@ def test_osd_ties_and_nans(H):
     x[10:20, 40:60] = np.nan
     x[20:24] = np.nan
     x[24:28] = 0.0
-    ok, lo, hi, trial = H.osd(x, 30, 2)
-    for k in range(len(x)):
-        w_ok, w_bits, w_trial, _ = O.osd(x[k], 30, 2)
-        assert bool(ok[k]) == w_ok and (not w_ok or (((int(hi[k]) << 64) | int(lo[k])) == w_bits and trial[k] == w_trial))
+    for s, d in [(30, 2), (91, 4)]:
+        ok, lo, hi, trial = H.osd(x, s, d)
+        for k in range(len(x)):
+            w_ok, w_bits, w_trial, _ = O.osd(x[k], s, d)
+            assert bool(ok[k]) == w_ok and (not w_ok or (((int(hi[k]) << 64) | int(lo[k])) == w_bits and trial[k] == w_trial))
 
 
 def test_osd_order3_and_distance_gate_exact(H):
@@ -885,6 +888,7 @@ def test_extension_knobs_pipeline():
     from pyft8_amd import _lib, synth
     audio = np.stack([synth.make_frame(70000 + i, n_signals=30, snr_range=(-20.0, -8.0)) for i in range(12)])
     for kw in (dict(bp_iters_b=30, osd_single=40, osd_double=3),
+               dict(osd_single=91, osd_double=4),                         # every basis position as a flip row (two-word flip storage)
                dict(bp_iters_b=30, osd_triple=20),                        # order-3 reprocessing, reference acceptance rule
                dict(osd_triple=30, osd_max_hd=32)):                       # config 4 as run by bench.py --config 4: order 3 + distance gate
         rec, cnt, ev, evc = _decode_with(kw, audio)
