@@ -16,7 +16,8 @@ from pyft8_amd.receiver import config_from_kwargs  # noqa: E402
 
 KW = [dict(), dict(), dict(sync_score_min=100, max_cands=150), dict(search_freq_range=[300, 2500], search_time_range=[-1.0, 2.0]),
       dict(search_freq_range=[100, 5900]), dict(search_freq_range=[1500, 4200], max_cands=90), dict(bp_iters_b=30, osd_single=40, osd_double=4),
-      dict(osd_triple=20, osd_max_hd=34), dict(max_cands=256, sync_score_min=70)]
+      dict(osd_triple=20, osd_max_hd=34), dict(max_cands=256, sync_score_min=70),
+      dict(osd_single=91, osd_double=3)]
 KNOBS = ("bp_nc0_a", "bp_iters_a", "bp_nc0_b", "bp_iters_b", "osd_single", "osd_double", "osd_triple", "osd_max_hd", "llr_sd_min")
 
 
@@ -31,7 +32,7 @@ def oracle_frame(args):
 
 
 def run_sweep(nb=20, fpb=16, seed=20260102, kw_list=None, first_index=9000000, verbose=True):
-    """nb batches of fpb random frames, batch b decoded with kw_list[b % len(kw_list)] (default: the nine sets of KW) and random
+    """nb batches of fpb random frames, batch b decoded with kw_list[b % len(kw_list)] (default: the ten sets of KW) and random
     stream counts / ladder modes; -> dict(frames, cands, msgs, bad, seconds, kwargs_sets).  Used by the command line below and by the
     driver-run test tests/test_gpu_parity.py::test_randomised_parity_sweep."""
     kw_list = KW if kw_list is None else kw_list
