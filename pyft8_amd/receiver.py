@@ -373,21 +373,22 @@ class AudioIn:
         # receiver's main handle must not touch that handle's staging audio, scratch rows or result slots
         with self._rx._live_lock:
             self.search_grid[self.search_grid_ptr, :] = self._rx._live_handle().hop_spectrum(self.audio_buffer[-self.search_fft_len:])[:self.search_grid.shape[1]]
-        early = self._rx.early_decode_hop
+        in_cycle = self.search_grid_ptr % self.search_hops_per_cycle
         if cycle_done:                                                   # the last hop of a cycle just landed
             self._audio = self.audio_buffer.copy()
             self.cycle_spectrum = None
             self.cycles_completed += 1
             with self._lock:
-                self._ready.append((self._audio, self._rx.time_source(), False))
-        elif early and self.search_grid_ptr % self.search_hops_per_cycle == early:
+                self._ready.append((self._audio, self._rx.time_source(), 0))
+        elif in_cycle in self._rx.early_decode_hops:
             # early pass (reference receiver.py:389-401 decodes candidates as their signals complete, first messages at ~12.9 s): the
-            # cycle so far, silence after it -- the payload of every signal that started by +1.6 s has arrived at hop 340 (13.6 s)
+            # cycle so far, silence after it -- the payload of every signal that started by +0.96 s has arrived at hop 320 (12.8 s), by
+            # +1.76 s at hop 340 (13.6 s)
             part = np.zeros(_lib.NSAMP, np.int16)
-            n_have = early * self.samples_perhop
+            n_have = in_cycle * self.samples_perhop
             part[:n_have] = self.audio_buffer[-n_have:]
             with self._lock:
-                self._ready.append((part, self._rx.time_source(), True))
+                self._ready.append((part, self._rx.time_source(), in_cycle))
         return (None, 0)                 # (None, pyaudio.paContinue)
 
     def get_cycle_spectrum(self):
@@ -403,7 +404,7 @@ class AudioIn:
 class Receiver:
     def __init__(self, input_device_keywords, on_message, sync_score_min=85, max_cands=200,
                  search_freq_range=[100, 3000], search_time_range=[-2.5 + 0.5, 2.5 + 0.5], verbose=False,
-                 device=0, max_frames=1, time_source=None, sleep=None, audio_source=None, autostart=None, early_decode_hop=340,
+                 device=0, max_frames=1, time_source=None, sleep=None, audio_source=None, autostart=None, early_decode_hop=(320, 340),
                  **extension_knobs):
         if search_freq_range[1] > 5900 or search_freq_range[0] < 12.5 or search_freq_range[0] >= search_freq_range[1]:
             # the reference sizes its grid from search_freq_range (receiver.py:234-240) and itself fails beyond ~5940 Hz, where the
@@ -423,12 +424,15 @@ class Receiver:
         self._live_lock = _threading.RLock()
         self._live = None
         self.thread_error = None
-        # streaming: also decode the partial cycle when this hop has arrived (340 = 13.6 s into the cycle), so that most messages are
-        # delivered before the next cycle starts, as the reference's are (its first decodes appear at ~12.9 s); None / 0 = only at
-        # the end of the cycle
-        if early_decode_hop and not 330 <= int(early_decode_hop) < 375:
-            raise _lib.Ft8rxError("early_decode_hop must lie in [330, 375) (a signal that starts at 0 s ends at hop 320) or be None")
-        self.early_decode_hop = int(early_decode_hop) if early_decode_hop else None
+        # streaming: also decode the partial cycle when these hops have arrived (320 = 12.8 s, 340 = 13.6 s into the cycle), so that
+        # most messages are delivered before the next cycle starts, as the reference's are (its first decodes appear at ~12.9 s,
+        # tests/PyFT8.txt:1-19); one hop, a sequence of hops, or None / 0 / () = only at the end of the cycle
+        hops = early_decode_hop if isinstance(early_decode_hop, (tuple, list)) else ((early_decode_hop,) if early_decode_hop else ())
+        hops = tuple(sorted({int(x) for x in hops}))
+        if any(not 300 <= x < 375 for x in hops):
+            raise _lib.Ft8rxError("early_decode_hop: hops must lie in [300, 375) (the payload of a signal that starts at 0 s is complete at hop 296) or be None")
+        self.early_decode_hops = hops
+        self.early_decode_hop = hops[-1] if hops else None    # the last early pass
         self._cycle_seen = {}                                 # cycle start -> message texts already delivered (early pass, then the full one)
         self.sync_score_min, self.max_cands = sync_score_min, max_cands
         self.verbose = verbose
@@ -691,7 +695,7 @@ class Receiver:
             with self.audio_in._lock:
                 if not self.audio_in._ready:
                     break
-                frame, t_now, early = self.audio_in._ready.pop(0)
+                frame, t_now, early = self.audio_in._ready.pop(0)           # early: hops of the cycle received so far, 0 = the complete frame
             # start of the cycle the frame belongs to: a full frame is handed over at its end, an early one inside it
             t0 = T_CYC * int(t_now / T_CYC) if early else T_CYC * int((t_now - T_CYC / 2) / T_CYC)
             cs = _time.strftime("%y%m%d_%H%M%S", _time.gmtime(t0))
@@ -707,7 +711,7 @@ class Receiver:
                 # criterion for starting on a candidate (its search_grid_bounds, receiver.py:355,389; the last Costas block only
                 # counts towards the sync gate) -- and no OSD decodes: first-CRC-valid-wins on a frame whose tail is padding
                 # produces false decodes that the complete frame does not; what OSD finds is delivered by the end-of-cycle pass
-                if early and (int(msgs[0, i]["h0_idx"]) + 4 + 4 * 72 + 4 > self.early_decode_hop or
+                if early and (int(msgs[0, i]["h0_idx"]) + 4 + 4 * 72 + 4 > early or
                               int(msgs[0, i]["method"]) in (_lib.M_OSD, _lib.M_LDPC_B_OSD)):
                     continue
                 text = " ".join(d["msg_tuple"])

@@ -1069,9 +1069,9 @@ def test_streaming_receiver_runs_itself_like_the_stock_cli():
 
 def test_streaming_early_decode_delivers_before_the_next_cycle():
     """VERDICT r2 #6 (reference receiver.py:389-401: candidates decode as their signals complete, first messages at ~12.9 s,
-    tests/PyFT8.txt:1-19): the streaming receiver also decodes the partial cycle at hop 340 (13.6 s) -- every signal that
-    whose payload symbols have arrived (start <= +1.6 s), OSD decodes excepted -- and the rest at hop 375.  Under the virtual clock: the early pass's messages are delivered
-    before 13.8 s, they are a subset of the frame-complete decode set, together with the end-of-cycle pass they ARE that set (up
+    tests/PyFT8.txt:1-19): the streaming receiver also decodes the partial cycle at hops 320 (12.8 s) and 340 (13.6 s) -- every signal
+    whose payload symbols have arrived (start <= +0.96 s / +1.76 s), OSD decodes excepted -- and the rest at hop 375.  Under the virtual
+    clock: the early passes' messages are delivered at 12.8 s and 13.6 s, they are a subset of the frame-complete decode set, together with the end-of-cycle pass they ARE that set (up
     to at most one OSD decode that depends on the padded tail), nothing is delivered twice, and a hop that arrives while the
     owner runs a two-pass decode_frames on the same Receiver does not disturb either (the live path has its own handle)."""
     from pyft8_amd.receiver import Receiver
@@ -1081,7 +1081,7 @@ def test_streaming_early_decode_delivers_before_the_next_cycle():
         vt = [0.0]
         got = []
         rx = Receiver("x", lambda d: got.append((vt[0], d)), time_source=lambda: vt[0])
-        assert rx.early_decode_hop == 340
+        assert rx.early_decode_hops == (320, 340) and rx.early_decode_hop == 340
         side = None
         for k in range(375):
             vt[0] = (k + 1) * 0.04
@@ -1092,7 +1092,11 @@ def test_streaming_early_decode_delivers_before_the_next_cycle():
         got = [(t, d) for t, d in got if "early" in d]           # (decode_frames delivers its own messages through on_message too)
         early = [(t, d) for t, d in got if d["early"]]
         late = [(t, d) for t, d in got if not d["early"]]
-        assert early and all(t <= 13.6 + 1e-9 for t, _ in early) and all(abs(t - 15.0) < 1e-9 for t, _ in late)
+        assert early and all(min(abs(t - 12.8), abs(t - 13.6)) < 1e-9 for t, _ in early) and all(abs(t - 15.0) < 1e-9 for t, _ in late)
+        first = [d for t, d in early if abs(t - 12.8) < 1e-9]
+        # the 12.8-s pass: h0 <= 24 hops (+ a time tweak).  These recordings start ~0.9 s before their cycle (signals at +1.4 s), so only
+        # test_09's three earliest signals qualify, none of test_08's; a receiver on the wall clock sees its signals at +0.5 s = hop 308
+        assert all(d["tsec"] <= 1.0 for d in first) and len(first) == (3 if name == "test_09" else 0)
         e_txt = [" ".join(d["msg_tuple"]) for _, d in early]
         all_txt = e_txt + [" ".join(d["msg_tuple"]) for _, d in late]
         assert len(set(all_txt)) == len(all_txt)                                   # the per-cycle duplicate filter
@@ -1105,7 +1109,7 @@ def test_streaming_early_decode_delivers_before_the_next_cycle():
         # the mid-cycle batch job saw exactly what a fresh Receiver decodes, both frames alike
         fresh = Receiver("x", None).decode_frames(np.stack([audio, audio]), passes=2)
         assert [[" ".join(m["msg_tuple"]) for m in f] for f in side] == [[" ".join(m["msg_tuple"]) for m in f] for f in fresh]
-        print(f"{name}: {len(e_txt)} of {len(ref_txt)} messages delivered at 13.6 s, {len(late)} at 15.0 s")
+        print(f"{name}: {len(first)} of {len(ref_txt)} messages delivered at 12.8 s, {len(e_txt) - len(first)} at 13.6 s, {len(late)} at 15.0 s")
         rx.stop()
 
 
