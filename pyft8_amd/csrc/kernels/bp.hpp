@@ -24,7 +24,10 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
                         int max_nc0, int max_iters) {
     __shared__ float llr[176];
     __shared__ float tl[576];        // 9 x 64 edge slots: slots >= 522 are dummy edges (variable 174, check 83) so that the
-    __shared__ float dl[576];        // per-edge code below is straight-line for all nine slots of a lane
+    // per-edge code below is straight-line for all nine slots of a lane.  The message deltas overwrite the tanh values in place: a
+    // lane reads tl[e] and writes dl[e] of its OWN slots only, after the barrier behind the check products (the only readers of other
+    // lanes' tanh values) -- 2.3 KB of LDS less per wave: bp_fine 0.719 -> 0.694 ms, bp_grid 0.171 -> 0.167 (profiles/r03_notes.md)
+    float* dl = tl;
     __shared__ float P[84];
     int frame = 0, ci = 0, ap = 0; size_t vec;
     if (mode == 2) vec = bid;

@@ -45,10 +45,12 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     __shared__ float llr[176];
     __shared__ uint64_t skey[256];
     __shared__ uint64_t ftab[192];                         // per column (natural order): bit i = flip i covers it (i < 62), bit 63 = order-0 codeword bit
-    uint32_t* ftabB = reinterpret_cast<uint32_t*>(skey);  // [192] bit i - 62 = flip i covers it (62 <= i < 91); the sort keys are dead by then
+    // the sort keys are dead once the reliability order has been read into registers; their 2 KB then hold
+    uint32_t* ftabB = reinterpret_cast<uint32_t*>(skey);  // [192] bit i - 62 = flip i covers it (62 <= i < 91), and
+    uint32_t* frow = ftabB + 192;                          // [3 (OSD_MAXFLIP + 1)] unit vectors of the flip columns (their pivot rows)
+    static_assert((192 + 3 * (OSD_MAXFLIP + 1)) * sizeof(uint32_t) <= 256 * sizeof(uint64_t), "ftabB + frow overlay the sort keys");
     constexpr bool wide = WIDE;                            // nflip > OSD_FLIPS_A (the launcher picks the kernel)
     const int nflipA = wide ? OSD_FLIPS_A : nflip;
-    __shared__ uint32_t frow[3 * (OSD_MAXFLIP + 1)];       // unit vectors of the flip columns (their pivot rows)
     __shared__ uint32_t hmw[3];
     __shared__ uint16_t fsyn[OSD_MAXFLIP + 2];             // [i] flip i, [OSD_MAXFLIP] = 0 ("no flip"), [OSD_MAXFLIP + 1] order-0 codeword
     int frame = 0, ci = 0, slot = 0; size_t vec = bid;
@@ -303,8 +305,14 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
 
 // mode 2 (test entry): one block per vector.  Pipeline: blocks stride over OSD work list x 10 attempts (5 AP variants of the fine
 // LLRs, then the 5 saved BP outputs).
+// Eight waves per SIMD: the elimination is a serial chain of readlane -> scalar logic -> masked XOR per step (~280 cycles), hidden only
+// by other waves.  The kernel needs 59 VGPRs when told to fit eight (71 otherwise) and 4.5 KB of LDS since the flip rows share the
+// dead sort keys (5.6 KB allowed 7): 0.739 -> 0.710 ms per 256 frames (profiles/r03_notes.md; the attribute alone, LDS-bound at 7: 0.781)
+#ifndef OSD_ATTR
+#define OSD_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 #define OSD_KERNEL(NAME, WIDE)                                                                                                       \
-__global__ __launch_bounds__(64) void NAME(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,             \
+__global__ __launch_bounds__(64) OSD_ATTR void NAME(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,             \
                                            const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,                            \
                                            const int32_t* __restrict__ ncand, Att* __restrict__ attO,                               \
                                            ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,        \

@@ -1131,6 +1131,13 @@ def test_error_paths_and_lifecycle():
     assert list(cnt) == [0, 0]
     h.close()
     h.close()                                                              # idempotent
+    from pyft8_amd.receiver import Receiver
+    with pytest.raises(_lib.Ft8rxError, match="early_decode_hop"):
+        Receiver("x", None, early_decode_hop=200)                          # before the payload of any signal can be complete
+    for v, want in (((320, 340), (320, 340)), (340, (340,)), (None, ()), ([350, 310, 350], (310, 350))):
+        rx = Receiver("x", None, early_decode_hop=v)
+        assert rx.early_decode_hops == want and rx.early_decode_hop == (want[-1] if want else None)
+        rx.stop()
 
 
 def test_repeatable_across_runs_and_stream_counts(ocfg):
