@@ -163,6 +163,12 @@ int  ft8rx_set_streams(ft8rx_handle* h, int n);
  *     (one frame: 0.38 vs 0.49 ms host to host).  The event log then also holds CRC-passing words of attempts the ladder would not
  *     have reached; ft8rx_package_batch skips them. */
 int  ft8rx_set_ladder_mode(ft8rx_handle* h, int mode);
+/* Local re-search of the reference's subtraction experiment (tests/pipeline/receiver_sub.py:434-445: after a signal has been
+ * subtracted, search(f0_idx - 2 .. f0_idx + 1, ignore_sync_score_min = True)): mask[n_frames][cfg.f0_hi - cfg.f0_lo], one byte per
+ * search column.  While a mask is set, the candidate selection of every batch (Receiver.search, receiver.py:338-367) takes ONLY the
+ * columns whose byte is non-zero and every score above 0 instead of above sync_score_min; order (score descending, stable) and the
+ * max_cands cap as always.  mask = NULL: back to the configured search.  Batches in flight finish under the setting they started with. */
+int  ft8rx_set_search_mask(ft8rx_handle* h, const uint8_t* mask, int n_frames);
 int  ft8rx_set_profiling(ft8rx_handle* h, int on);
 int  ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms);
 

@@ -45,6 +45,16 @@ static int run_sub(const int16_t* audio, const ft8o_config* cfg) {
         f = msgs[i].fHz; t = (i == 0) ? 0.0001 : 2.45;            /* start sample 1; a signal that runs off the end of the buffer */
         done += ft8o_refine2_subtract(wf, tones, &f, &t, 1);
     }
+    /* the local re-search: a mask shorter than / as long as / longer than the search range, then the configured search again */
+    static uint8_t mask[5000];
+    for (int i = 0; i < 5000; i++) mask[i] = (uint8_t)((i % 11) == 0);
+    const int lens[3] = {100, cfg->f0_hi - cfg->f0_lo, 5000};
+    for (int k = 0; k < 3; k++) {
+        ft8o_set_search_mask(mask, lens[k]);
+        ft8o_decode_frame(audio, cfg, cands, &nc, evlog, 4096, &nl, msgs, 256, &nm);
+        done += nm;
+    }
+    ft8o_set_search_mask(NULL, 0);
     return done;
 }
 

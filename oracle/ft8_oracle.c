@@ -245,9 +245,21 @@ static inline float grid_at(const float* grid, int row, int col) {
 /* ------------------------------------------------------------------ sync search (receiver.py:338-367) */
 static const double W6 = (double)(-0.16666667163372040f);          /* np.float32(-1/6), receiver.py:323 */
 
+/* Local re-search of the subtraction experiment (tests/pipeline/receiver_sub.py:434-445: search(range(f0 - 2, f0 + 2),
+ * ignore_sync_score_min = True) around every subtracted signal): while a mask is set, only the columns with a non-zero byte are
+ * searched and every score above 0 makes a candidate.  mask[f0 - f0_lo]; NULL = the configured search.  Process-global (test
+ * infrastructure: one frame at a time per process). */
+static uint8_t g_search_mask[4096]; static int g_search_mask_n = 0;
+void ft8o_set_search_mask(const uint8_t* mask, int32_t n) {
+    if (!mask || n <= 0) { g_search_mask_n = 0; return; }
+    if (n > (int32_t)sizeof(g_search_mask)) n = (int32_t)sizeof(g_search_mask);
+    memcpy(g_search_mask, mask, (size_t)n); g_search_mask_n = n;
+}
+
 int ft8o_sync_search(const float* grid, const ft8o_config* c, ft8o_cand* out) {
     int n = 0;
     for (int f0 = c->f0_lo; f0 < c->f0_hi; f0++) {
+        if (g_search_mask_n && !(f0 - c->f0_lo < g_search_mask_n && g_search_mask[f0 - c->f0_lo])) continue;
         float best = 0.0f; int best_h0 = 0;
         for (int h0 = c->h0_lo; h0 < c->h0_hi; h0++) {
             double s1 = 0.0, tsum = 0.0;
@@ -261,7 +273,7 @@ int ft8o_sync_search(const float* grid, const ft8o_config* c, ft8o_cand* out) {
             float score = (float)(s1 + W6 * (tsum - s1));
             if (score > best) { best = score; best_h0 = h0; }       /* first strict maximum */
         }
-        if (best > c->sync_score_min) {
+        if (best > (g_search_mask_n ? 0.0f : c->sync_score_min)) {
             memset(&out[n], 0, sizeof(out[n]));
             out[n].f0_idx = f0; out[n].h0_idx = best_h0; out[n].score = best; out[n].ipass = -1;
             n++;

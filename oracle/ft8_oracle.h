@@ -83,6 +83,8 @@ float ft8o_tanhf(float x);
 void  ft8o_fft(float* data /* interleaved re,im */, int n, const int32_t* plan, float* scratch);
 void  ft8o_spectrogram(const int16_t* audio, const ft8o_config* c, float* grid /*[376][976]*/);
 int   ft8o_sync_search(const float* grid, const ft8o_config* c, ft8o_cand* out /* >= 960 */);
+/* local re-search (receiver_sub.py:434-445): only the columns with mask[f0 - f0_lo] != 0, every score above 0; NULL = configured search */
+void  ft8o_set_search_mask(const uint8_t* mask, int32_t n);
 void  ft8o_payload(const float* grid, int f0_idx, int h0_idx, float* p /*[58][8]*/);
 int   ft8o_db_to_llr(const float* p /*[58][8]*/, float* llr /*[174]*/, float* sd, int32_t* snr);
 void  ft8o_cycle_spectrum(const int16_t* audio, const ft8o_config* c, float* spec /*[SPEC_BINS][2]*/);

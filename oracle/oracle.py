@@ -342,11 +342,39 @@ def to_int16(audio_f32):
     return np.clip(np.rint(audio_f32), -32768, 32767).astype(np.int16)
 
 
-def decode_frame_passes(audio, cfg=None, passes=2, min_snr=-10, refine=2, drop_osd=False):
+def set_search_mask(mask, cfg=None):
+    """ft8o_set_search_mask: mask[f0_hi - f0_lo] of bytes (local re-search, receiver_sub.py:434-445) or None = the configured search;
+    process-global in both oracle builds."""
+    for wide in (False, True):
+        try:
+            L = lib(wide)
+        except Exception:
+            continue
+        if mask is None:
+            L.ft8o_set_search_mask(None, 0)
+        else:
+            m = np.ascontiguousarray(mask, np.uint8)
+            L.ft8o_set_search_mask(_p(m, C.c_uint8), len(m))
+
+
+def local_search_mask(sig_f0, cfg):
+    """The columns the experiment re-searches after subtracting signals at the search columns sig_f0: range(f0 - 2, f0 + 2) each
+    (receiver_sub.py:440), clipped to the configured range."""
+    m = np.zeros(cfg.f0_hi - cfg.f0_lo, np.uint8)
+    for f0 in sig_f0:
+        for c in range(int(f0) - 2, int(f0) + 2):
+            if cfg.f0_lo <= c < cfg.f0_hi:
+                m[c - cfg.f0_lo] = 1
+    return m
+
+
+def decode_frame_passes(audio, cfg=None, passes=2, min_snr=-10, refine=2, drop_osd=False, research="full"):
     """Multi-pass decode of one frame as pyft8_amd.Receiver.decode_frames_arrays(passes=...) composes it (extension):
     decode; subtract every new message with snr > min_snr, in emit order, from a float32 copy (refine = 2: origin re-estimated on the
     decimated baseband copy; 3: the reference experiment's refine_time_origin then its subtract_signal; 0: subtract_signal as is);
-    round to int16; decode the residual; append the messages whose text the frame does not have yet.
+    round to int16; decode the residual; append the messages whose text the frame does not have yet.  research = "local": the
+    residual is searched only in the columns f0 - 2 .. f0 + 1 of the subtracted signals, with the sync threshold ignored, and what that
+    finds is not subtracted again (the experiment's scheduling, receiver_sub.py:434-445, batched: one sweep instead of one per decode).
     -> dict(msgs = [(pass, msg dict)], origins = per sweep the refined (fHz, tsec) list, residual = int16 audio after the last sweep)"""
     cfg = cfg or default_config()
     audio = np.ascontiguousarray(audio, np.int16)
@@ -359,6 +387,7 @@ def decode_frame_passes(audio, cfg=None, passes=2, min_snr=-10, refine=2, drop_o
         sigs = subtraction_list(fresh, min_snr)
         if not sigs:
             break
+        sig_f0 = [fresh["cands"][m["cand"]].f0_idx for m in fresh["msgs"] if m["snr"] > int(np.floor(min_snr))]
         wf = cur.astype(np.float32)
         sweep = []
         for tones, fHz, tsec in sigs:
@@ -372,7 +401,14 @@ def decode_frame_passes(audio, cfg=None, passes=2, min_snr=-10, refine=2, drop_o
             sweep.append((fHz, tsec))
         origins.append(sweep)
         cur = to_int16(wf)
-        r2 = decode_frame(cur, cfg)
+        if research == "local":
+            set_search_mask(local_search_mask(sig_f0, cfg))
+            try:
+                r2 = decode_frame(cur, cfg)
+            finally:
+                set_search_mask(None)
+        else:
+            r2 = decode_frame(cur, cfg)
         have = {m["msg_tuple"] for _, m in out}
         new = []
         for m in r2["msgs"]:
@@ -384,4 +420,6 @@ def decode_frame_passes(audio, cfg=None, passes=2, min_snr=-10, refine=2, drop_o
             new.append(m)
             out.append((p, m))
         fresh = dict(cands=r2["cands"], msgs=new)
+        if research == "local":
+            break                                                   # candidates of the local re-search are not subtracted again (:444)
     return dict(msgs=out, origins=origins, residual=cur)

@@ -292,6 +292,18 @@ class Handle:
         """0 (default) = fine-stage BP in ladder order, three launches (throughput); 1 = one launch for the five AP variants (latency)."""
         self._chk(self._L.ft8rx_set_ladder_mode(self._h, int(mode)), "ft8rx_set_ladder_mode")
 
+    def set_search_mask(self, mask):
+        """mask[n_frames, f0_hi - f0_lo] (non-zero = search this column, any score > 0) for the following batches, or None = the
+        configured search again (ft8rx_set_search_mask: the subtraction experiment's local re-search)."""
+        if mask is None:
+            self._chk(self._L.ft8rx_set_search_mask(self._h, None, 0), "ft8rx_set_search_mask")
+            return
+        m = np.ascontiguousarray(mask, np.uint8)
+        nf0 = self.cfg.f0_hi - self.cfg.f0_lo
+        if m.ndim != 2 or m.shape[1] != nf0:
+            raise Ft8rxError(f"set_search_mask: mask must be [n_frames, {nf0}]")
+        self._chk(self._L.ft8rx_set_search_mask(self._h, m.ctypes.data_as(C.c_void_p), m.shape[0]), "ft8rx_set_search_mask")
+
     def set_profiling(self, on):
         self._L.ft8rx_set_profiling(self._h, int(bool(on)))
 

@@ -100,6 +100,7 @@ struct ft8rx_handle {
     const uint32_t* d_trials; int n_trials;      // OSD trial list of this configuration
     int32_t* d_work[WL_N];                       // ladder work lists (kernels/common.hpp: WorkList), [B][MAXC] candidate ids each
     int32_t* d_wcount;                           // [16 chunks][WL_N] list lengths, zeroed at the head of every chunk's chain
+    uint8_t* d_colmask; bool use_mask;           // [B][NF0MAX] search mask of the local re-search (ft8rx_set_search_mask), allocated on first use
     // Result slots.  A batch writes its records/events into slot k % 2 (slot 0 = d_rec/d_ncand/d_ev/d_evcount above) and, when its
     // kernels are done, the copy stream moves them into page-locked host buffers while the next batch computes into the other
     // slot; ft8rx_fetch_results hands out the oldest unfetched batch.  At most two batches' results are retained.
@@ -275,6 +276,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) h->ev_cdone[k][i] = nullptr;
     h->free_running = false; h->need_barrier = true; h->part_B = h->part_n = 0;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
+    h->d_colmask = nullptr; h->use_mask = false;
     h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr; h->d_ones = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
@@ -435,7 +437,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
     k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, c);
     STAGE("topk");
-    k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c, evc, wc);
+    k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c, evc, wc, h->use_mask ? h->d_colmask + F * NF0MAX : nullptr);
     STAGE("grid_llr");
     k_grid_llr<<<B * MAXC, 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr, att0, ev, evc);
     k_worklist_att<<<(B * MAXC * 5 + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_BP0]);
@@ -657,6 +659,20 @@ int ft8rx_enqueue_batch_host(ft8rx_handle* h, const int16_t* audio, int B) {
 int ft8rx_set_streams(ft8rx_handle* h, int n) { if (!h || n < 1 || n > 8) return -1; h->n_streams = n; return 0; }
 int ft8rx_set_ladder_mode(ft8rx_handle* h, int mode) { if (!h || mode < 0 || mode > 1) return -1; h->ladder_mode = mode; return 0; }
 
+int ft8rx_set_search_mask(ft8rx_handle* h, const uint8_t* mask, int n_frames) {
+    if (!h) return -1;
+    ENTER(h);                                   // batches in flight were enqueued under the previous setting
+    if (!mask) { h->use_mask = false; return 0; }
+    if (n_frames < 1 || n_frames > h->max_frames) { set_err(h, "ft8rx_set_search_mask: n_frames %d outside [1, %d]", n_frames, h->max_frames); return -1; }
+    if (!h->d_colmask && dalloc(h, &h->d_colmask, (size_t)h->max_frames * NF0MAX)) return -2;
+    const int nf0 = h->cfg.f0_hi - h->cfg.f0_lo;
+    HIPCHK(h, hipMemsetAsync(h->d_colmask, 0, (size_t)h->max_frames * NF0MAX, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->d_colmask, NF0MAX, mask, (size_t)nf0, (size_t)nf0, n_frames, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->use_mask = true;
+    return 0;
+}
+
 int ft8rx_sync(ft8rx_handle* h) {
     if (!h) return -1;
     HIPCHK(h, hipSetDevice(h->device));
@@ -780,7 +796,7 @@ int ft8rx_sync_search(ft8rx_handle* h, const float* grid, int B, int32_t* f0_idx
     HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
     const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
     k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), h->stream>>>(h->d_grid, h->d_best_score, h->d_best_h0, c);
-    k_topk<<<B, 1024, 0, h->stream>>>(h->d_best_score, h->d_best_h0, h->d_rec, h->d_ncand, c, nullptr, nullptr);
+    k_topk<<<B, 1024, 0, h->stream>>>(h->d_best_score, h->d_best_h0, h->d_rec, h->d_ncand, c, nullptr, nullptr, nullptr);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<ft8rx_record> rec((size_t)B * MAXC);
     HIPCHK(h, hipMemcpy(rec.data(), h->d_rec, sizeof(ft8rx_record) * rec.size(), hipMemcpyDeviceToHost));

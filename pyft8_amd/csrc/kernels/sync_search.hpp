@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, fl
 // NF0MAX keys (1024; 2048 in the wide build) on 1024 threads: bitonic network in LDS, KPT compare-exchanges per thread and step.
 __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ best_score, const int32_t* __restrict__ best_h0,
                                                ft8rx_record* __restrict__ rec, int32_t* __restrict__ ncand, ft8rx_config cfg,
-                                               int32_t* __restrict__ evcount, int32_t* __restrict__ wcount) {
+                                               int32_t* __restrict__ evcount, int32_t* __restrict__ wcount,
+                                               const uint8_t* __restrict__ colmask) {
     constexpr int KPT = NF0MAX / 1024;
     // the chain's per-frame event counters and its work-list lengths start at zero: cleared here (the first kernel after which they
     // are used) instead of by two memset launches per chain
@@ -89,7 +90,9 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ best_sc
         uint64_t k = ~0ull;
         if (i < nf0) {
             float s = best_score[(size_t)f * NF0MAX + i];
-            if (s > cfg.sync_score_min) k = ((uint64_t)(~__float_as_uint(s)) << 32) | (uint32_t)i;   // s > 0: bit pattern is monotonic
+            // local re-search (ft8rx_set_search_mask; receiver_sub.py:434-445): only the masked columns, every score above 0
+            const bool take = colmask ? (colmask[(size_t)f * NF0MAX + i] != 0 && s > 0.0f) : (s > cfg.sync_score_min);
+            if (take) k = ((uint64_t)(~__float_as_uint(s)) << 32) | (uint32_t)i;   // s > 0: bit pattern is monotonic
         }
         key[i] = k;
     }

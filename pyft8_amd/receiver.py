@@ -567,7 +567,7 @@ class Receiver:
         return cands
 
     def decode_frames(self, audio_i16, cyclestart_strings=None, return_records=False, passes=1, subtract_min_snr=-10,
-                      sub_pass_osd=True):
+                      sub_pass_osd=True, research="full"):
         """Decode B independent 15-s frames.  -> list (per frame) of message dicts in emit order.
 
         passes > 1 (extension): after each pass every newly decoded signal with SNR > subtract_min_snr is
@@ -576,15 +576,47 @@ class Receiver:
         messages found that way are appended with "_SUB" added to decode_notes (as the reference tags them, :131-132).  Unlike
         the reference experiment -- which subtracts after every single decode, serially -- a pass subtracts all of a frame's
         new decodes at once, so whole batches stay on the GPU.  sub_pass_osd=False drops OSD decodes (ipass 5/6: first CRC-valid
-        trial wins, the reference's source of false decodes) found in the later passes -- fewer false decodes, slightly less yield."""
+        trial wins, the reference's source of false decodes) found in the later passes -- fewer false decodes, slightly less yield.
+        research="local" is the experiment's re-search (receiver_sub.py:434-445), batched: the residual is searched only in the columns
+        f0 - 2 .. f0 + 1 of the subtracted signals, with the sync threshold ignored (ft8rx_set_search_mask), and what that finds is not
+        subtracted again -- one sweep for all of a frame's decodes where the experiment does one per decode."""
         audio = _as_frames(audio_i16)
         B = audio.shape[0]
         if B == 0:
             return ([], np.zeros((0, self.cfg.max_cands), _lib.RECORD_DTYPE), np.zeros(0, np.int32)) if return_records else []
         with self._hlock:
-            return self._decode_frames_locked(audio, B, cyclestart_strings, return_records, passes, subtract_min_snr, sub_pass_osd)
+            return self._decode_frames_locked(audio, B, cyclestart_strings, return_records, passes, subtract_min_snr, sub_pass_osd, research)
 
-    def _decode_frames_locked(self, audio, B, cyclestart_strings, return_records, passes, subtract_min_snr, sub_pass_osd):
+    def _local_mask(self, msgs, mcnt, min_snr):
+        """Search mask of the local re-search: columns f0 - 2 .. f0 + 1 (receiver_sub.py:440) of every message the sweep subtracts."""
+        B = len(mcnt)
+        lo, hi = self.cfg.f0_lo, self.cfg.f0_hi
+        mask = np.zeros((B, hi - lo), np.uint8)
+        sel = (np.arange(msgs.shape[1])[None, :] < np.asarray(mcnt)[:, None]) & (msgs["snr"] > min_snr)
+        fi, mi = np.nonzero(sel)
+        f0 = msgs["f0_idx"][fi, mi].astype(np.int64)
+        for d in (-2, -1, 0, 1):
+            c = f0 + d
+            ok = (c >= lo) & (c < hi)
+            mask[fi[ok], c[ok] - lo] = 1
+        return mask
+
+    def _residual_decode(self, h, B, local, msgs, mcnt, min_snr):
+        """Decode the frames in the handle's staging buffer (after a subtraction sweep); local = the experiment's local re-search."""
+        if not local:
+            h.enqueue(h.staging_ptr(), B)
+            return h.fetch(B)
+        h.set_search_mask(self._local_mask(msgs, mcnt, min_snr))
+        try:
+            h.enqueue(h.staging_ptr(), B)
+            return h.fetch(B)
+        finally:
+            h.set_search_mask(None)
+
+    def _decode_frames_locked(self, audio, B, cyclestart_strings, return_records, passes, subtract_min_snr, sub_pass_osd, research="full"):
+        if research not in ("full", "local"):
+            raise _lib.Ft8rxError('research must be "full" or "local"')
+        local = research == "local"
         h = self._handle(B)
         rec, cnt, ev, evc = h.decode_batch(audio)
         # host message layer: native, multithreaded (ft8rx_package_batch); messages.package_frame is its Python twin
@@ -598,8 +630,7 @@ class Receiver:
             if not sigs[1].any():
                 break
             h.subtract(h.staging_ptr(), B, sigs, refine=self.subtract_refine)    # decode_batch left the frames in the handle's device buffer
-            h.enqueue(h.staging_ptr(), B)
-            rec, cnt, ev, evc = h.fetch(B)
+            rec, cnt, ev, evc = self._residual_decode(h, B, local, msgs, mcnt, subtract_min_snr)
             msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc)
             keep = np.zeros(mcnt.shape, np.int32)
             for f in range(B):
@@ -616,6 +647,8 @@ class Receiver:
                             self.on_message(d)
                 out[f] += new
             mcnt = keep
+            if local:
+                break                                                # candidates of the local re-search are not subtracted again (:444)
         return (out, rec, cnt) if return_records else out
 
     @staticmethod
@@ -645,7 +678,7 @@ class Receiver:
         arr["tsec"][fi, slot] = m["h0_idx"] / 25.0 + np.where(fine, m["ttweak"] / 200.0, 0.0)
         return arr, cnt
 
-    def decode_frames_arrays(self, audio_i16, n_threads=None, passes=1, subtract_min_snr=-10, sub_pass_osd=True):
+    def decode_frames_arrays(self, audio_i16, n_threads=None, passes=1, subtract_min_snr=-10, sub_pass_osd=True, research="full"):
         """High-throughput variant of decode_frames: no Python dicts.  -> (messages[B, 128] of _lib.MESSAGE_DTYPE,
         counts[B], records[B, max_cands], record_counts[B]); rows are in the reference's emit order.  With passes > 1 (see
         decode_frames) the messages of the later passes are appended per frame and carry the pass index (1, 2, ...) in
@@ -655,9 +688,12 @@ class Receiver:
         if B == 0:
             raise _lib.Ft8rxError("empty batch")
         with self._hlock:
-            return self._decode_frames_arrays_locked(audio, B, n_threads, passes, subtract_min_snr, sub_pass_osd)
+            return self._decode_frames_arrays_locked(audio, B, n_threads, passes, subtract_min_snr, sub_pass_osd, research)
 
-    def _decode_frames_arrays_locked(self, audio, B, n_threads, passes, subtract_min_snr, sub_pass_osd):
+    def _decode_frames_arrays_locked(self, audio, B, n_threads, passes, subtract_min_snr, sub_pass_osd, research="full"):
+        if research not in ("full", "local"):
+            raise _lib.Ft8rxError('research must be "full" or "local"')
+        local = research == "local"
         h = self._handle(B)
         rec, cnt, ev, evc = h.decode_batch(audio)
         msgs, mcnt = _lib.package_batch(rec, cnt, ev, evc, n_threads=n_threads)
@@ -670,11 +706,12 @@ class Receiver:
             if not sigs[1].any():
                 break
             h.subtract(h.staging_ptr(), B, sigs, refine=self.subtract_refine)
-            h.enqueue(h.staging_ptr(), B)
-            rec2, cnt2, ev2, evc2 = h.fetch(B)
+            rec2, cnt2, ev2, evc2 = self._residual_decode(h, B, local, cur_m, cur_c, subtract_min_snr)
             m2, c2 = _lib.package_batch(rec2, cnt2, ev2, evc2, n_threads=n_threads)
             new_m, new_c = _lib.merge_messages(out, ocnt, m2, c2, p, drop_osd=not sub_pass_osd)      # native: appends in place
             cur_m, cur_c, cur_rec = new_m, new_c, rec2
+            if local:
+                break
         return out, ocnt, rec, cnt
 
     def decode_frame(self, audio_i16, cyclestart_string="700101_000015"):
@@ -725,9 +762,9 @@ class Receiver:
         return out
 
 
-def decode_frames(audio_i16, on_message=None, passes=1, **receiver_kwargs):
+def decode_frames(audio_i16, on_message=None, passes=1, research="full", **receiver_kwargs):
     """decode_frames(audio_i16[B,180000], **receiver_kwargs) -> list[list[message dict]]  (SURVEY.md 8b); passes > 1 adds the
     subtraction passes of Receiver.decode_frames."""
     audio = _as_frames(audio_i16)
     rx = Receiver("", on_message, max_frames=max(1, audio.shape[0]), **receiver_kwargs)
-    return rx.decode_frames(audio, passes=passes)
+    return rx.decode_frames(audio, passes=passes, research=research)

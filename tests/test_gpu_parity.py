@@ -843,6 +843,65 @@ def test_multi_pass_matches_the_oracle_composition(ocfg):
     print(f"multi-pass vs oracle: {same_pt}/{tot} refined origins on the same grid point, {frames_equal}/{B} frames with identical message lists")
 
 
+def test_local_research_mask_and_composition(ocfg):
+    """The experiment's re-search (tests/pipeline/receiver_sub.py:434-445: after a subtraction, search(f0 - 2 .. f0 + 1,
+    ignore_sync_score_min = True)) as ft8rx_set_search_mask: (1) a batch decoded under a mask -- only the masked columns, every
+    score above 0 -- equals the oracle under the same mask record for record, and the mask is gone after set_search_mask(None);
+    (2) Receiver.decode_frames_arrays(passes=2, research="local") against oracle.decode_frame_passes(research="local"): identical
+    (pass, text) lists in every frame whose refined origins all agree, and in at least 5 of 6 frames."""
+    from pyft8_amd import _lib, synth
+    from pyft8_amd.receiver import Receiver
+    n = 5
+    rx = Receiver("", None, max_frames=n + 1)
+    h = rx._handle(n + 1)
+    h.synth_frames(h.staging_ptr(), 8400000, n, n_signals=50, snr_range=(-10.0, 10.0))
+    audio = np.concatenate([h.download_audio(h.staging_ptr(), n), load_golden("test_08")[0][None]])
+    B = n + 1
+    # (1) masked search, bit for bit
+    rng = np.random.default_rng(3)
+    mask = (rng.random((B, rx.cfg.f0_hi - rx.cfg.f0_lo)) < 0.08).astype(np.uint8)
+    mask[1] = 0                                                     # a frame with nothing to search
+    h.set_search_mask(mask)
+    rec, cnt, ev, evc = h.decode_batch(audio)
+    h.set_search_mask(None)
+    assert cnt[1] == 0 and cnt.max() <= int(mask.sum(axis=1).max())
+    for f in range(B):
+        O.set_search_mask(mask[f])
+        try:
+            _check_frame(rec[f], cnt[f], ev[f], evc[f], audio[f], None, ocfg)
+        finally:
+            O.set_search_mask(None)
+        assert all(mask[f, int(r["f0_idx"]) - rx.cfg.f0_lo] for r in rec[f, :cnt[f]])
+    rec0, cnt0, ev0, evc0 = h.decode_batch(audio)
+    for f in range(2):
+        _check_frame(rec0[f], cnt0[f], ev0[f], evc0[f], audio[f], None, ocfg)               # the configured search is back
+    # (2) the composition
+    msgs, mcnt, _, _ = rx.decode_frames_arrays(audio, passes=2, research="local")
+    full, fcnt, _, _ = rx.decode_frames_arrays(audio, passes=2)
+    r1, c1, e1, ec1 = h.decode_batch(audio)
+    m1, mc1 = _lib.package_batch(r1, c1, e1, ec1)
+    _, orig = h.subtract(h.staging_ptr(), B, _lib.subtraction_list(m1, mc1, r1, -10), refine=2, return_origins=True)
+    frames_equal = n_local = n_full = 0
+    for f in range(B):
+        want = O.decode_frame_passes(audio[f], ocfg, passes=2, research="local")
+        mine = [(int(m["pad"][0]), tuple(x.decode() for x in m["f"])) for m in msgs[f, :mcnt[f]]]
+        theirs = [(p, m["msg_tuple"]) for p, m in want["msgs"]]
+        assert [t for p, t in mine if p == 0] == [t for p, t in theirs if p == 0], f
+        all_same = all(round((tg - to) * 12000) == 0 and abs((fg - fo) * 64) < 1e-6 for (fg, tg), (fo, to) in zip(orig[f], want["origins"][0]))
+        if all_same:
+            assert mine == theirs, (f, mine, theirs)
+        frames_equal += mine == theirs
+        n_local += sum(p == 1 for p, _ in mine)
+        n_full += int((full[f, :fcnt[f]]["pad"][:, 0] == 1).sum())
+    assert frames_equal >= B - 1, frames_equal
+    # (±2 search columns = ±6 Hz around a 50-Hz-wide subtracted signal: most of what a subtraction uncovers lies further away, so the
+    # experiment's local re-search finds only part of what a full second pass finds -- 15 vs 54 messages on these six frames)
+    assert 0 < n_local <= n_full, (n_local, n_full)
+    with pytest.raises(_lib.Ft8rxError, match="research"):
+        rx.decode_frames(audio[:1], passes=2, research="nearby")
+    print(f"local re-search vs oracle: {frames_equal}/{B} frames with identical message lists; second-pass messages: local {n_local}, full {n_full}")
+
+
 def test_special_message_types_through_the_pipeline(H, ocfg):
     """Frames carrying i3 = 4 / hashed / suffixed / directed-CQ messages (words from the reference-generated message golden):
     every record, event and rendered message equals the oracle's, and the special forms do come out."""

@@ -34,6 +34,15 @@ def main():
         true = sum(len(got[f] & want[f]) for f in range(n)) / n
         false = sum(len(got[f] - want[f]) for f in range(n)) / n
         print(f"{passes:6d} {true:19.2f} {false:12.2f} {dt:12.3f}" + ("" if osd else "   (no OSD decodes accepted in passes > 1)"))
+      # the reference experiment's local re-search (receiver_sub.py:434-445), batched: columns f0 - 2 .. f0 + 1 of the subtracted signals only
+      for osd in (True, False):
+        t0 = time.perf_counter()
+        out = rx.decode_frames(audio, passes=2, sub_pass_osd=osd, research="local")
+        dt = time.perf_counter() - t0
+        got = [{" ".join(d["msg_tuple"]) for d in out[f]} for f in range(n)]
+        true = sum(len(got[f] & want[f]) for f in range(n)) / n
+        false = sum(len(got[f] - want[f]) for f in range(n)) / n
+        print(f"{2:6d} {true:19.2f} {false:12.2f} {dt:12.3f}   (local re-search, sync threshold ignored" + (")" if osd else "; no OSD decodes accepted in pass 2)"))
 
 
 if __name__ == "__main__":
