@@ -53,12 +53,14 @@ VALU_PEAK_TFLOPS = 157.3
 # 41 % of candidates that pass the gate (45 symbols on average): 140 k + 56 x 0.6 k + 8 x (140 k + 7 x 0.6 k) + 160 k + 45 x 0.6 k
 EXEC_FLOP_FINE_CAND = 140e3 + 56 * 0.6e3 + 8 * (140e3 + 7 * 0.6e3) + 160e3 + 45 * 0.6e3
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py, collected by tools/collect_profiles.sh),
-# by frames per launch: B = 256 (config 1) and B = 4096 (config 2 as stated: BP 30 iterations)
-PMC_PROFILES = {256: os.path.join(ROOT, "profiles", "pmc_latest.json"), 4096: os.path.join(ROOT, "profiles", "pmc_config2_latest.json")}
+# by BASELINE configuration (the exact command `bench.py --config N`; config 1 = the default command)
+PMC_PROFILES = {1: os.path.join(ROOT, "profiles", "pmc_latest.json"), 2: os.path.join(ROOT, "profiles", "pmc_config2_latest.json"),
+                3: os.path.join(ROOT, "profiles", "pmc_config3_latest.json"), 4: os.path.join(ROOT, "profiles", "pmc_config4_latest.json")}
 
 
 def pmc_traffic(kernel_stage, B):
-    """HBM bytes per launch of the stage's kernels from the committed PMC profile (collected at B=256), or None."""
+    """HBM bytes per launch of the stage's kernels from the committed PMC profile of this configuration (B = its key in PMC_PROFILES, None
+    for a workload no profile was collected for), or None."""
     names = {"spectrogram": ["k_spectrogram"], "sync": ["k_sync"], "fine": ["k_fine"], "osd": ["k_osd"],
              "cycle_fft": ["k_cyc_a", "k_cyc_b", "k_cyc_c"], "grid_llr": ["k_grid_llr"], "topk": ["k_topk"]}.get(kernel_stage)
     if not names or B not in PMC_PROFILES or not os.path.exists(PMC_PROFILES[B]):
@@ -70,7 +72,7 @@ def pmc_traffic(kernel_stage, B):
 
 
 def per_kernel_hbm(acc, B):
-    """Measured HBM GB/s of every stage that has PMC traffic on file (B = 256 only): bytes per launch / HIP-event duration."""
+    """Measured HBM GB/s of every stage that has PMC traffic on file for this configuration: bytes per launch / HIP-event duration."""
     if B not in PMC_PROFILES or not os.path.exists(PMC_PROFILES[B]):
         return None
     prof = json.load(open(PMC_PROFILES[B]))
@@ -309,6 +311,10 @@ def main():
         else:
             dist.init_process_group(args.backend, timeout=tmo)
     B = args.frames
+    # which committed PMC profile describes this workload: the BASELINE configuration asked for, or config 1 for the plain default command
+    default_workload = (args.frames, args.signals, tuple(args.snr), args.bp_iters, args.osd, args.osd3, args.osd_max_hd) == (256, 50, (-10.0, 10.0), None, None, None, None)
+    knob_flags = {"--frames", "--signals", "--snr", "--bp-iters", "--osd", "--osd3", "--osd-max-hd"}
+    pmc_key = (args.config if not (knob_flags & explicit) else None) if args.config is not None else (1 if default_workload else None)
     cfg = _lib.default_config()
     if args.bp_iters is not None:
         cfg.bp_iters_b = args.bp_iters
@@ -499,13 +505,13 @@ def main():
                        "host_pointer_sync_entry_frames_per_s_pageable": pcie, "host_pointer_sync_entry_frames_per_s_pinned": pcie_sync,
                        "host_pointer_pipelined_entry_frames_per_s_pinned": pcie_pinned, "parallelism": f"frames sharded over {world} GPU(s), no collective on the decode path", "gather": gather_note},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
-                         "traffic_source": f"profiles/{os.path.basename(PMC_PROFILES[B])} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of this "
-                                           f"command at B = {B}, collected by tools/collect_profiles.sh; not measured in this run)" if pmc_traffic(dom, B) is not None else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, pmc_key),
+                         "traffic_source": f"profiles/{os.path.basename(PMC_PROFILES[pmc_key])} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of "
+                                           f"`bench.py --config {pmc_key}` at B = {B}, collected by tools/collect_profiles.sh; not measured in this run)" if pmc_traffic(dom, pmc_key) is not None else None,
                          "kernel_ms": dom_ms, "alg_bytes_per_launch": ALG_BYTES[dom] * B,
                          "whole_path_frac": value / world * ALG_BYTES_FRAME / 1e9 / HBM_PEAK_GBS,
                          # measured HBM rate of each stage (PMC bytes / event time): the memory-bound stages sit near the roofline
-                         "per_stage_measured_hbm": per_kernel_hbm(acc, B),
+                         "per_stage_measured_hbm": per_kernel_hbm(acc, pmc_key),
                          # secondary figure SURVEY.md 8d asks for: the path is VALU/LDS/latency bound, not HBM bound
                          "valu": None if (args.signals, tuple(args.snr)) != (50, (-10.0, 10.0)) else {"unit": "TFLOP/s", "peak": VALU_PEAK_TFLOPS,
                                   "whole_path_achieved": value / world * ALG_FLOP_FRAME / 1e12,

@@ -37,6 +37,17 @@ W=$(find "$OUT/${TAG}_c2_pmcW" -name '*counter_collection.csv' | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_c2_pmc.json" "$OUT/${TAG}_pmc_b4096_config2.txt" > /dev/null
 timeout 900 $B2 > "$OUT/${TAG}_bench_b4096_config2_bp30.json" 2>> "$OUT/${TAG}_big.err"
 
+# PMC traffic of configs 3 and 4 (bench.py --config 3 / 4 fill roofline.traffic from these)
+for C in 3 4; do
+  BC="python3 bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0"
+  rm -rf "$OUT/${TAG}_c${C}_pmcF" "$OUT/${TAG}_c${C}_pmcW"
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_c${C}_pmcF" -o f -- $BC > "$OUT/${TAG}_c${C}_pmcF.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_c${C}_pmcW" -o w -- $BC > "$OUT/${TAG}_c${C}_pmcW.log" 2>&1
+  F=$(find "$OUT/${TAG}_c${C}_pmcF" -name '*counter_collection.csv' | head -1)
+  W=$(find "$OUT/${TAG}_c${C}_pmcW" -name '*counter_collection.csv' | head -1)
+  [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_c${C}_pmc.json" "$OUT/${TAG}_pmc_config${C}.txt" > /dev/null
+done
+
 # other BASELINE configurations (single GPU): config 2 (B = 4096; reference knobs and extension knobs), the config-3 shard
 # size (8192 frames per GPU) and config 4 (low SNR, few signals, truth-based decode probability)
 timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b4096_ref_knobs.json" 2> "$OUT/${TAG}_big.err"
