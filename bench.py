@@ -10,8 +10,12 @@ One "step" = one pass of the whole receive hot path (spectrogram -> Costas sync 
 fine sync -> LDPC BP -> OSD -> records -> D2H -> host message layer: every message tuple rendered) over one
 batch of B synthetic 15-s frames per GPU (BASELINE config 1: 50 signals/frame, -10..+10 dB).  The audio is
 resident in HBM before the timed region; the host work of batch k-1 overlaps the GPU work of batch k.
-Frames are independent, so ranks shard them with no data-path collective (weak scaling); the decoded
-records are gathered to rank 0 over RCCL once, outside the timed region, to validate the gather path.
+Frames are independent, so ranks shard them with no collective on the decode path (weak scaling).  With more
+than one rank (or --force-gather) every batch's PACKED results -- the decoded / event-logging candidates' records
+and the used event log, ~4 KB per frame -- are gathered to rank 0 over RCCL INSIDE the timed steps, on a side
+stream that overlaps the next batch (pyft8_amd/distributed.py: PackedGather); `value` includes it.
+At N = 1 the default command then also runs BASELINE configs 2, 3 (one rank's shard) and 4 (per GPU) for a few steps
+each and nests them under "other_configs" (outside `value`).
 Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement" for the roofline accounting).
 """
 import argparse
@@ -222,12 +226,72 @@ def place_rank(local_rank, world, bus_id_of):
     return info
 
 
+OTHER_CONFIGS = {      # BASELINE.json configs 2-4 per GPU, as `--config N` runs them; steps chosen so that the un-overlapped last fetch weighs < 2 %
+    2: dict(frames=4096, signals=50, snr=(-10.0, 10.0), knobs=dict(bp_iters_b=30, osd_single=30, osd_double=2), steps=4,
+            what="4096 frames, LDPC BP 30 iterations + OSD depth 2"),
+    3: dict(frames=8192, signals=50, snr=(-10.0, 10.0), knobs={}, steps=3, what="one rank's 8192-frame shard of the 65 536-frame job, Receiver defaults"),
+    4: dict(frames=2048, signals=10, snr=(-24.0, -20.0), knobs=dict(osd_triple=30, osd_max_hd=32), steps=24,
+            what="2048 frames per GPU, 10 signals at -24..-20 dB, OSD order 3 over 30 positions with the distance gate at 32"),
+}
+
+
+def run_other_config(n, device, rank, pk_threads, streams):
+    """A short run of BASELINE config n on this GPU, measured like the headline: pipelined steps to rendered messages, then per-stage
+    HIP-event times of whole-batch launches.  -> the dict nested under other_configs[n]."""
+    import torch
+    from pyft8_amd import _lib
+    c = OTHER_CONFIGS[n]
+    B = c["frames"]
+    cfg = _lib.default_config(**c["knobs"])
+    t_setup = time.perf_counter()
+    h = _lib.Handle(cfg=cfg, device=device, max_frames=B)
+    try:
+        h.set_streams(streams)
+        d_audio = torch.empty((B, _lib.NSAMP), dtype=torch.int16, device="cuda")
+        h.synth_frames(d_audio.data_ptr(), rank * 1000000, B, n_signals=c["signals"], snr_range=c["snr"])
+        setup_s = time.perf_counter() - t_setup
+
+        def steps(k):
+            for i in range(k):
+                h.enqueue(d_audio.data_ptr(), B)
+                if i > 0:
+                    _lib.package_batch(*h.fetch_view(B), n_threads=pk_threads)
+            return _lib.package_batch(*h.fetch_view(B), n_threads=pk_threads)
+        steps(1)
+        h.sync()
+        t0 = time.perf_counter()
+        msgs, mcnt = steps(c["steps"])
+        h.sync()
+        dt = time.perf_counter() - t0
+        h.set_profiling(True)
+        samples = {}
+        for _ in range(3):
+            h.enqueue(d_audio.data_ptr(), B)
+            h.sync()
+            for k, v in h.stage_times().items():
+                samples.setdefault(k, []).append(v)
+        h.set_profiling(False)
+        acc = {k: float(np.median(v)) for k, v in samples.items()}
+        dom = max(acc, key=acc.get)
+        achieved = ALG_BYTES[dom] * B / (acc[dom] * 1e-3) / 1e9
+        return {"workload": c["what"], "value": B * c["steps"] / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / c["steps"], "steps": c["steps"],
+                "frames_per_gpu": B, "messages_per_frame": float(mcnt.mean()), "stage_ms": {k: round(v, 4) for k, v in acc.items()},
+                "kernels_only_frames_per_s": B / (sum(acc.values()) * 1e-3),
+                "roofline": {"kernel": dom, "kernel_ms": acc[dom], "achieved": achieved, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "traffic": pmc_traffic(dom, n), "whole_path_frac": B * c["steps"] / dt * ALG_BYTES_FRAME / 1e9 / HBM_PEAK_GBS},
+                "setup_s": round(setup_s, 2)}
+    finally:
+        h.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100 = 0.5 s of config 1: the un-overlapped fetch + host layer of the LAST step, 1.3 ms, then weighs 0.3 % instead of 1.3 % at 20)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 1: 256)")
+    ap.add_argument("--total-frames", type=int, default=None, help="N > 1: shard THIS many frames per step over the ranks (contiguous blocks, "
+                    "pyft8_amd.distributed.shard: the first total %% N ranks get one more) instead of --frames per GPU -- an uneven split for flow tests")
     ap.add_argument("--unique", type=int, default=64, help="(host generator only) distinct frames generated per rank, tiled to --frames")
     ap.add_argument("--host-synth", action="store_true", help="generate frames with the numpy generator instead of the device kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,6 +300,13 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for flow tests on one GPU)")
     ap.add_argument("--force-gather", action="store_true", help="run the gather collectives even with one rank (a one-rank process group is "
                     "initialised): the RCCL device path on a one-GPU box")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the per-step gather of the packed results to rank 0 out (A/B of its cost)")
+    ap.add_argument("--gather-repeat", type=int, default=1, help="measurement aid: gather every batch this many times (rank 0's receive + D2H load "
+                    "of that many ranks in a one-rank group)")
+    ap.add_argument("--render-gathered", action="store_true", help="rank 0 also renders the messages of ALL gathered frames inside the timed steps "
+                    "(by default every rank renders its own shard and rank 0 keeps the packed form of the others)")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1 default command: skip the short runs of BASELINE configs 2-4")
+    ap.add_argument("--other-configs", action="store_true", help="run the short config 2-4 passes even for a non-default workload")
     ap.add_argument("--no-pin", action="store_true", help="leave the rank's CPU affinity alone")
     ap.add_argument("--share-gpu", action="store_true", help="flow tests on a box with fewer GPUs than ranks: rank r uses device r %% device_count "
                     "(gloo always does this; RCCL itself refuses two ranks on one device)")
@@ -311,6 +382,14 @@ def main():
         else:
             dist.init_process_group(args.backend, timeout=tmo)
     B = args.frames
+    shard_counts, frame0 = [args.frames] * world, rank * 1000000          # frames per rank and step; index of this rank's first synthetic frame
+    if args.total_frames is not None:
+        from pyft8_amd.distributed import shard
+        shard_counts = [shard(args.total_frames, r, world)[1] for r in range(world)]
+        frame0, B = shard(args.total_frames, rank, world)
+        if min(shard_counts) < 8:
+            raise SystemExit(f"bench.py: --total-frames {args.total_frames} leaves a rank fewer than 8 frames")
+    job_frames = sum(shard_counts)                                           # frames of the whole job per step
     # which committed PMC profile describes this workload: the BASELINE configuration asked for, or config 1 for the plain default command
     default_workload = (args.frames, args.signals, tuple(args.snr), args.bp_iters, args.osd, args.osd3, args.osd_max_hd) == (256, 50, (-10.0, 10.0), None, None, None, None)
     knob_flags = {"--frames", "--signals", "--snr", "--bp-iters", "--osd", "--osd3", "--osd-max-hd"}
@@ -331,7 +410,7 @@ def main():
     h.set_streams(args.streams)
     if args.host_synth:
         uniq = min(args.unique, B)
-        frames = make_frames(rank * 1000000, uniq, args.signals, tuple(args.snr))
+        frames = make_frames(frame0, uniq, args.signals, tuple(args.snr))
         reps = (B + uniq - 1) // uniq
         d_audio = torch.from_numpy(np.concatenate([frames] * reps)[:B]).cuda()
         data_desc = f"{uniq} distinct numpy-generated frames tiled to {B}"
@@ -339,7 +418,7 @@ def main():
         # B distinct frames per rank, generated on the GPU (k_synth: GFSK + Philox noise), config-1 recipe
         uniq = B
         d_audio = torch.empty((B, _lib.NSAMP), dtype=torch.int16, device="cuda")
-        h.synth_frames(d_audio.data_ptr(), rank * 1000000, B, n_signals=args.signals, snr_range=tuple(args.snr))
+        h.synth_frames(d_audio.data_ptr(), frame0, B, n_signals=args.signals, snr_range=tuple(args.snr))
         frames = d_audio[:min(B, 192)].cpu().numpy()  # CPU-baseline sample (bounded by cpu_baseline's 15-s budget)
         data_desc = f"{B} distinct device-generated frames"
     torch.cuda.synchronize()
@@ -355,13 +434,34 @@ def main():
     cores = len(os.sched_getaffinity(0))                   # this rank's slice after place_rank
     pk_threads = max(2, min(32, cores if not args.no_pin else cores // max(1, world)))
 
+    # The gather (BASELINE config 3 "RCCL gather of decoded messages"): with more than one rank every batch's packed results go to
+    # rank 0 inside the step -- submit() after the fetch of batch k-1, while batch k computes; the last one is drained before the
+    # clock stops.  Every rank renders the messages of its own shard (the host layer scales with the ranks); rank 0 holds the
+    # packed form of all shards and can render any frame from it (--render-gathered does, for all of them, inside the step).
+    gather = None
+    if (world > 1 or args.force_gather) and not args.no_gather:
+        from pyft8_amd.distributed import PackedGather
+        gather = PackedGather(h, max(shard_counts), dst=0, force=args.force_gather, repeat=args.gather_repeat)
+    rendered = [0]
+
+    def host_side(view):
+        if gather is not None:
+            gather.submit()
+            if args.render_gathered and rank == 0:
+                parts = gather.collect() if len(gather.pending) > 1 else None      # the batch before: its gather has landed
+                for pk in parts or []:
+                    rendered[0] += int(_lib.package_packed(pk, n_threads=pk_threads)[1].sum())
+        return _lib.package_batch(*view, n_threads=pk_threads)
+
     def run_steps(n):
-        msgs = None
         for i in range(n):
             h.enqueue(d_audio.data_ptr(), B)
             if i > 0:
-                msgs = _lib.package_batch(*h.fetch_view(B), n_threads=pk_threads)
-        return _lib.package_batch(*h.fetch_view(B), n_threads=pk_threads)
+                host_side(h.fetch_view(B))
+        out = host_side(h.fetch_view(B))
+        if gather is not None:
+            gather.drain()                  # the last batch's results have reached rank 0's host memory
+        return out
 
     if args.warmup:
         run_steps(args.warmup)
@@ -449,35 +549,78 @@ def main():
     n_fine = int((valid & ~(((rec["status"] == 1) & (rec["ipass"] < 2)) | (rec["status"] == 2))).sum())
     n_msgs = sum(len(messages.package_frame(rec[f], int(cnt[f]), ev[f], int(evc[f]))) for f in range(min(B, 16)))
 
-    # gather path (RCCL): per-rank fixed-capacity record blocks to rank 0 -- off the timed path
-    gather_note = "single rank"
-    gather_ms = None
-    if world > 1 or args.force_gather:
-        from pyft8_amd.distributed import gather_results, gather_results_device
+    # the gather ran inside the timed steps; here (outside) rank 0 checks what arrived: one packed part per rank, rank 0's own part
+    # against its local results (decoded set byte for byte, messages rendered from the packed form = from the dense arrays)
+    gather_note = "single rank: nothing to gather" if not args.no_gather else "gather left out (--no-gather)"
+    gather_info = None
+    if gather is not None:
         try:
-            gather_ms = []
-            for _ in range(2):                       # first call: communicator set-up included; second: the steady-state cost
-                barrier()
-                t3 = time.perf_counter()
-                if args.backend == "nccl":           # device-resident: D2D into torch buffers, RCCL gather over xGMI, one D2H on rank 0
-                    allres = gather_results_device(h, B, dst=0, force=args.force_gather)
-                else:
-                    allres = gather_results(rec, cnt, ev, evc, dst=0, force=args.force_gather)
-                torch.cuda.synchronize()
-                gather_ms.append(1e3 * (time.perf_counter() - t3))
-            gather_note = (f"records/events of {world} rank{'s' if world > 1 else ' (forced)'} gathered to rank 0 over {args.backend}"
-                           f"{' (device-resident buffers)' if args.backend == 'nccl' else ''} in {gather_ms[-1]:.1f} ms "
-                           f"(first call {gather_ms[0]:.1f} ms)")
+            h.enqueue(d_audio.data_ptr(), B)
+            view = h.fetch_view(B)
+            t3 = time.perf_counter()
+            gather.submit()
+            parts = gather.drain()
+            sync_ms = 1e3 * (time.perf_counter() - t3)       # one un-overlapped gather, submit to landed
+            # frame identity across the job: every rank's per-frame digest of its decoded records, against the gathered parts in rank order
+            import zlib
+
+            def digests(recs_of_frame, n):
+                out = []
+                for f in range(n):
+                    r = recs_of_frame(f)
+                    d = r[r["status"] == _lib.ST_DECODED]
+                    out.append(zlib.crc32(np.ascontiguousarray(d[["msg_lo", "msg_hi", "f0_idx", "h0_idx"]]).tobytes()))
+                return out
+            mine = digests(lambda f: view[0][f, :view[1][f]], B)
+            every = [mine]
+            if world > 1:
+                every = [None] * world
+                dist.all_gather_object(every, mine)
+            sub = np.array(gather.seconds[args.warmup + 1:] or gather.seconds)
+            gather_info = {"submit_ms_per_step": round(1e3 * float(sub.mean()), 4), "submit_ms_max": round(1e3 * float(sub.max()), 4),
+                           "unoverlapped_ms": round(sync_ms, 3), "repeat": args.gather_repeat, "rendered_on_rank0": bool(args.render_gathered)}
             if rank == 0:
-                # (the gathered batch is a later decode of the same audio: records are deterministic, the order of a frame's log is not)
-                same_ev = all(sorted(allres[2][f, :min(int(evc[f]), ev.shape[1])].tolist()) == sorted(ev[f, :min(int(evc[f]), ev.shape[1])].tolist())
-                              for f in range(min(B, 64)))
-                if not (np.array_equal(allres[1][:B], cnt) and allres[0][:B].tobytes() == rec.tobytes() and np.array_equal(allres[3][:B], evc) and same_ev):
-                    gather_note = "gather mismatch: rank 0's own block differs from its local results"
-            if rank == 0 and allres[0].shape[0] != world * B:
-                gather_note = f"gather returned {allres[0].shape[0]} frames, expected {world * B}"
-        except Exception as e:                    # the gather is validation outside the timed region: report, do not lose the line
-            gather_note = f"gather failed: {type(e).__name__}: {e}"
+                assert len(parts) == world * args.gather_repeat, f"{len(parts)} parts from {world} ranks"
+                total = sum(p.n_frames for p in parts[:world])
+                assert [p.n_frames for p in parts[:world]] == shard_counts, f"gathered {[p.n_frames for p in parts[:world]]} frames, expected {shard_counts}"
+                order_ok = [digests(lambda f, p=p: p.frame(f)[0], p.n_frames) for p in parts[:world]] == every
+                own = parts[0]
+                gather_info["bytes_per_frame"] = round(sum(p.nbytes for p in parts[:world]) / total, 1)
+                gather_info["records_per_frame"] = round(sum(len(p.records) for p in parts[:world]) / total, 2)
+                r2, c2, e2, ec2 = own.expand()
+                keep = np.zeros(view[0].shape, bool)
+                for f in range(B):
+                    keep[f, own.frame(f)[0]["pad2"]] = True
+                dec = view[0]["status"] == _lib.ST_DECODED
+                ok = (np.array_equal(c2, view[1]) and np.array_equal(ec2, view[3]) and not (dec & ~keep).any()
+                      and r2[keep].tobytes() == view[0][keep].tobytes())
+                m_dense = _lib.package_batch(*view, n_threads=pk_threads)
+                m_packed = _lib.package_packed(own, n_threads=pk_threads)
+                ok = ok and m_dense[0].tobytes() == m_packed[0].tobytes() and np.array_equal(m_dense[1], m_packed[1])
+                gather_note = (f"packed results of {world} rank{'s' if world > 1 else ' (forced)'} gathered to rank 0 over {args.backend} inside every "
+                               f"timed step ({gather_info['bytes_per_frame']:.0f} B/frame; host time in submit {gather_info['submit_ms_per_step']:.3f} ms/step, "
+                               f"one un-overlapped gather {sync_ms:.2f} ms); rank 0's own part "
+                               + ("= its local decoded set and messages" if ok else "DIFFERS from its local results")
+                               + ("; every rank's frames arrived in shard order" if order_ok else "; FRAME ORDER / CONTENT MISMATCH against the ranks' own digests"))
+                gather_info["ok"] = bool(ok and order_ok)
+        except Exception as e:                    # validation outside the timed region: report, do not lose the line
+            gather_note = f"gather check failed: {type(e).__name__}: {e}"
+
+    # the other single-GPU BASELINE configurations, a few steps each, outside `value` (N = 1, default command)
+    other = None
+    if world == 1 and not args.no_other_configs and ((default_workload and args.config is None) or args.other_configs):
+        other = {}
+        if gather is not None:
+            gather.close()
+            gather = None
+        h.close()                                   # HBM and page-locked memory back before the 8192-frame handle
+        del d_audio
+        torch.cuda.empty_cache()
+        for n in (2, 3, 4):
+            try:
+                other[str(n)] = run_other_config(n, local, rank, pk_threads, args.streams)
+            except Exception as e:                    # informational: never lose the line over it
+                other[str(n)] = {"error": f"{type(e).__name__}: {e}"}
 
     placements = [placement]
     if world > 1:
@@ -487,7 +630,7 @@ def main():
         dom = max(acc, key=acc.get)
         dom_ms = acc[dom]
         achieved = ALG_BYTES[dom] * B / (dom_ms * 1e-3) / 1e9
-        value = world * B * args.steps / dt
+        value = job_frames * args.steps / dt
         line = {
             "metric": "FT8 15-s frames decoded/sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -495,7 +638,7 @@ def main():
             # SURVEY 8d defines the metric as H2D + kernels + D2H + host unpack: the same batch handed over as HOST audio (page-locked),
             # this rank only (PCIe inclusive; `value` has the audio resident in HBM as the bench contract asks)
             "value_incl_h2d": pcie_pinned, "value_incl_h2d_sync_call": pcie_sync, "value_incl_h2d_sync_call_pageable": pcie,
-            "extra_steps": extra_steps, "extra_steps_frames_per_s": (world * B * extra_steps / extra_dt) if extra_steps else None,
+            "extra_steps": extra_steps, "extra_steps_frames_per_s": (job_frames * extra_steps / extra_dt) if extra_steps else None,
             "config": {"workload": f"{'config 1: ' if (B, args.signals, reference_knobs) == (256, 50, True) else ''}batch of {B} synthetic 15-s frames "
                                    f"per GPU ({data_desc}), {args.signals} signals/frame, {args.snr[0]:+.0f}..{args.snr[1]:+.0f} dB SNR, "
                                    f"{'Receiver defaults' if reference_knobs else 'extension knobs'} ({knobs})",
@@ -528,17 +671,20 @@ def main():
                                           "fine sync 0.78 G of 18 full IFFTs); the kernels execute fewer (10 pruned IFFTs) and, by the "
                                           "bit-exact arithmetic contract, without FMA contraction"}},
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
+            "other_configs": other,
             # each rank's own clock over the K timed steps (value uses the max), its kernels-only rate, and where it ran
             "per_rank": {"ms_per_step": [round(1e3 * r[0] / args.steps, 4) for r in per_rank_raw],
-                         "frames_per_s": [round(B * args.steps / r[0], 1) for r in per_rank_raw],
+                         "frames_per_s": [round(n * args.steps / r[0], 1) for n, r in zip(shard_counts, per_rank_raw)], "frames": shard_counts,
                          "kernel_only_frames_per_s": [round(r[1], 1) for r in per_rank_raw],
-                         "placement": placements, "gather_ms": gather_ms},
+                         "placement": placements, "gather": gather_info},
         }
         if not args.no_cpu_baseline:
             # the CPU oracle timed on this box's host cores: rank 0 at N = 1 only (the contract); null in multi-GPU runs
             os.sched_setaffinity(0, orig_affinity)      # the CPU baseline may use every host core, not this rank's slice
             line["cpu_baseline"] = cpu_baseline(frames) if world == 1 else None
         print(json.dumps(line))
+    if gather is not None:
+        gather.close()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

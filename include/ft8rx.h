@@ -97,6 +97,7 @@ typedef struct {
 } ft8rx_message;
 
 typedef struct ft8rx_handle ft8rx_handle;
+typedef struct ft8rx_hashes ft8rx_hashes;                           /* persistent call-hash table, ft8rx_hashes_* below */
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 int  ft8rx_default_config(ft8rx_config* cfg);                       /* Receiver.__init__ defaults */
@@ -153,6 +154,43 @@ int  ft8rx_fetch_results_view(ft8rx_handle* h, int n_frames, const ft8rx_record*
  * these buffers to its collective (RCCL gather over xGMI, pyft8_amd/distributed.py) -- no host round trip.  Any pointer may be NULL. */
 int  ft8rx_results_to_device(ft8rx_handle* h, int n_frames, ft8rx_record* d_records, int32_t* d_counts,
                              ft8rx_event* d_events, int32_t* d_event_counts);
+/* ---- packed results: what a multi-GPU gather moves (the reference has no counterpart) -------------------------
+ * The dense result arrays are [n_frames][max_cands] records + [n_frames][512] events = up to 24 KB per frame, of which the host
+ * message layer reads ~4 KB: the records of the candidates that DECODED or made at least one unpack() call (an event), and the
+ * used part of the event log.  With a packed output set, every enqueued batch ends with three small kernels that write exactly
+ * that, back to back, into the caller's buffer of the batch's result slot:
+ *     ft8rx_packed_header | ft8rx_packed_frame[n_frames] | ft8rx_record[n_records] | ft8rx_event[n_events]
+ * frame f's records are records[rec_off .. rec_off + n_rec) in candidate order, each with pad2 = its candidate index inside the
+ * frame; its events are events[ev_off .. ev_off + min(n_ev, FT8RX_EVENT_CAP)).  ft8rx_package_packed renders the same messages from
+ * this as ft8rx_package_batch does from the dense arrays (the replay only ever looks at those candidates), so a rank sends ~4 KB
+ * per frame to rank 0 instead of 13-24 KB and rank 0 keeps the packed form (pyft8_amd/distributed.py: PackedGather). */
+#define FT8RX_PACKED_MAGIC 0x50385446u      /* "FT8P" */
+typedef struct {
+    uint32_t magic;                  /* FT8RX_PACKED_MAGIC */
+    int32_t  n_frames;
+    int32_t  n_records, n_events;    /* totals over the batch */
+    uint64_t bytes;                  /* header + frame table + records + events */
+    int32_t  max_cands;              /* cfg.max_cands of the producing handle */
+    int32_t  overflow;               /* != 0: `bytes` exceeds the buffer's capacity -- only header and frame table were written */
+} ft8rx_packed_header;               /* 32 bytes */
+typedef struct {
+    int32_t  rec_off, ev_off;        /* first record / event of the frame in the packed runs */
+    uint16_t n_cand;                 /* the frame's candidate count (counts[f] of the dense form) */
+    uint16_t n_rec;                  /* records kept: decoded or with at least one event */
+    int32_t  n_ev;                   /* event_counts[f] of the dense form (may exceed FT8RX_EVENT_CAP: the log overflowed) */
+} ft8rx_packed_frame;                /* 16 bytes */
+/* d_buf0 / d_buf1: one buffer per result slot (batches alternate), cap_bytes each, device memory or page-locked host memory
+ * (ft8rx_alloc_host: the kernels then write straight across PCIe); NULL, NULL turns the packed output off.  Worst case per frame:
+ * 16 + 48 max_cands + 24 x 512 bytes; config 1 frames need ~4 KB.  Applies to batches enqueued afterwards. */
+int  ft8rx_set_packed_output(ft8rx_handle* h, void* d_buf0, void* d_buf1, uint64_t cap_bytes);
+/* The packed output of the batch the last ft8rx_fetch_results / _view / ft8rx_decode_batch call returned (that call has waited for
+ * it): which of the two buffers (0 / 1) and a copy of its header.  -1 if no packed output was set when that batch was enqueued. */
+int  ft8rx_packed_results(ft8rx_handle* h, int32_t* which, ft8rx_packed_header* header);
+/* Host side (no GPU needed): messages of frames [frame_lo, frame_lo + n_frames) of a packed buffer, as ft8rx_package_batch renders
+ * them from the dense arrays (n_threads / table / flags as there); out [n_frames][max_msgs].  Returns -1 for a malformed or
+ * overflowed buffer. */
+int  ft8rx_package_packed(const void* packed, uint64_t bytes, int frame_lo, int n_frames, ft8rx_message* out, int max_msgs,
+                          int32_t* out_counts, int n_threads, ft8rx_hashes* table, int32_t* flags);
 /* per-kernel HIP-event timing of the most recent enqueue (enable before enqueue). names/ms: up to 16 */
 /* number of HIP streams a batch is cut across (1..8, default 2: measured best, profiles/r02_notes.md); profiling mode always uses one */
 int  ft8rx_set_streams(ft8rx_handle* h, int n);
@@ -231,7 +269,6 @@ int  ft8rx_synth_frames_ex(ft8rx_handle* h, uint64_t seed, int first_index, int 
  * flags (optional, [n_frames]): FT8RX_PKG_* bits per frame. */
 #define FT8RX_PKG_MSG_TRUNCATED    1   /* more than max_msgs messages: the list was cut (size max_msgs >= cfg.max_cands to rule it out) */
 #define FT8RX_PKG_EVENTS_TRUNCATED 2   /* event_counts[f] > FT8RX_EVENT_CAP: unpack() calls were dropped, `<...>` strings may differ */
-typedef struct ft8rx_hashes ft8rx_hashes;
 int  ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, const ft8rx_event* events, const int32_t* event_counts,
                          int n_frames, int max_cands, ft8rx_message* out, int max_msgs, int32_t* out_counts, int n_threads,
                          ft8rx_hashes* table, int32_t* flags);

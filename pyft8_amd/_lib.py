@@ -43,6 +43,12 @@ MESSAGE_DTYPE = np.dtype([("f", "S16", (3,)), ("cand", "<i2"), ("f0_idx", "<i2")
                           ("ftweak", "i1"), ("ipass", "u1"), ("ap", "u1"), ("method", "u1"), ("fine", "u1"), ("pad", "u1", (3,))])
 SUBSIG_DTYPE = np.dtype([("fHz", "<f8"), ("tsec", "<f8"), ("tones", "u1", (79,)), ("pad", "u1")])
 assert SUBSIG_DTYPE.itemsize == 96
+# packed results (include/ft8rx.h: ft8rx_packed_header / ft8rx_packed_frame): header | frame table | kept records | used events
+PACKED_MAGIC = 0x50385446
+PACKED_HEADER_DTYPE = np.dtype([("magic", "<u4"), ("n_frames", "<i4"), ("n_records", "<i4"), ("n_events", "<i4"), ("bytes", "<u8"),
+                                ("max_cands", "<i4"), ("overflow", "<i4")])
+PACKED_FRAME_DTYPE = np.dtype([("rec_off", "<i4"), ("ev_off", "<i4"), ("n_cand", "<u2"), ("n_rec", "<u2"), ("n_ev", "<i4")])
+assert PACKED_HEADER_DTYPE.itemsize == 32 and PACKED_FRAME_DTYPE.itemsize == 16
 assert RECORD_DTYPE.itemsize == 48 and EVENT_DTYPE.itemsize == 24 and MESSAGE_DTYPE.itemsize == 64
 
 ST_ACTIVE, ST_DECODED, ST_STOP_GRID_SD, ST_STOP_COSTAS, ST_STOP_FINE_SD, ST_EXHAUSTED = range(6)
@@ -56,49 +62,81 @@ class Ft8rxError(RuntimeError):
     pass
 
 
+def _build_one(path, extra=(), ilp_flags=None, verbose=False):
+    """Two objects (different scheduling strategies), one shared library at `path`.  If the ILP unit does not compile WITH its
+    scheduling flag -- a hidden LLVM option a ROCm update may rename -- it is retried without (results are bit-identical either way,
+    the flag is worth ~3 % on two kernels); objects and stray compiler processes are cleaned up whatever happens."""
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    ilp = list(ILP_FLAGS if ilp_flags is None else ilp_flags)
+    objs = [path[:-3] + ".main.o", path[:-3] + ".ilp.o"]
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    cmds = [["hipcc"] + flags + list(extra) + ["-c", "-o", objs[0], SRC],
+            ["hipcc"] + flags + ilp + list(extra) + ["-c", "-o", objs[1], SRC_ILP]]
+    link = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", path] + objs
+    procs = []
+    try:
+        if verbose:
+            for c in cmds + [link]:
+                print(" ".join(c))
+        procs = [subprocess.Popen(c) for c in cmds]
+        rcs = [p.wait() for p in procs]
+        if rcs[1] != 0 and ilp:
+            import warnings
+            warnings.warn(f"hipcc rejected the ILP unit with {' '.join(ilp)}; building it with the default scheduler", RuntimeWarning)
+            cmds[1] = [a for a in cmds[1] if a not in ilp]
+            rcs[1] = subprocess.call(cmds[1])
+        for c, rc in zip(cmds, rcs):
+            if rc != 0:
+                raise subprocess.CalledProcessError(rc, c)
+        subprocess.check_call(link)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
+    return path
+
+
 def build(force=False, verbose=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): libft8rx.so and libft8rx_wide.so."""
     deps = [os.path.join(os.path.dirname(HERE), "include", "ft8rx.h")]
     for d, _, files in os.walk(os.path.join(HERE, "csrc")):            # ft8rx.hip + ft8_dev.h, ft8_tables.h, kernels/*.hpp, host_messages.hpp
         deps += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".hpp"))]
     newest = max(os.path.getmtime(d) for d in deps)
-    jobs = []
-    for path, extra in ((LIB_PATH, []), (LIB_PATH_WIDE, ["-DFT8RX_WIDE"])):
-        if force or not os.path.exists(path) or os.path.getmtime(path) < newest:
-            # two objects (different scheduling strategies), one shared library
-            flags = [f for f in HIPCC_FLAGS if f != "-shared"]
-            objs = [path[:-3] + ".main.o", path[:-3] + ".ilp.o"]
-            cmds = [["hipcc"] + flags + extra + ["-c", "-o", objs[0], SRC],
-                    ["hipcc"] + flags + ILP_FLAGS + extra + ["-c", "-o", objs[1], SRC_ILP]]
-            link = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", path] + objs
-            if verbose:
-                for c in cmds + [link]:
-                    print(" ".join(c))
-            jobs.append((cmds, [subprocess.Popen(c) for c in cmds], link, objs))
-    for cmds, procs, link, objs in jobs:
-        for c, j in zip(cmds, procs):
-            if j.wait() != 0:
-                raise subprocess.CalledProcessError(j.returncode, c)
-        subprocess.check_call(link)
-        for o in objs:
-            os.remove(o)
+    todo = [(path, extra) for path, extra in ((LIB_PATH, []), (LIB_PATH_WIDE, ["-DFT8RX_WIDE"]))
+            if force or not os.path.exists(path) or os.path.getmtime(path) < newest]
+    if len(todo) == 2:                                       # both variants side by side (four compiler processes)
+        import threading
+        errs = []
+
+        def run(path, extra):
+            try:
+                _build_one(path, extra, verbose=verbose)
+            except Exception as e:
+                errs.append(e)
+        ts = [threading.Thread(target=run, args=t) for t in todo]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+    else:
+        for path, extra in todo:
+            _build_one(path, extra, verbose=verbose)
     return LIB_PATH
 
 
 def build_variant(path, extra=(), ilp_flags=None):
     """An alternative build of the library (same two-unit recipe) at `path`, e.g. build_variant("build/ab/x.so", ["-DFINE_TIMING"]) for
     A/B timing through FT8RX_LIB (tools/ab_full.sh) -- never the product path."""
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
-    objs = [path[:-3] + ".main.o", path[:-3] + ".ilp.o"]
-    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    procs = [subprocess.Popen(["hipcc"] + flags + list(extra) + ["-c", "-o", objs[0], SRC]),
-             subprocess.Popen(["hipcc"] + flags + list(ILP_FLAGS if ilp_flags is None else ilp_flags) + list(extra) + ["-c", "-o", objs[1], SRC_ILP])]
-    if any(p.wait() != 0 for p in procs):
-        raise Ft8rxError(f"build_variant({path}) failed")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", path] + objs)
-    for o in objs:
-        os.remove(o)
-    return path
+    try:
+        return _build_one(path, extra, ilp_flags)
+    except subprocess.CalledProcessError as e:
+        raise Ft8rxError(f"build_variant({path}) failed: {e}")
 
 
 def lib(wide=False):
@@ -284,6 +322,37 @@ class Handle:
         L.ft8rx_results_to_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
         self._chk(L.ft8rx_results_to_device(self._h, int(B), C.c_void_p(d_rec), C.c_void_p(d_cnt), C.c_void_p(d_ev), C.c_void_p(d_evc)),
                   "ft8rx_results_to_device")
+
+    def set_packed_output(self, buf0, buf1, cap_bytes):
+        """ft8rx_set_packed_output: raw pointers (device memory, or page-locked host memory from pinned_bytes()) of the two buffers the
+        following batches write their packed results into (one per result slot); None, None turns it off."""
+        L = self._L
+        L.ft8rx_set_packed_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        self._chk(L.ft8rx_set_packed_output(self._h, C.c_void_p(buf0 or None), C.c_void_p(buf1 or None), C.c_uint64(int(cap_bytes))),
+                  "ft8rx_set_packed_output")
+
+    def packed_results(self):
+        """ft8rx_packed_results: (which of the two packed buffers, its header as a dict) for the batch the last fetch returned."""
+        which = C.c_int32()
+        hdr = np.zeros(1, PACKED_HEADER_DTYPE)
+        L = self._L
+        L.ft8rx_packed_results.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+        self._chk(L.ft8rx_packed_results(self._h, C.byref(which), hdr.ctypes.data), "ft8rx_packed_results")
+        return int(which.value), {k: int(hdr[0][k]) for k in PACKED_HEADER_DTYPE.names}
+
+    def pinned_bytes(self, nbytes):
+        """uint8 array of page-locked host memory (ft8rx_alloc_host), released with the array."""
+        L = self._L
+        L.ft8rx_alloc_host.restype = C.c_void_p
+        L.ft8rx_alloc_host.argtypes = [C.c_void_p, C.c_uint64]
+        L.ft8rx_free_host.argtypes = [C.c_void_p, C.c_void_p]
+        p = L.ft8rx_alloc_host(self._h, int(nbytes))
+        if not p:
+            raise Ft8rxError(f"ft8rx_alloc_host failed: {L.ft8rx_last_error(self._h).decode()}")
+        buf = (C.c_uint8 * int(nbytes)).from_address(p)
+        arr = np.frombuffer(buf, dtype=np.uint8)
+        weakref.finalize(buf, L.ft8rx_free_host, None, C.c_void_p(p))
+        return arr
 
     def set_streams(self, n):
         self._chk(self._L.ft8rx_set_streams(self._h, int(n)), "ft8rx_set_streams")
@@ -591,6 +660,114 @@ def package_batch(rec, cnt, ev, evc, max_msgs=None, n_threads=None, table=None, 
     if rc != 0:
         raise Ft8rxError(f"ft8rx_package_batch failed ({rc})")
     _warn_truncation(flags, "package_batch")
+    return (out, oc, flags) if return_flags else (out, oc)
+
+
+def packed_capacity(n_frames, max_cands=MAX_CANDS, per_frame=None):
+    """Bytes a packed result buffer needs for n_frames frames: the worst case (every candidate kept, full event logs) by default, or
+    per_frame bytes of records + events per frame (config 1 frames use ~4 KB; an overflow is flagged, never silent)."""
+    worst = RECORD_DTYPE.itemsize * int(max_cands) + EVENT_DTYPE.itemsize * EVENT_CAP
+    body = worst if per_frame is None else min(worst, int(per_frame))
+    return PACKED_HEADER_DTYPE.itemsize + int(n_frames) * (PACKED_FRAME_DTYPE.itemsize + body)
+
+
+def pack_results(rec, cnt, ev, evc):
+    """Host twin of the k_pack_* kernels: dense result arrays (as returned by fetch / decode_batch) -> one uint8 array in the packed
+    layout of include/ft8rx.h.  Used where results are host arrays already (the gloo gather of tests, tools)."""
+    rec = np.ascontiguousarray(rec)
+    B, mc = rec.shape
+    cnt = np.clip(np.asarray(cnt, np.int64), 0, mc)
+    evc = np.asarray(evc, np.int64)
+    nev = np.clip(evc, 0, EVENT_CAP)
+    keep = np.zeros((B, mc), bool)
+    for f in range(B):
+        n = int(cnt[f])
+        k = rec[f, :n]["status"] == ST_DECODED
+        c = np.asarray(ev[f, :int(nev[f])]["cand"], np.int64)
+        k[c[c < n]] = True
+        if np.isnan(rec[f, :n]["grid_sd"]).any() or np.isnan(rec[f, :n]["fine_sd"]).any():
+            k[:] = True
+        keep[f, :n] = k
+    nrec = keep.sum(1)
+    table = np.zeros(B, PACKED_FRAME_DTYPE)
+    table["rec_off"] = np.concatenate([[0], np.cumsum(nrec)[:-1]]) if B else []
+    table["ev_off"] = np.concatenate([[0], np.cumsum(nev)[:-1]]) if B else []
+    table["n_cand"], table["n_rec"], table["n_ev"] = cnt, nrec, np.maximum(evc, 0)
+    recs = rec[keep].copy()                                   # row-major boolean take: frame order, candidate order inside a frame
+    recs["pad2"] = np.nonzero(keep)[1]
+    evs = np.concatenate([ev[f, :int(nev[f])] for f in range(B)]) if B else np.zeros(0, EVENT_DTYPE)
+    hdr = np.zeros(1, PACKED_HEADER_DTYPE)
+    hdr["magic"], hdr["n_frames"], hdr["n_records"], hdr["n_events"], hdr["max_cands"] = PACKED_MAGIC, B, len(recs), len(evs), mc
+    hdr["bytes"] = hdr.nbytes + table.nbytes + recs.nbytes + evs.nbytes
+    return np.concatenate([hdr.view(np.uint8), table.view(np.uint8), recs.view(np.uint8).reshape(-1), evs.view(np.uint8).reshape(-1)])
+
+
+class Packed:
+    """Read-only view of a packed result buffer (any object with the buffer protocol; nothing is copied): .header, .frames (the
+    frame table), .records, .events, frame(f) -> (records, events) of one frame."""
+
+    def __init__(self, buf):
+        b = np.frombuffer(buf, np.uint8) if not isinstance(buf, np.ndarray) else buf.view(np.uint8).reshape(-1)
+        if b.size < PACKED_HEADER_DTYPE.itemsize:
+            raise Ft8rxError("packed results: buffer shorter than a header")
+        self.header = b[:32].view(PACKED_HEADER_DTYPE)[0]
+        h = self.header
+        if int(h["magic"]) != PACKED_MAGIC:
+            raise Ft8rxError("packed results: bad magic")
+        if int(h["overflow"]):
+            raise Ft8rxError(f"packed results: {int(h['bytes'])} bytes did not fit the buffer handed to set_packed_output")
+        nf, nr, ne = int(h["n_frames"]), int(h["n_records"]), int(h["n_events"])
+        o1 = 32 + 16 * nf
+        o2 = o1 + RECORD_DTYPE.itemsize * nr
+        o3 = o2 + EVENT_DTYPE.itemsize * ne
+        if o3 != int(h["bytes"]) or o3 > b.size:
+            raise Ft8rxError("packed results: inconsistent sizes")
+        self.nbytes = o3
+        self.buf = b[:o3]
+        self.n_frames, self.max_cands = nf, int(h["max_cands"])
+        self.frames = b[32:o1].view(PACKED_FRAME_DTYPE)
+        self.records = b[o1:o2].view(RECORD_DTYPE)
+        self.events = b[o2:o3].view(EVENT_DTYPE)
+
+    def frame(self, f):
+        t = self.frames[f]
+        return (self.records[int(t["rec_off"]):int(t["rec_off"]) + int(t["n_rec"])],
+                self.events[int(t["ev_off"]):int(t["ev_off"]) + min(int(t["n_ev"]), EVENT_CAP)])
+
+    def expand(self):
+        """-> dense (records[B, max_cands], counts[B], events[B, EVENT_CAP], event_counts[B]) with the kept records at their candidate
+        positions; every other record is zero (tests, tools)."""
+        B, mc = self.n_frames, self.max_cands
+        rec = np.zeros((B, mc), RECORD_DTYPE)
+        ev = np.zeros((B, EVENT_CAP), EVENT_DTYPE)
+        for f in range(B):
+            r, e = self.frame(f)
+            idx = r["pad2"].astype(np.int64)
+            rr = r.copy()
+            rr["pad2"] = 0
+            rec[f, idx] = rr
+            ev[f, :len(e)] = e
+        return rec, self.frames["n_cand"].astype(np.int32), ev, self.frames["n_ev"].astype(np.int32)
+
+
+def package_packed(buf, frame_lo=0, n_frames=None, max_msgs=None, n_threads=None, table=None, return_flags=False):
+    """ft8rx_package_packed (host only): the messages of frames [frame_lo, frame_lo + n_frames) of a packed result buffer, as
+    package_batch renders them from the dense arrays."""
+    pk = buf if isinstance(buf, Packed) else Packed(buf)
+    n = pk.n_frames - frame_lo if n_frames is None else int(n_frames)
+    if max_msgs is None:
+        max_msgs = max(pk.max_cands, 1)
+    out = np.zeros((max(n, 0), max_msgs), MESSAGE_DTYPE)
+    oc = np.zeros(max(n, 0), np.int32)
+    flags = np.zeros(max(n, 0), np.int32)
+    if n > 0:
+        L = lib()
+        L.ft8rx_package_packed.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        rc = L.ft8rx_package_packed(pk.buf.ctypes.data, C.c_uint64(pk.nbytes), int(frame_lo), n, out.ctypes.data, int(max_msgs), oc.ctypes.data,
+                                    int(n_threads or min(32, os.cpu_count() or 1)), table._t if table is not None else None, flags.ctypes.data)
+        if rc != 0:
+            raise Ft8rxError(f"ft8rx_package_packed failed ({rc})")
+        _warn_truncation(flags, "package_packed")
     return (out, oc, flags) if return_flags else (out, oc)
 
 

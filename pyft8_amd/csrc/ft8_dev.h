@@ -270,6 +270,9 @@ FT8_DEV void sym32_quad(cpx* x, int n2, const cpx* wq, float* mag) {
     }
 }
 
+// Everything below reads tables that ft8rx_create fills at run time in the MAIN translation unit (hipMemcpyToSymbol); the second
+// unit (ft8rx_ilp.hip: the FFT kernels, FT8RX_ILP_UNIT) would get zero-filled copies of its own, so it does not see them at all.
+#ifndef FT8RX_ILP_UNIT
 // ------------------------------------------------------------------------------------ CRC-14 and message validity
 // CRC-14 (poly 0x2757, zero init, 77 message bits followed by 19 zero bits; reference decoders.py:123-129) is
 // linear over GF(2): crc(m) = XOR of the syndromes of the set bits.  d_CRC_SYN[pos] = crc of the message with
@@ -405,3 +408,4 @@ FT8_DEV int ft8_crc_check_wave(uint64_t b0, uint64_t b1, int lane, uint64_t* lo,
     if (*lo == 0 && *hi == 0) return 0;
     return ft8_valid77(*lo, *hi) ? 2 : 1;
 }
+#endif  // FT8RX_ILP_UNIT

@@ -117,6 +117,10 @@ struct ft8rx_handle {
     // [frame][cap] rows (fetch_events)
     bool slot_evpending[2];
     int32_t* d_evoffs[2]; ft8rx_event* h_evpacked[2]; ft8rx_event* d_evpacked[2];
+    // packed results (ft8rx_set_packed_output): the caller's buffers (as device addresses), one per result slot, the scratch of the
+    // pack kernels and a page-locked mirror of each slot's header
+    unsigned char* pk_buf[2]; uint64_t pk_cap; uint64_t* d_pkneed; int32_t* d_pknrec;
+    ft8rx_packed_header* h_pkhdr[2]; ft8rx_packed_header* d_pkhdr[2]; bool slot_packed[2]; int fetched_slot;
     // signal subtraction (extension, allocated on first use): float32 working copy, per-chunk partial sums, GFSK tables
     float* d_wf; double2* d_part; double* d_pulse; double* d_pc; ft8rx_subsig* d_sigs; int32_t* d_sigcnt; int sig_cap;
     float2 *d_zdec, *d_model, *d_adec; SubdCtx* d_subctx;      // decimated-baseband refinement (refine = 2), allocated on first use
@@ -187,10 +191,10 @@ struct Scratch {
 // handle's shared workspaces from the main stream; while the chunk streams run free (launch_batch) their work is not ordered
 // against the main stream, so such calls first wait until the batches in flight are complete.
 static int quiesce(ft8rx_handle* h) {
-    if (h->free_running) {
-        HIPCHK(h, hipStreamSynchronize(h->copy_s));           // the result copy of the last batch waits for every chunk stream
-        h->free_running = false;
-    }
+    // the result copy of the last batch waits for every chunk stream (free-running batches) and still reads the slot's device
+    // buffers on the copy stream after a plain one -- either way nothing of a batch is pending once the copy stream is idle
+    if (h->free_running || h->last_slot >= 0) HIPCHK(h, hipStreamSynchronize(h->copy_s));
+    h->free_running = false;
     h->need_barrier = true;
     return 0;
 }
@@ -251,6 +255,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
         if (h->h_ev[k]) hipHostFree(h->h_ev[k]);
         if (h->h_evc[k]) hipHostFree(h->h_evc[k]);
         if (h->h_evpacked[k]) hipHostFree(h->h_evpacked[k]);
+        if (h->h_pkhdr[k]) hipHostFree(h->h_pkhdr[k]);
     }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -277,6 +282,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     h->free_running = false; h->need_barrier = true; h->part_B = h->part_n = 0;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
     h->d_colmask = nullptr; h->use_mask = false;
+    h->pk_buf[0] = h->pk_buf[1] = nullptr; h->pk_cap = 0; h->d_pkneed = nullptr; h->d_pknrec = nullptr; h->fetched_slot = -1;
+    for (int k = 0; k < 2; k++) { h->h_pkhdr[k] = nullptr; h->d_pkhdr[k] = nullptr; h->slot_packed[k] = false; }
     h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr; h->d_ones = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
@@ -609,6 +616,12 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
         k_ev_scan<<<1, 1024, 0, fin>>>(h->s_evcount[slot], B, h->d_evoffs[slot]);
         k_ev_compact<<<B, 64, 0, fin>>>(h->s_ev[slot], h->s_evcount[slot], h->d_evoffs[slot], h->d_evpacked[slot]);
     }
+    h->slot_packed[slot] = h->pk_buf[slot] != nullptr;
+    if (h->slot_packed[slot]) {                              // packed results for a gather: header | frame table | kept records | used events
+        k_pack_count<<<B, 256, 0, fin>>>(h->s_rec[slot], h->s_ncand[slot], h->s_ev[slot], h->s_evcount[slot], h->d_pkneed, h->d_pknrec);
+        k_pack_scan<<<1, 1024, 0, fin>>>(h->d_pknrec, h->s_ncand[slot], h->s_evcount[slot], B, mc, (unsigned long long)h->pk_cap, h->pk_buf[slot], h->d_pkhdr[slot]);
+        k_pack_write<<<B, 256, 0, fin>>>(h->s_rec[slot], h->s_ev[slot], h->d_pkneed, B, h->pk_buf[slot]);
+    }
     HIPCHK(h, hipEventRecord(h->ev_comp[slot], fin));
     if (!free_run) HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_comp[slot], 0));
     HIPCHK(h, hipMemcpyAsync(h->h_cnt[slot], h->s_ncand[slot], sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->copy_s));
@@ -701,6 +714,7 @@ int ft8rx_fetch_results(ft8rx_handle* h, int B, ft8rx_record* records, int32_t* 
         int c = h->h_evc[slot][f]; if (c > FT8RX_EVENT_CAP) c = FT8RX_EVENT_CAP;
         if (c > 0) memcpy(events + (size_t)f * FT8RX_EVENT_CAP, h->h_ev[slot] + (size_t)f * FT8RX_EVENT_CAP, sizeof(ft8rx_event) * (size_t)c);
     }
+    h->fetched_slot = slot;
     if (h->inflight) { h->slot_fetch ^= 1; h->inflight--; }
     return 0;
 }
@@ -718,7 +732,45 @@ int ft8rx_fetch_results_view(ft8rx_handle* h, int B, const ft8rx_record** record
     if (counts) *counts = h->h_cnt[slot];
     if (events) *events = h->h_ev[slot];
     if (event_counts) *event_counts = h->h_evc[slot];
+    h->fetched_slot = slot;
     if (h->inflight) { h->slot_fetch ^= 1; h->inflight--; }
+    return 0;
+}
+
+int ft8rx_set_packed_output(ft8rx_handle* h, void* d_buf0, void* d_buf1, uint64_t cap_bytes) {
+    if (!h) return -1;
+    ENTER(h);                                   // batches in flight keep the buffers they were enqueued with
+    HIPCHK(h, hipStreamSynchronize(h->copy_s));
+    if (!d_buf0 && !d_buf1) { h->pk_buf[0] = h->pk_buf[1] = nullptr; h->pk_cap = 0; return 0; }
+    if (!d_buf0 || !d_buf1 || d_buf0 == d_buf1 || cap_bytes < sizeof(ft8rx_packed_header)) {
+        set_err(h, "ft8rx_set_packed_output: two distinct buffers of at least %zu bytes each are needed", sizeof(ft8rx_packed_header)); return -1; }
+    void* in[2] = {d_buf0, d_buf1};
+    unsigned char* dev[2];
+    for (int k = 0; k < 2; k++) {               // page-locked host memory is addressed through its device pointer
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, in[k]) != hipSuccess) { (void)hipGetLastError(); set_err(h, "ft8rx_set_packed_output: buffer %d is neither device nor page-locked host memory", k); return -1; }
+        dev[k] = (unsigned char*)(at.type == hipMemoryTypeHost ? at.devicePointer : in[k]);
+        if (!dev[k] || ((uintptr_t)dev[k] & 15)) { set_err(h, "ft8rx_set_packed_output: buffer %d is not device-accessible / 16-byte aligned", k); return -1; }
+    }
+    if (!h->d_pkneed) {
+        int rc = dalloc(h, &h->d_pkneed, (size_t)h->max_frames * 4);
+        rc |= dalloc(h, &h->d_pknrec, (size_t)h->max_frames);
+        if (rc) return -2;
+        for (int k = 0; k < 2; k++) {
+            if (hipHostMalloc((void**)&h->h_pkhdr[k], sizeof(ft8rx_packed_header), hipHostMallocDefault) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&h->d_pkhdr[k], h->h_pkhdr[k], 0) != hipSuccess) { set_err(h, "ft8rx_set_packed_output: page-locked header could not be allocated"); return -2; }
+            memset(h->h_pkhdr[k], 0, sizeof(ft8rx_packed_header));
+        }
+    }
+    h->pk_buf[0] = dev[0]; h->pk_buf[1] = dev[1]; h->pk_cap = cap_bytes;
+    return 0;
+}
+
+int ft8rx_packed_results(ft8rx_handle* h, int32_t* which, ft8rx_packed_header* header) {
+    if (!h) return -1;
+    if (h->fetched_slot < 0 || !h->slot_packed[h->fetched_slot]) { set_err(h, "ft8rx_packed_results: the batch fetched last was enqueued without a packed output (ft8rx_set_packed_output)"); return -1; }
+    if (which) *which = h->fetched_slot;
+    if (header) *header = *h->h_pkhdr[h->fetched_slot];
     return 0;
 }
 
@@ -1127,6 +1179,11 @@ int ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, cons
                         ft8rx_hashes* table, int32_t* flags) {
     return hostmsg::package_batch(records, counts, events, event_counts, n_frames, max_cands, out, max_msgs, out_counts, n_threads,
                                   table ? &table->H : nullptr, flags);
+}
+
+int ft8rx_package_packed(const void* packed, uint64_t bytes, int frame_lo, int n_frames, ft8rx_message* out, int max_msgs,
+                         int32_t* out_counts, int n_threads, ft8rx_hashes* table, int32_t* flags) {
+    return hostmsg::package_packed(packed, bytes, frame_lo, n_frames, out, max_msgs, out_counts, n_threads, table ? &table->H : nullptr, flags);
 }
 
 int ft8rx_merge_messages(ft8rx_message* out, int32_t* out_counts, int max_out, const ft8rx_message* add, const int32_t* add_counts,

@@ -4,9 +4,11 @@
 // hipcc's default scheduler and `-mllvm -amdgpu-sched-strategy=iterative-ilp` produce the same arithmetic in a different order; on
 // gfx950 the ILP strategy is 3.9 % faster for k_fine (2.675 -> 2.570 ms per 256 frames) and 3 % for k_spectrogram, but 56 % SLOWER
 // for k_bp (profiles/r03_notes.md) -- and the strategy can only be chosen per translation unit.  So these kernels are built here,
-// from the same headers as ft8rx.hip, and ft8rx.hip launches them through the three functions at the bottom.  Every other kernel
-// the shared headers define is made `static` in this unit (unused; it keeps the two units' symbols apart).  Results are
-// bit-identical either way: the GPU parity suite runs against this build.
+// from the same headers as ft8rx.hip, and ft8rx.hip launches them through the three functions at the bottom.  FT8RX_ILP_UNIT selects
+// this unit's share of the headers: the FFT device code, the three kernels and the plain structs / constant tables they need -- no
+// other kernel and none of the run-time initialised device tables (those live in the main unit only), so every kernel exists exactly
+// once in libft8rx.so.  Results are bit-identical with either scheduler: the GPU parity suite runs against this build.
+#define FT8RX_ILP_UNIT 1
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -17,14 +19,10 @@
 #define MAXC FT8RX_MAX_CANDS
 #define NF0MAX (FT8RX_MAX_F0 > 1024 ? 2048 : 1024)
 
-#undef __global__
-#define __global__ static __attribute__((global))
 #include "kernels/common.hpp"
 #include "kernels/spectrogram.hpp"
 #include "kernels/llr.hpp"
 #include "kernels/fine_sync.hpp"
-#undef __global__
-#define __global__ __attribute__((global))
 #include "ilp_launch.hpp"
 
 void ft8rx_ilp_spectrogram(int n_frames, hipStream_t s, const int16_t* audio, float* grid, const Tables& T) {

@@ -168,9 +168,22 @@ static bool ev_before(const Ev& a, const Ev& b) {          // the reference's ca
     return a.seq < b.seq;
 }
 // -> number of messages written (<= cap).  *flags: FT8RX_PKG_MSG_TRUNCATED if more than cap messages were emitted.
-static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, int nev, ft8rx_message* out, int cap, Hashes& H, int* flags) {
+// sparse = the records of a packed result buffer (include/ft8rx.h): only the candidates that decoded or logged an event, in candidate
+// order, each carrying its candidate index in pad2.  The replay never looks at any other candidate, and a stable sort orders a
+// subset exactly as it orders it inside the full list, so the messages are the ones the dense arrays give.
+static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, int nev, ft8rx_message* out, int cap, Hashes& H, int* flags,
+                         bool sparse = false) {
     std::vector<Ev> E; E.reserve((size_t)nev);
-    for (int i = 0; i < nev; i++) E.push_back({ev[i].cand, ev[i].ipass, ev[i].slot, ev[i].seq, ev[i].msg_lo, ev[i].msg_hi});
+    int16_t pos[FT8RX_MAX_CANDS];
+    if (sparse) {
+        for (int i = 0; i < FT8RX_MAX_CANDS; i++) pos[i] = -1;
+        for (int i = 0; i < n; i++) if (rec[i].pad2 < (uint32_t)FT8RX_MAX_CANDS) pos[rec[i].pad2] = (int16_t)i;
+    }
+    for (int i = 0; i < nev; i++) {
+        int c = ev[i].cand;
+        if (sparse) { c = c < FT8RX_MAX_CANDS ? pos[c] : -1; if (c < 0) continue; }
+        E.push_back({c, ev[i].ipass, ev[i].slot, ev[i].seq, ev[i].msg_lo, ev[i].msg_hi});
+    }
     std::sort(E.begin(), E.end(), ev_before);
     std::vector<int> last(n), order; order.reserve(n);
     for (int i = 0; i < n; i++) {
@@ -211,7 +224,7 @@ static int package_frame(const ft8rx_record* rec, int n, const ft8rx_event* ev, 
             if (nm < cap) {
                 ft8rx_message& o = out[nm]; memset(&o, 0, sizeof(o));
                 for (int k = 0; k < 3; k++) { const size_t L = got[k].size() < 15 ? got[k].size() : 15; memcpy(o.f[k], got[k].data(), L); }      // (o is zeroed: NUL-terminated)
-                o.cand = (int16_t)i; o.f0_idx = r.f0_idx; o.h0_idx = r.h0_idx; o.ipass = r.ipass; o.ap = r.ap; o.method = r.method;
+                o.cand = (int16_t)(sparse ? (int)r.pad2 : i); o.f0_idx = r.f0_idx; o.h0_idx = r.h0_idx; o.ipass = r.ipass; o.ap = r.ap; o.method = r.method;
                 const bool fine = rnd >= 2;
                 o.fine = fine; o.snr = fine ? r.snr_fine : r.snr_grid; o.ttweak = fine ? r.ttweak : 0; o.ftweak = fine ? r.ftweak : 0;
             }
@@ -279,6 +292,46 @@ static int package_batch(const ft8rx_record* records, const int32_t* counts, con
     if (n_threads == 1) { work(0); return 0; }
     std::vector<std::thread> pool;
     for (int t = 0; t < n_threads; t++) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
+    return 0;
+}
+// The same from a packed result buffer (header | frame table | kept records | used events; include/ft8rx.h): frames
+// [frame_lo, frame_lo + n_frames) -> out[n_frames][max_msgs].  Every offset is checked against `bytes` before it is followed.
+static int package_packed(const void* packed, uint64_t bytes, int frame_lo, int n_frames, ft8rx_message* out, int max_msgs,
+                          int32_t* out_counts, int n_threads, Hashes* table, int32_t* flags) {
+    if (!packed || !out || !out_counts || n_frames < 1 || frame_lo < 0 || max_msgs < 1 || bytes < sizeof(ft8rx_packed_header)) return -1;
+    ft8rx_packed_header hd; memcpy(&hd, packed, sizeof(hd));
+    if (hd.magic != FT8RX_PACKED_MAGIC || hd.overflow || hd.bytes > bytes || hd.n_frames < 0 || hd.n_records < 0 || hd.n_events < 0 ||
+        (int64_t)frame_lo + n_frames > hd.n_frames) return -1;
+    if (hd.bytes != sizeof(hd) + (uint64_t)hd.n_frames * sizeof(ft8rx_packed_frame) + (uint64_t)hd.n_records * sizeof(ft8rx_record) +
+                    (uint64_t)hd.n_events * sizeof(ft8rx_event)) return -1;
+    const unsigned char* base = (const unsigned char*)packed;
+    const ft8rx_packed_frame* tab = (const ft8rx_packed_frame*)(base + sizeof(hd));
+    const ft8rx_record* recs = (const ft8rx_record*)(base + sizeof(hd) + (size_t)hd.n_frames * sizeof(ft8rx_packed_frame));
+    const ft8rx_event* evs = (const ft8rx_event*)((const unsigned char*)recs + (size_t)hd.n_records * sizeof(ft8rx_record));
+    for (int f = frame_lo; f < frame_lo + n_frames; f++) {
+        const ft8rx_packed_frame& t = tab[f];
+        const int ne = t.n_ev > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : (t.n_ev < 0 ? 0 : t.n_ev);
+        if (t.rec_off < 0 || t.ev_off < 0 || (int64_t)t.rec_off + t.n_rec > hd.n_records || (int64_t)t.ev_off + ne > hd.n_events ||
+            t.n_rec > FT8RX_MAX_CANDS) return -1;
+    }
+    if (n_threads < 1 || table) n_threads = 1;
+    if (n_threads > n_frames) n_threads = n_frames;
+    auto work = [&](int th) {
+        Hashes local;
+        for (int i = th; i < n_frames; i += n_threads) {
+            const ft8rx_packed_frame& t = tab[frame_lo + i];
+            int fl = 0, nev = t.n_ev < 0 ? 0 : t.n_ev;
+            if (nev > FT8RX_EVENT_CAP) { nev = FT8RX_EVENT_CAP; fl |= FT8RX_PKG_EVENTS_TRUNCATED; }
+            if (!table) local.clear();
+            out_counts[i] = package_frame(recs + t.rec_off, t.n_rec, evs + t.ev_off, nev, out + (size_t)i * max_msgs, max_msgs,
+                                          table ? *table : local, &fl, true);
+            if (flags) flags[i] = fl;
+        }
+    };
+    if (n_threads == 1) { work(0); return 0; }
+    std::vector<std::thread> pool;
+    for (int th = 0; th < n_threads; th++) pool.emplace_back(work, th);
     for (auto& th : pool) th.join();
     return 0;
 }

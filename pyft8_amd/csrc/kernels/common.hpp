@@ -1,5 +1,7 @@
 // common.hpp -- device tables, attempt records, event log shared by all kernels
-// Part of libft8rx.so; included by ft8rx.hip (single translation unit: the kernels share __constant__/__device__ tables).
+// Part of libft8rx.so.  Included by both translation units: ft8rx.hip (everything) and ft8rx_ilp.hip (FT8RX_ILP_UNIT: the FFT kernels,
+// which only need the first part -- the statically initialised constants and the plain structs).  Tables that ft8rx_create fills at
+// run time, and every kernel of this file, exist in the main unit only.
 #ifndef FT8RX_COMMON_HPP
 #define FT8RX_COMMON_HPP
 
@@ -20,6 +22,19 @@ struct Tables {
 __device__ __constant__ int d_COSTAS[7] = {3, 1, 4, 0, 6, 5, 2};
 __device__ __constant__ uint8_t d_PAYSYM[58] = {7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,
     43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71};
+// Work lists of the decode ladder.  Each ladder kernel only has work for the candidates that are still ACTIVE (39 % of the 256 slots
+// per frame for the second BP, 27 % for OSD, a few per cent in sparse low-SNR frames), so instead of one mostly-empty block per slot
+// a thread-per-candidate kernel (k_worklist, k_select0, k_select1) appends the candidates that go on to a compact list and the
+// consumer indexes list x attempts: k_fine and k_osd with a bounded grid whose blocks stride over the items, k_bp with one
+// attempt per block (its attempts are short and very uneven).  Entries are chunk-relative candidate ids (frame * MAXC + ci); the
+// order is whatever the atomics give -- every attempt writes its own result slot and the host sorts the event log, so results do
+// not depend on it.
+struct WorkList { int32_t* items; int32_t* count; };
+enum { WL_BP0 = 0, WL_FINE = 1, WL_BP1 = 2, WL_BP1B = 3, WL_BP1C = 4, WL_OSD = 5, WL_N = 6 };
+
+#define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */
+
+#ifndef FT8RX_ILP_UNIT                           /* ---- main translation unit only from here on ---- */
 // AP masks (reference receiver.py:21-27), copied verbatim as data
 __device__ __constant__ int8_t d_AP_CQ[29]   = {0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0, 0,1,0,0};
 __device__ __constant__ int8_t d_AP_END[3][19] = {{0,1, 1,1,1,1,1, 0,0,1,1,1, 0,1,0,1,0, 0,1},
@@ -45,14 +60,6 @@ struct Att {               // one decode attempt's outcome
     uint8_t pad[2];
 };
 
-// Work lists of the decode ladder.  Each ladder kernel only has work for the candidates that are still ACTIVE (39 % of the 256 slots
-// per frame for the second BP, 27 % for OSD, a few per cent in sparse low-SNR frames), so instead of one mostly-empty block per slot
-// a thread-per-candidate kernel (k_worklist, k_select0, k_select1) appends the candidates that go on to a compact list and the
-// consumer indexes list x attempts: k_fine and k_osd with a bounded grid whose blocks stride over the items, k_bp with one
-// attempt per block (its attempts are short and very uneven).  Entries are chunk-relative candidate ids (frame * MAXC + ci); the
-// order is whatever the atomics give -- every attempt writes its own result slot and the host sorts the event log, so results do
-// not depend on it.
-struct WorkList { int32_t* items; int32_t* count; };
 FT8_DEV void work_push(const WorkList& w, int cand) { if (w.items) w.items[atomicAdd(w.count, 1)] = cand; }
 // Block-aggregated push for thread-per-candidate kernels (256-thread blocks): ONE atomic per block reserves a range -- tens of
 // thousands of atomics on a single counter serialise in L2 (measured: k_grid_llr 0.09 -> 0.61 ms with one atomic per candidate).
@@ -74,10 +81,6 @@ FT8_DEV void work_push_block(const WorkList& w, bool want, int cand) {
         w.items[off] = cand;
     }
 }
-enum { WL_BP0 = 0, WL_FINE = 1, WL_BP1 = 2, WL_BP1B = 3, WL_BP1C = 4, WL_OSD = 5, WL_N = 6 };
-
-#define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */
-
 // grid row accessor with the reference's modulo-750 wrap (receiver.py:240,347,360)
 // (branch-free: an always-valid clamped load, then an integer mask selects the grid's initial 1.0 -- a branch or select around
 // the load would serialise the loads of a gather loop, one memory round trip per basic block)
@@ -136,5 +139,112 @@ __global__ __launch_bounds__(64) void k_ev_compact(const ft8rx_event* __restrict
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + offs[f]);
     for (int i = threadIdx.x; i < c * 6; i += 64) dst[i] = src[i];
 }
+
+// ------------------------------------------------------------------------------------ packed results (multi-GPU gather, include/ft8rx.h)
+// What the host message layer reads of a frame: the records of the candidates that decoded or made at least one unpack() call (an
+// entry in the event log), and the used part of the log.  Three kernels at the end of a batch write exactly that into the caller's
+// buffer: header | frame table | records | events.  k_pack_count (a block per frame) marks the candidates to keep, k_pack_scan (one
+// block) turns the per-frame counts into offsets and the header, k_pack_write (a block per frame) moves the entries.
+// A frame in which any candidate has a NaN llr_sd keeps ALL its candidates: the replay orders candidates by a stable sort on llr_sd
+// (receiver.py:389), and with unordered keys the order of a subset need not be the order inside the full list.
+static_assert(MAXC == 256 && sizeof(ft8rx_record) == 48 && sizeof(ft8rx_event) == 24 && sizeof(ft8rx_packed_frame) == 16 &&
+              sizeof(ft8rx_packed_header) == 32, "packed result layout");
+__global__ __launch_bounds__(256) void k_pack_count(const ft8rx_record* __restrict__ rec, const int32_t* __restrict__ ncand,
+                                                    const ft8rx_event* __restrict__ ev, const int32_t* __restrict__ evcount,
+                                                    uint64_t* __restrict__ need /*[B][4]*/, int32_t* __restrict__ nrec /*[B]*/) {
+    __shared__ uint32_t s_has[8];
+    __shared__ int s_cnt[4], s_nan;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 8) s_has[tid] = 0;
+    if (tid == 0) s_nan = 0;
+    __syncthreads();
+    int c = evcount[f]; c = c > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : (c < 0 ? 0 : c);
+    for (int i = tid; i < c; i += 256) {
+        const unsigned cand = ev[(size_t)f * FT8RX_EVENT_CAP + i].cand;
+        if (cand < (unsigned)MAXC) atomicOr(&s_has[cand >> 5], 1u << (cand & 31));
+    }
+    int n = ncand[f]; n = n > MAXC ? MAXC : (n < 0 ? 0 : n);
+    const ft8rx_record& r = rec[(size_t)f * MAXC + (tid < n ? tid : 0)];
+    const bool decoded = tid < n && r.status == FT8RX_ST_DECODED;
+    if (tid < n && (r.grid_sd != r.grid_sd || r.fine_sd != r.fine_sd)) s_nan = 1;
+    __syncthreads();
+    const bool want = tid < n && (decoded || ((s_has[tid >> 5] >> (tid & 31)) & 1u) || s_nan);
+    const uint64_t m = __ballot(want);
+    if (lane == 0) { need[(size_t)f * 4 + wv] = m; s_cnt[wv] = __popcll(m); }
+    __syncthreads();
+    if (tid == 0) nrec[f] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+// offsets of every frame's records / events in the packed runs, the frame table and the header (also mirrored into page-locked
+// host memory, `hdr_host`, so that the host knows the size without a copy)
+__global__ __launch_bounds__(1024) void k_pack_scan(const int32_t* __restrict__ nrec, const int32_t* __restrict__ ncand,
+                                                    const int32_t* __restrict__ evcount, int B, int max_cands, unsigned long long cap_bytes,
+                                                    unsigned char* __restrict__ buf, ft8rx_packed_header* __restrict__ hdr_host) {
+    __shared__ int s_wr[16], s_we[16];
+    __shared__ int s_cr, s_ce;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    ft8rx_packed_frame* table = reinterpret_cast<ft8rx_packed_frame*>(buf + sizeof(ft8rx_packed_header));
+    const bool table_fits = sizeof(ft8rx_packed_header) + (size_t)B * sizeof(ft8rx_packed_frame) <= cap_bytes;
+    if (tid == 0) { s_cr = 0; s_ce = 0; }
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int f = base + tid;
+        const int r = f < B ? nrec[f] : 0;
+        const int eraw = f < B ? evcount[f] : 0;
+        const int e = eraw > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : (eraw < 0 ? 0 : eraw);
+        int ir = r, ie = e;                                            // inclusive scans inside the wavefront
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int tr = __shfl_up(ir, d), te = __shfl_up(ie, d); if (lane >= d) { ir += tr; ie += te; } }
+        if (lane == 63) { s_wr[wv] = ir; s_we[wv] = ie; }
+        __syncthreads();
+        int br = s_cr, be = s_ce;
+        for (int i = 0; i < wv; i++) { br += s_wr[i]; be += s_we[i]; }
+        if (f < B && table_fits) {
+            ft8rx_packed_frame t;
+            t.rec_off = br + ir - r; t.ev_off = be + ie - e;
+            int n = ncand[f]; n = n > MAXC ? MAXC : (n < 0 ? 0 : n);
+            t.n_cand = (uint16_t)n; t.n_rec = (uint16_t)r; t.n_ev = eraw < 0 ? 0 : eraw;
+            table[f] = t;
+        }
+        __syncthreads();
+        if (tid == 1023) { s_cr = br + ir; s_ce = be + ie; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ft8rx_packed_header hd;
+        hd.magic = FT8RX_PACKED_MAGIC; hd.n_frames = B; hd.n_records = s_cr; hd.n_events = s_ce; hd.max_cands = max_cands;
+        hd.bytes = sizeof(ft8rx_packed_header) + (unsigned long long)B * sizeof(ft8rx_packed_frame) +
+                   (unsigned long long)s_cr * sizeof(ft8rx_record) + (unsigned long long)s_ce * sizeof(ft8rx_event);
+        hd.overflow = hd.bytes > cap_bytes;
+        if (cap_bytes >= sizeof(hd)) *reinterpret_cast<ft8rx_packed_header*>(buf) = hd;
+        *hdr_host = hd;
+    }
+}
+__global__ __launch_bounds__(256) void k_pack_write(const ft8rx_record* __restrict__ rec, const ft8rx_event* __restrict__ ev,
+                                                    const uint64_t* __restrict__ need, int B, unsigned char* __restrict__ buf) {
+    const ft8rx_packed_header hd = *reinterpret_cast<const ft8rx_packed_header*>(buf);
+    if (hd.overflow) return;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const ft8rx_packed_frame t = reinterpret_cast<const ft8rx_packed_frame*>(buf + sizeof(ft8rx_packed_header))[f];
+    unsigned char* recs = buf + sizeof(ft8rx_packed_header) + (size_t)B * sizeof(ft8rx_packed_frame);
+    unsigned char* evs = recs + (size_t)hd.n_records * sizeof(ft8rx_record);
+    const uint64_t m0 = need[(size_t)f * 4], m1 = need[(size_t)f * 4 + 1], m2 = need[(size_t)f * 4 + 2], m3 = need[(size_t)f * 4 + 3];
+    const uint64_t mine = wv == 0 ? m0 : wv == 1 ? m1 : wv == 2 ? m2 : m3;
+    if ((mine >> lane) & 1ull) {
+        int p = __popcll(mine & ((1ull << lane) - 1));
+        if (wv > 0) p += __popcll(m0);
+        if (wv > 1) p += __popcll(m1);
+        if (wv > 2) p += __popcll(m2);
+        const uint4* src = reinterpret_cast<const uint4*>(rec + (size_t)f * MAXC + tid);
+        uint4* dst = reinterpret_cast<uint4*>(recs + ((size_t)t.rec_off + p) * sizeof(ft8rx_record));
+        uint4 a = src[0], b = src[1], c = src[2];
+        c.w = (uint32_t)tid;                                           // pad2 = the candidate's index inside its frame
+        dst[0] = a; dst[1] = b; dst[2] = c;
+    }
+    const int ne = t.n_ev > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : t.n_ev;
+    const uint2* es = reinterpret_cast<const uint2*>(ev + (size_t)f * FT8RX_EVENT_CAP);
+    uint2* ed = reinterpret_cast<uint2*>(evs + (size_t)t.ev_off * sizeof(ft8rx_event));
+    for (int i = tid; i < ne * 3; i += 256) ed[i] = es[i];
+}
+#endif  // FT8RX_ILP_UNIT
 
 #endif

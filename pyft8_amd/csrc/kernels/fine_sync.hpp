@@ -1,5 +1,6 @@
 // fine_sync.hpp -- fine time/frequency sync (receiver.py:140-206)
-// Part of libft8rx.so; included by ft8rx.hip (single translation unit: the kernels share __constant__/__device__ tables).
+// Part of libft8rx.so.  The IFFT stages and the symbol DFT are shared device code (k_refine3 of the main unit uses them); the
+// kernel itself, k_fine, is built in the second translation unit only (ft8rx_ilp.hip, ILP scheduling: FT8RX_ILP_UNIT).
 #ifndef FT8RX_FINE_SYNC_HPP
 #define FT8RX_FINE_SYNC_HPP
 
@@ -241,6 +242,7 @@ FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, const cpx* wq, float* m
     sym32_quad<NT>(x, n2, wq, mag);
 }
 
+#ifdef FT8RX_ILP_UNIT
 FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
                             const int32_t* __restrict__ ncand, float* __restrict__ llr0, const Tables& T, const ft8rx_config& cfg,
                             const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
@@ -437,5 +439,6 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
         __syncthreads();                                            // the LDS images are reused by the next candidate
     }
 }
+#endif  // FT8RX_ILP_UNIT
 
 #endif

@@ -1,5 +1,5 @@
 // llr.hpp -- LLR extraction from the search grid, AP masks (receiver.py:208-222, 109-117)
-// Part of libft8rx.so; included by ft8rx.hip (single translation unit: the kernels share __constant__/__device__ tables).
+// Part of libft8rx.so.  llr_from_p is shared with the second translation unit (k_fine); the rest is the main unit's.
 #ifndef FT8RX_LLR_HPP
 #define FT8RX_LLR_HPP
 
@@ -55,6 +55,7 @@ FT8_DEV void llr_from_p(const float* p, float* llr, float* sq, int lane, bool ac
     *sd_out = sd; *snr_out = snr;
 }
 
+#ifndef FT8RX_ILP_UNIT
 // ------------------------------------------------------------------------------------ AP masks (receiver.py:109-117)
 FT8_DEV float ap_value(int ap, int i, float v) {
     if (ap == 1) {
@@ -176,5 +177,6 @@ __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid,
     if (att0 && !(sd <= cfg.llr_sd_min))        // pipeline: the candidate stays ACTIVE -> pre-check its five ipass-0 attempts
         bp0_precheck(lane, llr, cm, frame, ci, att0 + (size_t)blockIdx.x * 5, ev, evcount, cfg.bp_nc0_a, cfg.bp_iters_a);
 }
+#endif  // FT8RX_ILP_UNIT
 
 #endif

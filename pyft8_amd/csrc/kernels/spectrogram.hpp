@@ -1,5 +1,6 @@
 // spectrogram.hpp -- K1: 375-hop dB spectrogram (receiver.py:288-306)
-// Part of libft8rx.so; included by ft8rx.hip (single translation unit: the kernels share __constant__/__device__ tables).
+// Part of libft8rx.so.  k_spectrogram / k_hop_spectrum are built in the second translation unit only (ft8rx_ilp.hip, ILP scheduling:
+// FT8RX_ILP_UNIT) and launched through ilp_launch.hpp; k_fill_row0 belongs to the main unit.
 #ifndef FT8RX_SPECTROGRAM_HPP
 #define FT8RX_SPECTROGRAM_HPP
 
@@ -11,6 +12,7 @@
 //   [5,3]  128 groups of 15 (one per thread), compile-time twiddles,
 // then the real-FFT split and 20 log10|.|.
 #define SPEC_NT 128
+#ifdef FT8RX_ILP_UNIT
 FT8_DEV void spectrogram_hop(const int16_t* __restrict__ a, int base, float* __restrict__ out, const Tables& T,
                              cpx* z, cpx* w240, int tid) {
     const cpx* __restrict__ W = T.W1920;
@@ -136,9 +138,11 @@ __global__ __launch_bounds__(SPEC_NT) void k_hop_spectrum(const int16_t* __restr
     spectrogram_hop(win3840, 0, row, T, z, w240, threadIdx.x);
 }
 
+#else
 __global__ void k_fill_row0(float* grid, int B) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B * FT8RX_GRID_COLS) grid[(size_t)(i / FT8RX_GRID_COLS) * FT8RX_GRID_ROWS * FT8RX_GRID_COLS + (i % FT8RX_GRID_COLS)] = 1.0f;
 }
+#endif  // FT8RX_ILP_UNIT
 
 #endif

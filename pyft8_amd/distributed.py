@@ -5,7 +5,18 @@ no collective: rank r decodes the contiguous block shard(n, r, world).  The only
 of fixed-capacity record/event blocks to rank 0 (RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for
 tests).  The reference has no counterpart.
 
-Two gather entry points, same result on rank `dst` (the concatenation over ranks in rank order = global frame order for shard()):
+The gather the measured path uses (bench.py, inside the timed step):
+  PackedGather(handle, n_frames)          every batch ends with three small kernels that pack what the host message layer reads of it
+                                          (records of the candidates that decoded or logged an unpack() call + the used event log,
+                                          ~4 KB per config-1 frame instead of 13-24 KB; include/ft8rx.h "packed results") into a
+                                          device buffer; submit() exchanges the byte counts and gathers the packed buffers to rank
+                                          `dst` on a side stream (RCCL over xGMI), where one D2H copy per rank lands them in
+                                          page-locked host memory -- all of it overlapping the next batch's kernels.  Rank `dst`
+                                          keeps the packed form (a view per rank / frame, `_lib.Packed`) and can render any frame's
+                                          messages from it (`_lib.package_packed`).  With gloo (flow tests) the GPU writes the packed
+                                          buffer straight into page-locked host memory and the gather moves host bytes.
+The dense variants (fixed-capacity blocks; kept for tools and as a cross-check, same result on rank `dst` = the concatenation over
+ranks in rank order = global frame order for shard()):
   gather_results(rec, cnt, ev, evc)       host arrays in, through the backend's device (gloo: CPU tensors; nccl: one H2D per rank)
   gather_results_device(handle, n_frames) nccl only: the latest batch's results go device -> device into torch buffers
                                           (ft8rx_results_to_device), RCCL gathers them over xGMI, and rank `dst` makes the single
@@ -81,7 +92,9 @@ def gather_results(rec, cnt, ev, evc, dst=0, group=None, force=False):
 
 
 def gather_results_device(handle, n_frames, dst=0, group=None, force=False):
-    """RCCL gather of the handle's latest batch straight from device memory (backend nccl).  -> like gather_results.
+    """RCCL gather of the handle's latest batch straight from device memory (backend nccl).  -> like gather_results, except that
+    only events[f, :event_counts[f]] is meaningful (columns between a frame's count and the largest count of the job hold stale
+    log entries here and zeros in gather_results).
     force=True runs the whole device path (D2D into torch buffers, RCCL all_gather / gather, one D2H on dst) even in a one-rank
     group: that is how the path is exercised on a one-GPU test box."""
     from . import _lib
@@ -114,3 +127,125 @@ def gather_results_device(handle, n_frames, dst=0, group=None, force=False):
     full[:, :used] = res[2]
     res[2] = full
     return tuple(res)
+
+
+class PackedGather:
+    """Gather of every batch's PACKED results to rank `dst`, overlapped with the next batch (module docstring).
+
+        g = PackedGather(handle, B)                  # all ranks; sets the handle's packed output
+        handle.enqueue(...); view = handle.fetch_view(B)
+        g.submit()                                   # all ranks, after the fetch of that batch: asynchronous from here on
+        ...                                          # (next enqueue / host message layer of this rank's own frames)
+        parts = g.collect()                          # rank dst: [Packed of rank 0, rank 1, ...] of the oldest submitted batch; else None
+
+    At most two gathers are in flight (the handle has two result slots); submit() first completes the one that used the same slot.
+    per_frame: bytes of records + events reserved per frame (default 12 KB; the worst case is 48 max_cands + 12 KB, config-1 frames
+    use ~4 KB); a batch that does not fit raises instead of being cut.  repeat > 1 (measurement aid) gathers every batch `repeat`
+    times into distinct buffers: rank dst's receive + D2H load of `repeat` ranks in a one-rank group."""
+
+    def __init__(self, handle, n_frames, dst=0, group=None, force=False, per_frame=12288, repeat=1):
+        from . import _lib
+        self._lib, self.h, self.B, self.dst, self.group, self.repeat = _lib, handle, int(n_frames), dst, group, max(1, int(repeat))
+        self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.nccl = self.active and dist.get_backend(group) == "nccl"
+        self.cap = (_lib.packed_capacity(self.B, handle.cfg.max_cands, per_frame) + 255) & ~255
+        self.pending = []                  # (slot, sizes, event-or-None) in submit order
+        self.seconds = []                  # host time spent inside submit() per call (the size exchange blocks; the rest is asynchronous)
+        if self.nccl:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self.stream = torch.cuda.Stream(device=dev)
+            self.src = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+            ptrs = [t.data_ptr() for t in self.src]
+            if self.rank == dst:
+                n = self.world * self.repeat
+                self.recv = [torch.empty((n, self.cap), dtype=torch.uint8, device=dev) for _ in range(2)]
+                self.host = [torch.empty((n, self.cap), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        else:
+            # host path (gloo, or no process group at all): the pack kernels write page-locked host memory directly
+            self.stream = None
+            self._pin = [handle.pinned_bytes(self.cap) for _ in range(2)]
+            self.src = [torch.from_numpy(a) for a in self._pin]
+            ptrs = [a.ctypes.data for a in self._pin]
+            if self.active and self.rank == dst:
+                n = self.world * self.repeat
+                self.host = [torch.empty((n, self.cap), dtype=torch.uint8) for _ in range(2)]
+        handle.set_packed_output(ptrs[0], ptrs[1], self.cap)
+
+    def close(self):
+        self.drain()
+        self.h.set_packed_output(None, None, 0)
+
+    def _finish(self, item):
+        slot, sizes, ev = item
+        if ev is not None:
+            ev.synchronize()
+        if not self.active:
+            return [self._lib.Packed(self._pin[slot][:sizes[0]])]
+        if self.rank != self.dst:
+            return None
+        rows = self.host[slot].numpy()
+        return [self._lib.Packed(rows[i][:sizes[i % self.world]]) for i in range(self.world * self.repeat)]
+
+    def submit(self):
+        """Start the gather of the batch the last fetch returned (every rank calls this once per fetched batch, in the same order)."""
+        import time
+        t0 = time.perf_counter()
+        slot, hdr = self.h.packed_results()
+        if hdr["overflow"]:
+            raise self._lib.Ft8rxError(f"PackedGather: a batch needs {hdr['bytes']} packed bytes, the buffers hold {self.cap} (raise per_frame)")
+        while any(p[0] == slot for p in self.pending):          # the gather that last used this slot's buffers
+            self._done = self._finish(self.pending.pop(0))
+        nbytes = int(hdr["bytes"])
+        if not self.active:
+            self.pending.append((slot, [nbytes], None))
+            self.seconds.append(time.perf_counter() - t0)
+            return
+        if self.nccl:
+            with torch.cuda.stream(self.stream):
+                mine = torch.tensor([nbytes], dtype=torch.int64).to(self.src[slot].device, non_blocking=True)
+                allsz = torch.empty(self.world, dtype=torch.int64, device=mine.device)
+                dist.all_gather_into_tensor(allsz, mine, group=self.group)
+                sizes = [int(x) for x in allsz.tolist()]                     # waits for the side stream only
+                m = (max(sizes) + 255) & ~255
+                for rep in range(self.repeat):
+                    out = None
+                    if self.rank == self.dst:
+                        out = [self.recv[slot][rep * self.world + r][:m] for r in range(self.world)]
+                    dist.gather(self.src[slot][:m], out, dst=self.dst, group=self.group)
+                    if self.rank == self.dst:
+                        for r in range(self.world):
+                            i = rep * self.world + r
+                            self.host[slot][i][:sizes[r]].copy_(self.recv[slot][i][:sizes[r]], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+        else:
+            mine = torch.tensor([nbytes], dtype=torch.int64)
+            lst = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(lst, mine, group=self.group)
+            sizes = [int(x.item()) for x in lst]
+            m = max(sizes)
+            for rep in range(self.repeat):
+                out = None
+                if self.rank == self.dst:
+                    out = [self.host[slot][rep * self.world + r][:m] for r in range(self.world)]
+                dist.gather(self.src[slot][:m], out, dst=self.dst, group=self.group)
+            ev = None
+        self.pending.append((slot, sizes, ev))
+        self.seconds.append(time.perf_counter() - t0)
+
+    def collect(self):
+        """Rank dst: the per-rank Packed views of the OLDEST submitted batch not collected yet (valid until two more submits);
+        other ranks: None.  Waits for that gather."""
+        if not self.pending:
+            return getattr(self, "_done", None)
+        return self._finish(self.pending.pop(0))
+
+    def drain(self):
+        """Wait for every gather in flight; -> the last one's result (as collect)."""
+        out = getattr(self, "_done", None)
+        while self.pending:
+            out = self._finish(self.pending.pop(0))
+        self._done = out
+        return out

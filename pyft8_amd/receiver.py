@@ -486,7 +486,20 @@ class Receiver:
         if self._thread is not None and self._thread is not _threading.current_thread():
             self._thread.join(timeout)
         self.audio_in.close(timeout)
+        self.close()
         self._raise_thread_error()
+
+    def close(self):
+        """Release the GPU handles (workspaces, page-locked buffers) of the batch and the live path; a later decode_frames / poll /
+        search re-creates what it needs.  stop() calls this."""
+        with self._hlock:
+            if self._h is not None:
+                self._h.close()
+                self._h = None
+        with self._live_lock:
+            if self._live is not None:
+                self._live.close()
+                self._live = None
 
     def _raise_thread_error(self):
         e, self.thread_error = self.thread_error, None

@@ -258,14 +258,30 @@ def pulse_cumsum():
     return np.concatenate([[0.0], np.cumsum(_PULSE)])
 
 
-def device_signal_table(start, count, n_signals=50, snr_range=(-10.0, 10.0), seed_base=SEED_BASE):
-    """Signal parameters for ft8rx_synth_frames: same recipe as make_frame (messages, f0, t0, SNR drawn from the
-    per-frame Philox stream); the noise itself is generated on the device.  -> (records[count, n_signals], truth)."""
+def _tones79_batch(words):
+    """tones79 for many 77-bit words at once (numpy GF(2) encode; same tones as tones79, which the tests pin to the reference)."""
+    n = len(words)
+    crc = np.array([crc14(w) for w in words], np.uint64)
+    m91 = np.zeros((n, 91), np.uint8)
+    w = np.array([[(x >> (76 - i)) & 1 for i in range(77)] for x in words], np.uint8).reshape(n, 77)
+    m91[:, :77] = w
+    m91[:, 77:] = (crc[:, None] >> (13 - np.arange(14, dtype=np.uint64))[None, :]) & np.uint64(1)
+    gen = np.array([[(row >> (90 - i)) & 1 for i in range(91)] for row in _GEN], np.uint8)       # [83][91]
+    par = (m91.astype(np.int32) @ gen.T.astype(np.int32)) & 1
+    cw = np.concatenate([m91, par.astype(np.uint8)], axis=1)                                    # [n][174]
+    sym = (cw[:, 0::3] << 2) | (cw[:, 1::3] << 1) | cw[:, 2::3]
+    g = np.asarray(GRAY, np.uint8)[sym]
+    c = np.broadcast_to(np.asarray(COSTAS, np.uint8), (n, 7))
+    return np.concatenate([c, g[:, :29], c, g[:, 29:], c], axis=1)
+
+
+def _signal_table_chunk(args):
+    start, count, n_signals, snr_range, seed_base = args
     Q = pulse_cumsum()
     qs = np.zeros(81)
     qs[0], qs[1] = Q[3840], Q[1920]
     recs = np.zeros((count, max(1, n_signals)), SIGNAL_DTYPE)
-    truth = []
+    truth, words = [], []
     for fi in range(count):
         rng = np.random.Generator(np.random.Philox(key=seed_base + int(start + fi)))
         tr = []
@@ -274,17 +290,51 @@ def device_signal_table(start, count, n_signals=50, snr_range=(-10.0, 10.0), see
             f0 = rng.uniform(200.0, 2800.0)
             t0 = 0.5 + rng.uniform(-0.5, 1.0)
             snr = rng.uniform(*snr_range)
-            tones = tones79(pack77(*msg))
-            ext = np.array([tones[0]] + list(tones) + [tones[-1]], dtype=np.float64)
+            words.append(pack77(*msg))
             r = recs[fi, s]
             r["f0"] = f0
-            r["cum"][1:] = np.cumsum(ext * (Q[5760] - qs))
             r["amp"] = np.sqrt(2.0 * (2500.0 / 6000.0) * 10.0 ** (snr / 10.0))
             r["i0"] = int(round(t0 * FS))
-            r["ext"][:81] = ext.astype(np.uint8)
             tr.append(dict(msg=" ".join(msg), f0=float(f0), t0=float(t0), snr=float(snr)))
         truth.append(tr)
+    if n_signals and count:
+        tones = _tones79_batch(words)
+        ext = np.concatenate([tones[:, :1], tones, tones[:, -1:]], axis=1)                       # [n][81]
+        cum = np.cumsum(ext.astype(np.float64) * (Q[5760] - qs)[None, :], axis=1)
+        recs["cum"][:, :n_signals, 1:] = cum.reshape(count, n_signals, 81)
+        recs["ext"][:, :n_signals, :81] = ext.reshape(count, n_signals, 81)
     return recs, truth
+
+
+def device_signal_table(start, count, n_signals=50, snr_range=(-10.0, 10.0), seed_base=SEED_BASE, workers=None):
+    """Signal parameters for ft8rx_synth_frames: same recipe as make_frame (messages, f0, t0, SNR drawn from the
+    per-frame Philox stream); the noise itself is generated on the device.  -> (records[count, n_signals], truth).
+    Large tables (the 8192-frame shards of config 3: 400 k messages to pack and encode) are built by `workers` child processes
+    (default: one per allowed CPU up to 32 for >= 512 frames) -- plain `python -m pyft8_amd.synth` children, numpy only, so
+    neither a GPU-initialised parent is forked nor its __main__ re-imported."""
+    import os
+    if workers is None:
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        workers = min(32, ncpu) if count >= 512 else 1
+    workers = max(1, min(int(workers), count // 64 or 1))
+    if workers == 1:
+        return _signal_table_chunk((start, count, n_signals, tuple(snr_range), seed_base))
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    per = (count + workers - 1) // workers
+    jobs = [(start + o, min(per, count - o)) for o in range(0, count, per)]
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    with tempfile.TemporaryDirectory() as d:
+        procs = [subprocess.Popen([sys.executable, "-m", "pyft8_amd.synth", os.path.join(d, f"{i}.pkl"), str(s0), str(n), str(n_signals),
+                                   repr(float(snr_range[0])), repr(float(snr_range[1])), str(seed_base)], cwd=root, env=env)
+                 for i, (s0, n) in enumerate(jobs)]
+        if any(p.wait() != 0 for p in procs):
+            raise RuntimeError("device_signal_table: a table worker failed")
+        parts = [pickle.load(open(os.path.join(d, f"{i}.pkl"), "rb")) for i in range(len(jobs))]
+    return np.concatenate([p[0] for p in parts]), [t for p in parts for t in p[1]]
 
 
 # ----------------------------------------------------------------------------- numpy twins of the device generator (k_synth)
@@ -336,3 +386,12 @@ def device_frame(frame_index, table_row, n_signals, noise=True, seed=DEVICE_SEED
         lo, hi = max(i0, 0), min(i0 + len(w), NFRAME)
         x[lo:hi] += float(r["amp"]) * w[lo - i0:hi - i0]
     return np.clip(np.rint(x * 1000.0), -32768, 32767).astype(np.int16)
+
+
+if __name__ == "__main__":          # table worker of device_signal_table: out.pkl start count n_signals snr_lo snr_hi seed_base
+    import pickle
+    import sys
+    _a = sys.argv[1:]
+    _res = _signal_table_chunk((int(_a[1]), int(_a[2]), int(_a[3]), (float(_a[4]), float(_a[5])), int(_a[6])))
+    with open(_a[0], "wb") as _f:
+        pickle.dump(_res, _f, protocol=pickle.HIGHEST_PROTOCOL)

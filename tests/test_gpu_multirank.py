@@ -52,22 +52,25 @@ def test_two_ranks_one_gpu_gloo():
     d = _one_line(out)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["config"]["frames_per_gpu"] == 32
-    assert "records/events of 2 ranks gathered to rank 0 over gloo" in d["config"]["gather"], d["config"]["gather"]
+    assert "packed results of 2 ranks gathered to rank 0 over gloo inside every timed step" in d["config"]["gather"], d["config"]["gather"]
+    assert d["per_rank"]["gather"]["ok"] and 1000 < d["per_rank"]["gather"]["bytes_per_frame"] < 8000, d["per_rank"]["gather"]
     # whole-job value = frames of BOTH ranks / max-over-ranks time
     assert abs(d["value"] - 2 * 32 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 1e-6 * d["value"]
     assert d["value"] > 500
 
 
 def test_rccl_gather_path_two_ranks_or_forced_single_rank():
-    """The RCCL branch of bench.py (nccl process group, ft8rx_results_to_device -> all_reduce / all_gather / gather on device
-    tensors -> one D2H on rank 0): two ranks where the box has two GPUs; on a one-GPU box (RCCL refuses two ranks on one device) the
-    same collectives run in a ONE-rank nccl group (--force-gather) -- no skip either way."""
+    """The RCCL branch of bench.py (nccl process group; every timed step ends with PackedGather.submit: all_gather of the byte counts,
+    gather of the packed device buffers, one D2H per rank on rank 0, on a side stream): two ranks where the box has two GPUs; on a
+    one-GPU box (RCCL refuses two ranks on one device) the same collectives run in a ONE-rank nccl group (--force-gather) -- no skip
+    either way."""
     import torch
     if torch.cuda.device_count() >= 2:
         out = _launch(2, ["--backend", "nccl"] + SMALL)
         assert out.returncode == 0, (out.stderr + out.stdout)[-3000:]
         d = _one_line(out)
-        assert d["n_gpus"] == 2 and "gathered to rank 0 over nccl (device-resident buffers)" in d["config"]["gather"], d["config"]["gather"]
+        assert d["n_gpus"] == 2 and "packed results of 2 ranks gathered to rank 0 over nccl" in d["config"]["gather"], d["config"]["gather"]
+        assert d["per_rank"]["gather"]["ok"]
         assert len(d["per_rank"]["frames_per_s"]) == 2 and len(d["per_rank"]["placement"]) == 2
     else:
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--force-gather",
@@ -75,8 +78,9 @@ def test_rccl_gather_path_two_ranks_or_forced_single_rank():
                              env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
         assert out.returncode == 0, (out.stderr + out.stdout)[-3000:]
         d = _one_line(out)
-        assert "1 rank (forced) gathered to rank 0 over nccl (device-resident buffers)" in d["config"]["gather"], d["config"]["gather"]
-        assert len(d["per_rank"]["gather_ms"]) == 2 and d["per_rank"]["placement"][0]["how"]
+        assert "packed results of 1 rank (forced) gathered to rank 0 over nccl inside every timed step" in d["config"]["gather"], d["config"]["gather"]
+        g = d["per_rank"]["gather"]
+        assert g["ok"] and g["submit_ms_per_step"] >= 0 and 1000 < g["bytes_per_frame"] < 8000 and d["per_rank"]["placement"][0]["how"], g
 
 
 _NCCL_ONE_RANK = r'''
@@ -100,6 +104,31 @@ assert got[0].tobytes() == want[0].tobytes() and np.array_equal(got[1], want[1])
 for f in range(B):
     n = min(int(want[3][f]), _lib.EVENT_CAP)
     assert got[2][f, :n].tobytes() == want[2][f, :n].tobytes(), f
+# the packed gather (what bench.py runs inside its timed steps): pack kernels -> device buffer -> RCCL all_gather of the sizes + gather
+# on a side stream -> D2H into page-locked memory; `repeat` = rank 0's load of that many ranks.  Byte-identical to the numpy twin
+# of the pack kernels applied to fetch()'s arrays, for three batches in a row (both result slots, two gathers in flight).
+from pyft8_amd.distributed import PackedGather
+g = PackedGather(h, B, dst=0, force=True, repeat=3)
+seen = []
+for k in range(3):
+    h.enqueue(ptr, B)
+    res = h.fetch(B)
+    g.submit()
+    seen.append(_lib.pack_results(*res))
+    if k > 0:
+        parts = g.collect()
+        assert len(parts) == 3 and all(p.buf.tobytes() == seen[k - 1].tobytes() for p in parts), k
+parts = g.drain()
+assert len(parts) == 3 and all(p.buf.tobytes() == seen[2].tobytes() for p in parts)
+pk = parts[0]
+assert pk.n_frames == B and 1500 < pk.nbytes / B < 8000, pk.nbytes / B
+m_dense = _lib.package_batch(*res)
+m_packed = _lib.package_packed(pk)
+assert m_dense[0].tobytes() == m_packed[0].tobytes() and np.array_equal(m_dense[1], m_packed[1]) and int(m_dense[1].sum()) > 20 * B
+r2, c2, e2, ec2 = pk.expand()
+dec = res[0]["status"] == _lib.ST_DECODED
+assert np.array_equal(c2, res[1]) and np.array_equal(ec2, res[3]) and r2[dec].tobytes() == res[0][dec].tobytes()      # fetch()'s decoded set, byte for byte
+g.close()
 via_host = gather_results(*want, dst=0, force=True)             # host arrays through the same backend (one H2D per array)
 assert via_host[0].tobytes() == want[0].tobytes() and np.array_equal(via_host[1], want[1])
 # a zero-copy view of the same batch is the same bytes
@@ -122,6 +151,112 @@ def test_rccl_device_gather_byte_equal_single_rank_group(tmp_path):
     out = subprocess.run([sys.executable, str(script), ROOT, str(_port())], capture_output=True, text=True, timeout=900, cwd=ROOT,
                          env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout + out.stderr)[-3000:]
+
+
+def test_packed_results_equal_the_numpy_twin_of_fetch():
+    """ft8rx_set_packed_output / ft8rx_packed_results: the three pack kernels at the end of a batch write header | frame table | kept
+    records | used events -- byte for byte what _lib.pack_results (numpy) makes of the same batch's fetch(); into device memory and
+    straight into page-locked host memory; large (event-log compaction, free-running chunks) and small (single chain) batches; an
+    undersized buffer is flagged, never overrun."""
+    import torch
+    from pyft8_amd import _lib
+    for B in (320, 6):
+        h = _lib.Handle(max_frames=B)
+        ptr = h.staging_ptr()
+        h.synth_frames(ptr, 5200000, B, n_signals=50, snr_range=(-10.0, 10.0))
+        cap = _lib.packed_capacity(B, h.cfg.max_cands)
+        dev = [torch.zeros(cap + 64, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        h.set_packed_output(dev[0].data_ptr(), dev[1].data_ptr(), cap)
+        slots = []
+        for k in range(3):
+            h.enqueue(ptr, B)
+            res = h.fetch(B)
+            which, hdr = h.packed_results()
+            slots.append(which)
+            want = _lib.pack_results(*res)
+            assert hdr["bytes"] == len(want) and not hdr["overflow"] and hdr["n_frames"] == B and hdr["max_cands"] == h.cfg.max_cands
+            got = dev[which][:hdr["bytes"]].cpu().numpy()
+            assert got.tobytes() == want.tobytes(), (B, k)
+            assert not dev[which][cap:].any()                               # nothing beyond the capacity
+        assert slots[0] != slots[1] and slots[0] == slots[2]                 # the two result slots alternate
+        pk = _lib.Packed(got)
+        assert int(pk.frames["n_rec"].sum()) == len(pk.records) > 20 * B and pk.nbytes / B < 8000
+        # page-locked host buffers: the kernels write across PCIe, no copy
+        pin = [h.pinned_bytes(cap) for _ in range(2)]
+        h.set_packed_output(pin[0].ctypes.data, pin[1].ctypes.data, cap)
+        h.enqueue(ptr, B)
+        res = h.fetch(B)
+        which, hdr = h.packed_results()
+        assert pin[which][:hdr["bytes"]].tobytes() == _lib.pack_results(*res).tobytes()
+        m1, m2 = _lib.package_batch(*res), _lib.package_packed(pin[which][:hdr["bytes"]])
+        assert m1[0].tobytes() == m2[0].tobytes() and np.array_equal(m1[1], m2[1])
+        # the synchronous entry fills it too
+        audio = h.download_audio(ptr, B)
+        res = h.decode_batch(audio)
+        which, hdr = h.packed_results()
+        assert pin[which][:hdr["bytes"]].tobytes() == _lib.pack_results(*res).tobytes()
+        # too small: header and frame table only, flagged
+        small = 32 + 16 * B + 4800
+        dev[0].zero_(); dev[1].zero_()
+        h.set_packed_output(dev[0].data_ptr(), dev[1].data_ptr(), small)
+        h.enqueue(ptr, B)
+        res = h.fetch(B)
+        which, hdr = h.packed_results()
+        assert hdr["overflow"] and hdr["bytes"] == len(_lib.pack_results(*res)) and not dev[which][32 + 16 * B:].any()
+        with pytest.raises(_lib.Ft8rxError):
+            _lib.Packed(dev[which].cpu().numpy())
+        # off again
+        h.set_packed_output(None, None, 0)
+        h.enqueue(ptr, B)
+        h.fetch(B)
+        with pytest.raises(_lib.Ft8rxError):
+            h.packed_results()
+        h.close()
+
+
+def test_eight_ranks_one_gpu_gloo_uneven_total():
+    """What the 8-GPU node will run cold, at world size 8 on the one GPU of a test box (gloo; RCCL refuses several ranks per device):
+    bench.py's whole N > 1 flow with an UNEVEN total (8 x 16 + 3 frames: shard() gives the first three ranks one more), per-rank
+    placement on pairwise-disjoint whole-core CPU sets, the packed gather inside every timed step with the frames arriving in shard
+    order, value = all frames x steps / max-over-ranks time."""
+    total, steps = 8 * 16 + 3, 2
+    out = _launch(8, ["--backend", "gloo", "--total-frames", str(total), "--steps", str(steps), "--warmup", "1", "--no-host-entry", "--min-seconds", "0"],
+                  timeout=2400)
+    assert out.returncode == 0, (out.stderr + out.stdout)[-4000:]
+    d = _one_line(out)
+    assert d["n_gpus"] == 8 and d["steps"] == steps and d["scaling"] == "weak" and d["cpu_baseline"] is None and d["other_configs"] is None
+    pr = d["per_rank"]
+    assert pr["frames"] == [17, 17, 17, 16, 16, 16, 16, 16]
+    assert all(len(pr[k]) == 8 for k in ("ms_per_step", "frames_per_s", "kernel_only_frames_per_s", "placement"))
+    assert abs(d["value"] - total * steps / (max(pr["ms_per_step"]) * steps * 1e-3)) < 2e-3 * d["value"]      # (per-rank ms are rounded)
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    g = pr["gather"]
+    assert g["ok"] and "packed results of 8 ranks gathered to rank 0 over gloo inside every timed step" in d["config"]["gather"], d["config"]["gather"]
+    assert "every rank's frames arrived in shard order" in d["config"]["gather"]
+    # placement: every rank pinned to its own CPUs; hardware threads of one core never split between two ranks
+    sets = []
+    for p in pr["placement"]:
+        assert p["cpus"], p
+        cpus = set()
+        for part in p["cpus"].split(","):
+            a, _, b = part.partition("-")
+            cpus |= set(range(int(a), int(b or a) + 1))
+        sets.append(cpus)
+    if len(set().union(*sets)) >= 16:                  # (a box with fewer cores than ranks cannot give disjoint slices)
+        for i in range(8):
+            for j in range(i + 1, 8):
+                assert not (sets[i] & sets[j]), (i, j, pr["placement"][i], pr["placement"][j])
+        for i, cs in enumerate(sets):
+            for c in cs:
+                try:
+                    sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+                except OSError:
+                    continue
+                sibs = set()
+                for part in sib.split(","):
+                    a, _, b = part.partition("-")
+                    sibs |= set(range(int(a), int(b or a) + 1))
+                assert not any(sibs & sets[j] for j in range(8) if j != i), (i, c, sib)
 
 
 def test_bench_gpus_flag_starts_the_launcher_itself():
@@ -174,7 +309,7 @@ def test_config3_shard_full_size():
                           "--no-cpu-baseline", "--min-seconds", "0"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _one_line(out)
-    assert d["config"]["frames_per_gpu"] == 8192 and "8192 synthetic 15-s frames per GPU" in d["config"]["workload"]
+    assert d["config"]["frames_per_gpu"] == 8192 and "8192 synthetic 15-s frames per GPU" in d["config"]["workload"] and d["other_configs"] is None
 
 
 def test_config4_low_snr_order3_full_size():
