@@ -348,6 +348,9 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env or 1}: launch one process per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
+    # (GPU_MAX_HW_QUEUES is deliberately left alone: eight hardware queues would give the gather's side stream a queue of its own, but
+    # they cost the decode kernels 9 % -- 53.9 k -> 49.1 k frames/s kernels only, profiles/r04_notes.md.  With the default four the gather's
+    # copies may sit behind a chunk's kernel chain for up to one batch; nothing waits for them, the byte counts travel over gloo.)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -556,7 +559,9 @@ def main():
     if gather is not None:
         try:
             h.enqueue(d_audio.data_ptr(), B)
-            view = h.fetch_view(B)
+            h.sync()
+            h.fetch_view(B)                           # (the un-timed passes above left older batches unfetched)
+            view = h.fetch_view(B)                    # the batch just enqueued; the GPU is idle now
             t3 = time.perf_counter()
             gather.submit()
             parts = gather.drain()
@@ -569,7 +574,8 @@ def main():
                 for f in range(n):
                     r = recs_of_frame(f)
                     d = r[r["status"] == _lib.ST_DECODED]
-                    out.append(zlib.crc32(np.ascontiguousarray(d[["msg_lo", "msg_hi", "f0_idx", "h0_idx"]]).tobytes()))
+                    cols = np.stack([d[k].astype(np.uint64) for k in ("msg_lo", "msg_hi", "f0_idx", "h0_idx", "ipass")]) if len(d) else np.zeros(0, np.uint64)
+                    out.append(zlib.crc32(np.ascontiguousarray(cols).tobytes()))
                 return out
             mine = digests(lambda f: view[0][f, :view[1][f]], B)
             every = [mine]
@@ -578,7 +584,9 @@ def main():
                 dist.all_gather_object(every, mine)
             sub = np.array(gather.seconds[args.warmup + 1:] or gather.seconds)
             gather_info = {"submit_ms_per_step": round(1e3 * float(sub.mean()), 4), "submit_ms_max": round(1e3 * float(sub.max()), 4),
-                           "unoverlapped_ms": round(sync_ms, 3), "repeat": args.gather_repeat, "rendered_on_rank0": bool(args.render_gathered)}
+                           "unoverlapped_ms": round(sync_ms, 3), "repeat": args.gather_repeat, "rendered_on_rank0": bool(args.render_gathered),
+                           "submit_phases_ms": {k: round(1e3 * float(np.mean([p.get(k, 0.0) for p in gather.phases[args.warmup + 1:] or gather.phases])), 4)
+                                                for k in ("header", "wait_slot", "sizes", "issue")}}
             if rank == 0:
                 assert len(parts) == world * args.gather_repeat, f"{len(parts)} parts from {world} ranks"
                 total = sum(p.n_frames for p in parts[:world])
@@ -645,6 +653,7 @@ def main():
                        "frames_per_gpu": B, "decoded_candidates_per_frame": n_dec / B,
                        "unique_messages_first16": n_msgs, "messages_per_frame": float(mc_.mean()),
                        "kernel_only_frames_per_s_this_rank": kernel_only, "host_message_threads": pk_threads,
+                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "host_pointer_sync_entry_frames_per_s_pageable": pcie, "host_pointer_sync_entry_frames_per_s_pinned": pcie_sync,
                        "host_pointer_pipelined_entry_frames_per_s_pinned": pcie_pinned, "parallelism": f"frames sharded over {world} GPU(s), no collective on the decode path", "gather": gather_note},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

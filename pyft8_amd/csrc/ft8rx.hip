@@ -146,6 +146,14 @@ template <typename T> static int dalloc(ft8rx_handle* h, T** p, size_t n) {
     h->allocs.push_back(q); *p = (T*)q; return 0;
 }
 
+// The handle's own device audio buffer ([max_frames][180000] int16: staging of the host-pointer entry points, ft8rx_staging_audio) is
+// allocated when something first asks for it: a caller that keeps its audio resident in HBM (ft8rx_enqueue_batch) never pays the
+// 360 KB per frame.
+static int need_staging(ft8rx_handle* h) {
+    if (h->d_audio) return 0;
+    return dalloc(h, &h->d_audio, (size_t)h->max_frames * FT8RX_NSAMP);
+}
+
 static void host_twiddle(int n, int count, std::vector<cpx>& w) {
     w.resize(count);
     for (int t = 0; t < count; t++) {
@@ -275,7 +283,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     ft8rx_handle* h = new ft8rx_handle();
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
     h->n_streams = 2; h->ladder_mode = 0; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
-    h->copy_s = nullptr; h->slot_evpending[0] = h->slot_evpending[1] = false; h->h2d_s = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
+    h->copy_s = nullptr; h->slot_evpending[0] = h->slot_evpending[1] = false; h->h2d_s = nullptr; h->d_audio = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
     for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->h_evpacked[k] = nullptr; h->d_evpacked[k] = nullptr; h->d_evoffs[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
     for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) h->ev_cdone[k][i] = nullptr;
@@ -288,7 +296,6 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
     int rc = 0;
-    rc |= dalloc(h, &h->d_audio, B * FT8RX_NSAMP);
     rc |= dalloc(h, &h->d_grid, B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS);
     rc |= dalloc(h, &h->d_best_score, B * NF0MAX);
     rc |= dalloc(h, &h->d_best_h0, B * NF0MAX);
@@ -300,8 +307,12 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     rc |= dalloc(h, &h->d_attG, B * MAXC * 2);
     rc |= dalloc(h, &h->d_attB, B * MAXC * 5);
     rc |= dalloc(h, &h->d_attO, B * MAXC * 10);
-    rc |= dalloc(h, &h->d_A, B * 96000);
-    rc |= dalloc(h, &h->d_spec, B * FT8RX_SPEC_BINS);
+    // The four-step scratch (768 KB per frame) and the cycle spectrum (393 KB; 768 KB in the wide build) live INSIDE the grid buffer: the
+    // dB grid is dead once k_grid_llr has gathered the payloads, and the cycle FFT only starts after that (enqueue_chain places a chunk's
+    // A and spectrum at the start of the chunk's own grid region; k_spectrogram rewrites the constant row 0 with every batch).  The
+    // stage entry points use one of the three at a time.  -1.16 MB of HBM per frame.
+    static_assert((size_t)(96000 + FT8RX_SPEC_BINS) * sizeof(cpx) <= (size_t)FT8RX_GRID_ROWS * FT8RX_GRID_COLS * sizeof(float), "scratch A + cycle spectrum fit a frame's grid");
+    if (!rc) { h->d_A = reinterpret_cast<cpx*>(h->d_grid); h->d_spec = h->d_A + B * 96000; }
     for (int i = 0; i < WL_N; i++) rc |= dalloc(h, &h->d_work[i], B * MAXC * (i == WL_BP0 ? 5 : 1));      // WL_BP0 lists attempts
     rc |= dalloc(h, &h->d_wcount, (size_t)16 * WL_N);
     rc |= dalloc(h, &h->d_ev, B * FT8RX_EVENT_CAP);
@@ -432,7 +443,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     ft8rx_record* rec = h->s_rec[slot] + F * MAXC; int32_t* ncand = h->s_ncand[slot] + F;
     float* llr0 = h->d_llr0 + F * MAXC * 174; float* saved = h->d_saved + F * MAXC * 5 * 174;
     Att* att0 = h->d_att0 + F * MAXC * 5; Att* attG = h->d_attG + F * MAXC * 2; Att* attB = h->d_attB + F * MAXC * 5; Att* attO = h->d_attO + F * MAXC * 10;
-    cpx* A = h->d_A + F * 96000; cpx* spec = h->d_spec + F * FT8RX_SPEC_BINS;
+    cpx* A = reinterpret_cast<cpx*>(grid); cpx* spec = A + (size_t)B * 96000;      // inside this chunk's (by then dead) grid region, see ft8rx_create
     ft8rx_event* ev = h->s_ev[slot] + F * FT8RX_EVENT_CAP; int32_t* evc = h->s_evcount[slot] + F;
 #define STAGE(name) do { if (prof) { hipEventRecord(h->pev[h->pnames.size()], s); h->pnames.push_back(name); } } while (0)
     int32_t* wc = h->d_wcount + WL_N * chunk;                      // (evc and wc are zeroed by k_topk)
@@ -499,6 +510,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     h->pnames.clear();
     if (h->inflight == 2) { h->slot_fetch ^= 1; h->inflight = 1; }          // the oldest unfetched batch is dropped
     const int slot = h->slot_enq;
+    if (host_audio && need_staging(h)) return -2;
     int16_t* stage = h->d_audio;
     hipStream_t cs = h->copy_s;
     if (pipelined) {
@@ -797,6 +809,7 @@ int ft8rx_decode_batch(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_recor
     if (!h || !audio) return -1;
     if (B < 1 || B > h->max_frames) { set_err(h, "ft8rx_decode_batch: n_frames %d outside [1, %d]", B, h->max_frames); return -1; }
     h->inflight = 0; h->slot_fetch = h->slot_enq;                     // synchronous entry: nothing older is kept
+    if (need_staging(h)) return -2;
     int rc = launch_batch(h, h->d_audio, audio, B);
     if (rc) return rc;
     return ft8rx_fetch_results(h, B, records, counts, events, event_counts);
@@ -809,6 +822,7 @@ int ft8rx_decode_messages(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_me
     if (!h || !audio || !out || !out_counts) return -1;
     if (B < 1 || B > h->max_frames || max_msgs < 1) { set_err(h, "ft8rx_decode_messages: bad n_frames / max_msgs"); return -1; }
     h->inflight = 0; h->slot_fetch = h->slot_enq;                     // synchronous entry: nothing older is kept
+    if (need_staging(h)) return -2;
     int rc = launch_batch(h, h->d_audio, audio, B);
     if (rc) return rc;
     const ft8rx_record* rec; const int32_t* cnt; const ft8rx_event* ev; const int32_t* evc;
@@ -823,6 +837,7 @@ int ft8rx_decode_messages(ft8rx_handle* h, const int16_t* audio, int B, ft8rx_me
 int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid) {
     if (!h || !audio || !grid || B < 1 || B > h->max_frames) return -1;
     ENTER(h);
+    if (need_staging(h)) return -2;
     HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
     ft8rx_ilp_spectrogram(B, h->stream, h->d_audio, h->d_grid, h->T);
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -833,6 +848,7 @@ int ft8rx_spectrogram(ft8rx_handle* h, const int16_t* audio, int B, float* grid)
 int ft8rx_hop_spectrum(ft8rx_handle* h, const int16_t* window3840, float* row) {
     if (!h || !window3840 || !row) return -1;
     ENTER(h);
+    if (need_staging(h)) return -2;
     float* d_row = h->d_best_score;                      // any scratch of FT8RX_GRID_COLS floats (NF0MAX >= that): not in use between batches
     HIPCHK(h, hipMemcpyAsync(h->d_audio, window3840, sizeof(int16_t) * 3840, hipMemcpyHostToDevice, h->stream));
     ft8rx_ilp_hop_spectrum(h->stream, h->d_audio, d_row, h->T);
@@ -902,6 +918,7 @@ int ft8rx_llr_grid(ft8rx_handle* h, const float* grid, int B, int n, const int32
 int ft8rx_cycle_spectrum(ft8rx_handle* h, const int16_t* audio, int B, float* spec) {
     if (!h || !audio || !spec || B < 1 || B > h->max_frames) return -1;
     ENTER(h);
+    if (need_staging(h)) return -2;
     HIPCHK(h, hipMemcpy(h->d_audio, audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice));
     k_cyc_a<<<dim3(40, B), 256, 0, h->stream>>>(h->d_audio, h->d_A, h->T);
     k_cyc_bc<<<dim3(CYC_BC_GRID, B), 256, 0, h->stream>>>(h->d_A, h->d_spec, h->T);
@@ -1012,7 +1029,10 @@ int ft8rx_valid77(ft8rx_handle* h, const uint64_t* msg_lo, const uint64_t* msg_h
     return 0;
 }
 
-int16_t* ft8rx_staging_audio(ft8rx_handle* h) { return h ? h->d_audio : nullptr; }
+int16_t* ft8rx_staging_audio(ft8rx_handle* h) {
+    if (!h || hipSetDevice(h->device) != hipSuccess || need_staging(h)) return nullptr;
+    return h->d_audio;
+}
 
 int ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes) {
     if (!h || !dst || !d_src) return -1;

@@ -126,7 +126,11 @@ __global__ __launch_bounds__(SPEC_NT) void k_spectrogram(const int16_t* __restri
     // (8x overlapping windows) instead of all of it.
     static_assert(FT8RX_GRID_ROWS == 8 * 47, "the hop map below assumes gridDim.x = 376 = 8 XCDs x 47");
     const int hop = (blockIdx.x & 7) * 47 + (blockIdx.x >> 3) + 1, f = blockIdx.y, tid = threadIdx.x;
-    if (hop > 375) return;
+    if (hop > 375) {           // the one spare workgroup of a frame: the never-written row 0 (receiver.py:240), which the cycle FFT's scratch overwrites
+        float* row0 = grid + (size_t)f * FT8RX_GRID_ROWS * FT8RX_GRID_COLS;
+        for (int i = tid; i < FT8RX_GRID_COLS; i += SPEC_NT) row0[i] = 1.0f;
+        return;
+    }
     spectrogram_hop(audio + (size_t)f * FT8RX_NSAMP, 480 * hop - 3840,
                     grid + ((size_t)f * FT8RX_GRID_ROWS + hop) * FT8RX_GRID_COLS, T, z, w240, tid);
 }

@@ -9,8 +9,9 @@ The gather the measured path uses (bench.py, inside the timed step):
   PackedGather(handle, n_frames)          every batch ends with three small kernels that pack what the host message layer reads of it
                                           (records of the candidates that decoded or logged an unpack() call + the used event log,
                                           ~4 KB per config-1 frame instead of 13-24 KB; include/ft8rx.h "packed results") into a
-                                          device buffer; submit() exchanges the byte counts and gathers the packed buffers to rank
-                                          `dst` on a side stream (RCCL over xGMI), where one D2H copy per rank lands them in
+                                          device buffer; submit() exchanges the byte counts on the host (gloo, 8 bytes per rank) and
+                                          gathers the packed buffers to rank `dst` on a side stream (RCCL over xGMI), where one D2H
+                                          copy per rank lands them in
                                           page-locked host memory -- all of it overlapping the next batch's kernels.  Rank `dst`
                                           keeps the packed form (a view per rank / frame, `_lib.Packed`) and can render any frame's
                                           messages from it (`_lib.package_packed`).  With gloo (flow tests) the GPU writes the packed
@@ -153,6 +154,11 @@ class PackedGather:
         self.cap = (_lib.packed_capacity(self.B, handle.cfg.max_cands, per_frame) + 255) & ~255
         self.pending = []                  # (slot, sizes, event-or-None) in submit order
         self.seconds = []                  # host time spent inside submit() per call (the size exchange blocks; the rest is asynchronous)
+        self.phases = []                   # the same, split: header / wait_slot (the gather two batches ago) / sizes / issue
+        # the byte counts are exchanged on the host (a gloo group next to the RCCL one): a device-side exchange would make every
+        # submit() wait for the side stream, and a side stream shares one of the runtime's few hardware queues with a chunk stream
+        # of the decode -- measured: the 8-byte all_gather then waits for the whole batch in front of it (135 ms at config 3)
+        self.cpu_group = dist.new_group(ranks=(dist.get_process_group_ranks(group) if group is not None else None), backend="gloo") if self.nccl else group
         if self.nccl:
             dev = torch.device("cuda", torch.cuda.current_device())
             self.stream = torch.cuda.Stream(device=dev)
@@ -178,61 +184,67 @@ class PackedGather:
         self.h.set_packed_output(None, None, 0)
 
     def _finish(self, item):
-        slot, sizes, ev = item
+        slot, sizes, ev, m = item
         if ev is not None:
             ev.synchronize()
         if not self.active:
             return [self._lib.Packed(self._pin[slot][:sizes[0]])]
         if self.rank != self.dst:
             return None
-        rows = self.host[slot].numpy()
-        return [self._lib.Packed(rows[i][:sizes[i % self.world]]) for i in range(self.world * self.repeat)]
+        flat = self.host[slot].view(-1).numpy()          # this batch's parts lie back to back, m bytes apart
+        return [self._lib.Packed(flat[i * m:i * m + sizes[i % self.world]]) for i in range(self.world * self.repeat)]
 
     def submit(self):
         """Start the gather of the batch the last fetch returned (every rank calls this once per fetched batch, in the same order)."""
         import time
         t0 = time.perf_counter()
+        ph = {}
+
+        def mark(name, _t=[t0]):
+            now = time.perf_counter()
+            ph[name] = ph.get(name, 0.0) + now - _t[0]
+            _t[0] = now
         slot, hdr = self.h.packed_results()
         if hdr["overflow"]:
             raise self._lib.Ft8rxError(f"PackedGather: a batch needs {hdr['bytes']} packed bytes, the buffers hold {self.cap} (raise per_frame)")
+        mark("header")
         while any(p[0] == slot for p in self.pending):          # the gather that last used this slot's buffers
             self._done = self._finish(self.pending.pop(0))
+        mark("wait_slot")
+        self.phases.append(ph)
         nbytes = int(hdr["bytes"])
         if not self.active:
-            self.pending.append((slot, [nbytes], None))
+            self.pending.append((slot, [nbytes], None, 0))
             self.seconds.append(time.perf_counter() - t0)
             return
+        mine = torch.tensor([nbytes], dtype=torch.int64)
+        lst = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(lst, mine, group=self.cpu_group)
+        sizes = [int(x.item()) for x in lst]
+        mark("sizes")
+        n = self.world * self.repeat
         if self.nccl:
             with torch.cuda.stream(self.stream):
-                mine = torch.tensor([nbytes], dtype=torch.int64).to(self.src[slot].device, non_blocking=True)
-                allsz = torch.empty(self.world, dtype=torch.int64, device=mine.device)
-                dist.all_gather_into_tensor(allsz, mine, group=self.group)
-                sizes = [int(x) for x in allsz.tolist()]                     # waits for the side stream only
                 m = (max(sizes) + 255) & ~255
+                # the parts of this batch are received back to back (m bytes apart) so that ONE D2H copy moves them all
+                flat = self.recv[slot].view(-1) if self.rank == self.dst else None
                 for rep in range(self.repeat):
-                    out = None
-                    if self.rank == self.dst:
-                        out = [self.recv[slot][rep * self.world + r][:m] for r in range(self.world)]
+                    out = [flat[(rep * self.world + r) * m:(rep * self.world + r + 1) * m] for r in range(self.world)] if flat is not None else None
                     dist.gather(self.src[slot][:m], out, dst=self.dst, group=self.group)
-                    if self.rank == self.dst:
-                        for r in range(self.world):
-                            i = rep * self.world + r
-                            self.host[slot][i][:sizes[r]].copy_(self.recv[slot][i][:sizes[r]], non_blocking=True)
+                if flat is not None:
+                    self.host[slot].view(-1)[:n * m].copy_(flat[:n * m], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
+                mark("issue")
         else:
-            mine = torch.tensor([nbytes], dtype=torch.int64)
-            lst = [torch.zeros_like(mine) for _ in range(self.world)]
-            dist.all_gather(lst, mine, group=self.group)
-            sizes = [int(x.item()) for x in lst]
             m = max(sizes)
+            flat = self.host[slot].view(-1) if self.rank == self.dst else None
             for rep in range(self.repeat):
-                out = None
-                if self.rank == self.dst:
-                    out = [self.host[slot][rep * self.world + r][:m] for r in range(self.world)]
+                out = [flat[(rep * self.world + r) * m:(rep * self.world + r + 1) * m] for r in range(self.world)] if flat is not None else None
                 dist.gather(self.src[slot][:m], out, dst=self.dst, group=self.group)
+            mark("issue")
             ev = None
-        self.pending.append((slot, sizes, ev))
+        self.pending.append((slot, sizes, ev, m))
         self.seconds.append(time.perf_counter() - t0)
 
     def collect(self):
