@@ -158,7 +158,14 @@ class PackedGather:
         # the byte counts are exchanged on the host (a gloo group next to the RCCL one): a device-side exchange would make every
         # submit() wait for the side stream, and a side stream shares one of the runtime's few hardware queues with a chunk stream
         # of the decode -- measured: the 8-byte all_gather then waits for the whole batch in front of it (135 ms at config 3)
-        self.cpu_group = dist.new_group(ranks=(dist.get_process_group_ranks(group) if group is not None else None), backend="gloo") if self.nccl else group
+        self.cpu_group = group
+        if self.nccl:
+            try:
+                self.cpu_group = dist.new_group(ranks=(dist.get_process_group_ranks(group) if group is not None else None), backend="gloo")
+            except Exception as e:                   # no gloo transport on this box: the counts go over RCCL (submit() then waits for the side stream)
+                import warnings
+                warnings.warn(f"PackedGather: no gloo group for the size exchange ({type(e).__name__}: {e}); using the device path", RuntimeWarning)
+                self.cpu_group = None
         if self.nccl:
             dev = torch.device("cuda", torch.cuda.current_device())
             self.stream = torch.cuda.Stream(device=dev)
@@ -217,10 +224,17 @@ class PackedGather:
             self.pending.append((slot, [nbytes], None, 0))
             self.seconds.append(time.perf_counter() - t0)
             return
-        mine = torch.tensor([nbytes], dtype=torch.int64)
-        lst = [torch.zeros_like(mine) for _ in range(self.world)]
-        dist.all_gather(lst, mine, group=self.cpu_group)
-        sizes = [int(x.item()) for x in lst]
+        if self.nccl and self.cpu_group is None:
+            with torch.cuda.stream(self.stream):
+                mine = torch.tensor([nbytes], dtype=torch.int64).to(self.src[slot].device)
+                allsz = torch.empty(self.world, dtype=torch.int64, device=mine.device)
+                dist.all_gather_into_tensor(allsz, mine, group=self.group)
+                sizes = [int(x) for x in allsz.tolist()]
+        else:
+            mine = torch.tensor([nbytes], dtype=torch.int64)
+            lst = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(lst, mine, group=self.cpu_group)
+            sizes = [int(x.item()) for x in lst]
         mark("sizes")
         n = self.world * self.repeat
         if self.nccl:

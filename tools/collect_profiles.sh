@@ -4,7 +4,7 @@
 # rocprofv3 passes are separate runs (kernel trace + stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE), each with the
 # program itself after `--`.  Everything is bounded by `timeout`.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -55,10 +55,23 @@ timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baselin
 timeout 900 python3 bench.py --config 3 --no-cpu-baseline > "$OUT/${TAG}_bench_config3_shard_b8192.json" 2>> "$OUT/${TAG}_big.err"
 timeout 900 python3 bench.py --config 4 --no-cpu-baseline > "$OUT/${TAG}_bench_config4_b2048_order3_gate.json" 2>> "$OUT/${TAG}_big.err"
 timeout 900 python3 bench.py --frames 4096 --steps 3 --warmup 1 --no-cpu-baseline --signals 8 --snr -24 -14 > "$OUT/${TAG}_bench_b4096_lowsnr.json" 2>> "$OUT/${TAG}_big.err"
-# two ranks on this one GPU over gloo: the N > 1 flow of bench.py (sharding, barriers, gather) -- not a scaling number
+# two ranks on this one GPU over gloo: the N > 1 flow of bench.py (sharding, barriers, the packed gather inside the steps) -- not a scaling number
 timeout 900 python3 bench.py --gpus 2 --backend gloo --no-host-entry > "$OUT/${TAG}_bench_2ranks_1gpu_gloo.json" 2>> "$OUT/${TAG}_big.err"
-# the RCCL gather path in a one-rank nccl group on this one GPU (config-3 shard): device-resident buffers, per-rank figures, placement
-timeout 900 python3 bench.py --gpus 1 --backend nccl --force-gather --config 3 --no-cpu-baseline --no-host-entry > "$OUT/${TAG}_bench_config3_forced_rccl_gather.json" 2>> "$OUT/${TAG}_big.err"
+# eight ranks on this one GPU over gloo: the rank-count-dependent paths at world size 8 (uneven total; 1024 frames per rank)
+timeout 900 python3 bench.py --gpus 8 --backend gloo --total-frames 131 --steps 2 --warmup 1 --no-host-entry --min-seconds 0 > "$OUT/${TAG}_bench_8ranks_1gpu_gloo_uneven131.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py --gpus 8 --backend gloo --frames 1024 --steps 3 --warmup 1 --no-host-entry --min-seconds 0 > "$OUT/${TAG}_bench_8ranks_1gpu_gloo_b1024.json" 2>> "$OUT/${TAG}_big.err"
+# the RCCL gather in a one-rank nccl group on this one GPU, INSIDE the timed steps: config-3 shard and config 1, each with the gather,
+# without it, and with rank 0's eight-rank load (--gather-repeat 8)
+G="--gpus 1 --backend nccl --force-gather --no-cpu-baseline --no-host-entry --no-other-configs"
+timeout 900 python3 bench.py $G --config 3 --steps 4 > "$OUT/${TAG}_bench_config3_rccl_gather_in_step.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py $G --config 3 --steps 4 --no-gather > "$OUT/${TAG}_bench_config3_rccl_no_gather.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py $G --config 3 --steps 4 --gather-repeat 8 > "$OUT/${TAG}_bench_config3_rccl_gather_x8.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py $G --config 3 --steps 4 --gather-repeat 8 --render-gathered > "$OUT/${TAG}_bench_config3_rccl_gather_x8_rank0_renders_all.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py $G > "$OUT/${TAG}_bench_config1_rccl_gather_in_step.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py $G --no-gather > "$OUT/${TAG}_bench_config1_rccl_no_gather.json" 2>> "$OUT/${TAG}_big.err"
+timeout 900 python3 bench.py $G --gather-repeat 8 > "$OUT/${TAG}_bench_config1_rccl_gather_x8.json" 2>> "$OUT/${TAG}_big.err"
+python3 tools/kernel_resources.py > "$OUT/${TAG}_kernel_resources.txt" 2>> "$OUT/${TAG}_big.err"
+timeout 300 tools/ubench/mfma_valu_overlap > "$OUT/${TAG}_mfma_valu_overlap.txt" 2>&1
 timeout 300 python3 tools/host_breakdown.py > "$OUT/${TAG}_host_breakdown.txt" 2>> "$OUT/${TAG}_big.err"
 # SQ counters per kernel (three --pmc passes)
 timeout 1500 tools/pmc_sq.sh "${TAG}" > /dev/null 2>&1
@@ -67,4 +80,8 @@ timeout 300 tools/ubench/valu_rate > "$OUT/${TAG}_valu_rate.txt" 2>&1
 timeout 300 python3 tools/latency.py > "$OUT/${TAG}_latency.txt" 2>> "$OUT/${TAG}_big.err"
 timeout 600 python3 tools/two_pass_yield.py 256 50 2>&1 | tail -7 > "$OUT/${TAG}_multi_pass_yield.txt"
 timeout 1200 python3 tools/sensitivity.py 2048 > "$OUT/${TAG}_sensitivity_wide.txt" 2>> "$OUT/${TAG}_big.err"
-ls -la "$OUT" | grep "${TAG}_" | head -40
+timeout 900 python3 tools/multipass_profile.py > "$OUT/${TAG}_multipass_profile.txt" 2>> "$OUT/${TAG}_big.err"
+timeout 1500 python3 tools/parity_sweep.py 130 16 > "$OUT/${TAG}_parity_sweep.txt" 2>> "$OUT/${TAG}_big.err"
+timeout 400 python3 tools/soak.py 120 > "$OUT/${TAG}_soak.txt" 2>> "$OUT/${TAG}_big.err"
+timeout 1500 python3 -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.log" 2>&1
+ls -la "$OUT" | grep "${TAG}_" | head -60
