@@ -307,6 +307,7 @@ def main():
                     "(by default every rank renders its own shard and rank 0 keeps the packed form of the others)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1 default command: skip the short runs of BASELINE configs 2-4")
     ap.add_argument("--other-configs", action="store_true", help="run the short config 2-4 passes even for a non-default workload")
+    ap.add_argument("--host-threads", type=int, default=None, help="threads of the native host message layer per rank (default: min(32, this rank's CPUs))")
     ap.add_argument("--no-pin", action="store_true", help="leave the rank's CPU affinity alone")
     ap.add_argument("--share-gpu", action="store_true", help="flow tests on a box with fewer GPUs than ranks: rank r uses device r %% device_count "
                     "(gloo always does this; RCCL itself refuses two ranks on one device)")
@@ -436,6 +437,8 @@ def main():
     # packages batch k-1.  All K batches are fully decoded to message arrays inside the timed region.
     cores = len(os.sched_getaffinity(0))                   # this rank's slice after place_rank
     pk_threads = max(2, min(32, cores if not args.no_pin else cores // max(1, world)))
+    if args.host_threads:
+        pk_threads = max(1, args.host_threads)
 
     # The gather (BASELINE config 3 "RCCL gather of decoded messages"): with more than one rank every batch's packed results go to
     # rank 0 inside the step -- submit() after the fetch of batch k-1, while batch k computes; the last one is drained before the

@@ -427,6 +427,15 @@ class Receiver:
         # streaming: also decode the partial cycle when these hops have arrived (320 = 12.8 s, 340 = 13.6 s into the cycle), so that
         # most messages are delivered before the next cycle starts, as the reference's are (its first decodes appear at ~12.9 s,
         # tests/PyFT8.txt:1-19); one hop, a sequence of hops, or None / 0 / () = only at the end of the cycle
+        if isinstance(early_decode_hop, str):
+            # "incremental": the reference starts on each candidate as soon as its payload has arrived (manage_cycle polls every 0.1 s from
+            # hop 260, receiver.py:389-401); here the partial cycle is decoded every 5 hops (0.2 s) from hop 300 -- the payload of a signal
+            # that starts at 0 s is complete at hop 296 -- so every message is delivered within 0.2 s of its last payload symbol
+            if early_decode_hop != "incremental":
+                raise _lib.Ft8rxError('early_decode_hop: a hop, a sequence of hops, None or "incremental"')
+            early_decode_hop = tuple(range(300, 375, 5))
+        if isinstance(early_decode_hop, range):
+            early_decode_hop = tuple(early_decode_hop)
         hops = early_decode_hop if isinstance(early_decode_hop, (tuple, list)) else ((early_decode_hop,) if early_decode_hop else ())
         hops = tuple(sorted({int(x) for x in hops}))
         if any(not 300 <= x < 375 for x in hops):

@@ -6,6 +6,7 @@
 //   make -C oracle asan && oracle/_build/asan_host [dump.bin]
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <random>
 #include "../include/ft8rx.h"
 #include "../pyft8_amd/csrc/ft8_tables.h"
@@ -65,6 +66,53 @@ int main(int argc, char** argv) {
             if (mc[0] > 0) ms[0].cand = 30000;
             const int most = hostmsg::subtraction_list(ms.data(), mc.data(), MC, R.data(), MC, B, -30, sg.data(), 4, sc.data());
             if (most > 4 || sc[0] > 4) return 9;
+        }
+        {   // packed results (multi-GPU gather format): a packed copy of the same frames renders the same messages; cut, corrupted and
+            // random-offset buffers are refused or survive without touching memory outside the buffer
+            std::vector<unsigned char> pk;
+            {
+                std::vector<ft8rx_packed_frame> tab(B);
+                std::vector<ft8rx_record> pr; std::vector<ft8rx_event> pe;
+                for (int b = 0; b < B; b++) {
+                    std::vector<char> keep(MC, 0);
+                    for (int i = 0; i < n; i++) keep[i] = rec[i].status == FT8RX_ST_DECODED;
+                    for (int i = 0; i < nev; i++) if (ev[i].cand < n) keep[ev[i].cand] = 1;
+                    tab[b].rec_off = (int32_t)pr.size(); tab[b].ev_off = (int32_t)pe.size(); tab[b].n_cand = (uint16_t)n; tab[b].n_ev = nev;
+                    int k = 0;
+                    for (int i = 0; i < n; i++) if (keep[i]) { ft8rx_record r = rec[i]; r.pad2 = (uint32_t)i; pr.push_back(r); k++; }
+                    tab[b].n_rec = (uint16_t)k;
+                    pe.insert(pe.end(), ev.begin(), ev.begin() + nev);
+                }
+                ft8rx_packed_header hd; memset(&hd, 0, sizeof hd);
+                hd.magic = FT8RX_PACKED_MAGIC; hd.n_frames = B; hd.n_records = (int32_t)pr.size(); hd.n_events = (int32_t)pe.size(); hd.max_cands = MC;
+                hd.bytes = sizeof(hd) + sizeof(ft8rx_packed_frame) * B + sizeof(ft8rx_record) * pr.size() + sizeof(ft8rx_event) * pe.size();
+                pk.resize(hd.bytes);
+                unsigned char* q = pk.data();
+                memcpy(q, &hd, sizeof hd); q += sizeof hd;
+                memcpy(q, tab.data(), sizeof(ft8rx_packed_frame) * B); q += sizeof(ft8rx_packed_frame) * B;
+                memcpy(q, pr.data(), sizeof(ft8rx_record) * pr.size()); q += sizeof(ft8rx_record) * pr.size();
+                memcpy(q, pe.data(), sizeof(ft8rx_event) * pe.size());
+            }
+            std::vector<ft8rx_message> dense((size_t)B * MC), packed((size_t)B * MC);
+            std::vector<int32_t> dc(B), pc(B);
+            if (hostmsg::package_batch(R.data(), std::vector<int32_t>(B, n).data(), E.data(), std::vector<int32_t>(B, nev).data(), B, MC, dense.data(), MC, dc.data(), 3, nullptr, fl.data())) return 3;
+            if (hostmsg::package_packed(pk.data(), pk.size(), 0, B, packed.data(), MC, pc.data(), 3, nullptr, fl.data())) return 10;
+            if (dc != pc || memcmp(dense.data(), packed.data(), sizeof(ft8rx_message) * dense.size())) return 11;
+            if (hostmsg::package_packed(pk.data(), pk.size() - 1, 0, B, packed.data(), MC, pc.data(), 1, nullptr, nullptr) != -1) return 12;     // cut short
+            if (hostmsg::package_packed(pk.data(), pk.size(), 1, B, packed.data(), MC, pc.data(), 1, nullptr, nullptr) != -1) return 12;         // frames beyond the batch
+            for (int t = 0; t < 2000; t++) {                                    // corrupted headers / frame tables: -1 or a clean run, never a stray access
+                std::vector<unsigned char> bad(pk);
+                const size_t where = rng() % (sizeof(ft8rx_packed_header) + sizeof(ft8rx_packed_frame) * B);
+                bad[where] ^= (unsigned char)(1u << (rng() % 8));
+                if (t % 3 == 0) bad[rng() % (sizeof(ft8rx_packed_header) + sizeof(ft8rx_packed_frame) * B)] = (unsigned char)rng();
+                hostmsg::package_packed(bad.data(), bad.size(), 0, B, packed.data(), MC, pc.data(), 2, nullptr, fl.data());
+            }
+            for (int t = 0; t < 300; t++) {                                     // corrupted records / events (candidate indices, counts in pad2): contents are untrusted too
+                std::vector<unsigned char> bad(pk);
+                const size_t lo = sizeof(ft8rx_packed_header) + sizeof(ft8rx_packed_frame) * B;
+                for (int r = 0; r < 8; r++) bad[lo + rng() % (bad.size() - lo)] = (unsigned char)rng();
+                hostmsg::package_packed(bad.data(), bad.size(), 0, B, packed.data(), MC, pc.data(), 2, nullptr, fl.data());
+            }
         }
         printf("frame dump: %d candidates, %d events, %d messages per frame\n", n, nev, (int)(total / B));
     }

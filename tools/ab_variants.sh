@@ -6,7 +6,7 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out; mkdir -p "$OUT"
 for L in "$@"; do
   N=$(basename "$L" .so)
-  FT8RX_LIB=$PWD/$L timeout 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-entry > "$OUT/${TAG}_${N}.json" 2> "$OUT/${TAG}_${N}.err" || echo "$N failed: $(tail -3 $OUT/${TAG}_${N}.err)"
+  FT8RX_LIB=$PWD/$L timeout 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-entry --no-other-configs > "$OUT/${TAG}_${N}.json" 2> "$OUT/${TAG}_${N}.err" || echo "$N failed: $(tail -3 $OUT/${TAG}_${N}.err)"
 done
 python3 - "$TAG" "$@" <<'PY'
 import json, sys, os

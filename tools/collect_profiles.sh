@@ -8,11 +8,11 @@ TAG=${1:-r04}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0"
+BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0 --no-other-configs"
 
 timeout 900 python3 bench.py > "$OUT/${TAG}_bench_b256_default.json" 2> "$OUT/${TAG}_bench_b256_default.err"
-timeout 600 python3 bench.py --streams 4 --no-cpu-baseline > "$OUT/${TAG}_bench_b256_s4.json" 2>> "$OUT/${TAG}_bench_b256_default.err"
-timeout 600 python3 bench.py --streams 1 --no-cpu-baseline > "$OUT/${TAG}_bench_b256_s1.json" 2>> "$OUT/${TAG}_bench_b256_default.err"
+timeout 600 python3 bench.py --streams 4 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_b256_s4.json" 2>> "$OUT/${TAG}_bench_b256_default.err"
+timeout 600 python3 bench.py --streams 1 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_b256_s1.json" 2>> "$OUT/${TAG}_bench_b256_default.err"
 
 rm -rf "$OUT/${TAG}_stats" "$OUT/${TAG}_pmcF" "$OUT/${TAG}_pmcW"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -o s -- $BENCH > "$OUT/${TAG}_stats.log" 2>&1
