@@ -140,11 +140,13 @@ class PackedGather:
         parts = g.collect()                          # rank dst: [Packed of rank 0, rank 1, ...] of the oldest submitted batch; else None
 
     At most two gathers are in flight (the handle has two result slots); submit() first completes the one that used the same slot.
-    per_frame: bytes of records + events reserved per frame (default 12 KB; the worst case is 48 max_cands + 12 KB, config-1 frames
-    use ~4 KB); a batch that does not fit raises instead of being cut.  repeat > 1 (measurement aid) gathers every batch `repeat`
-    times into distinct buffers: rank dst's receive + D2H load of `repeat` ranks in a one-rank group."""
+    per_frame: bytes of records + events reserved per frame in each rank's two pack buffers (default None = the worst case, 48 max_cands
+    + 12 KB: a batch always fits; config-1 frames use ~6 KB, and a smaller figure makes an oversized batch raise instead of being
+    cut).  Rank dst's receive and page-locked buffers are sized from the byte counts actually seen (twice the first batch's, grown if
+    a later batch needs more), not from the capacity.  repeat > 1 (measurement aid) gathers every batch `repeat` times into distinct
+    buffers: rank dst's receive + D2H load of `repeat` ranks in a one-rank group."""
 
-    def __init__(self, handle, n_frames, dst=0, group=None, force=False, per_frame=12288, repeat=1):
+    def __init__(self, handle, n_frames, dst=0, group=None, force=False, per_frame=None, repeat=1):
         from . import _lib
         self._lib, self.h, self.B, self.dst, self.group, self.repeat = _lib, handle, int(n_frames), dst, group, max(1, int(repeat))
         self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
@@ -171,20 +173,34 @@ class PackedGather:
             self.stream = torch.cuda.Stream(device=dev)
             self.src = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(2)]
             ptrs = [t.data_ptr() for t in self.src]
-            if self.rank == dst:
-                n = self.world * self.repeat
-                self.recv = [torch.empty((n, self.cap), dtype=torch.uint8, device=dev) for _ in range(2)]
-                self.host = [torch.empty((n, self.cap), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self.recv = self.host = None               # rank dst: allocated by _room() from the first batch's byte counts
+            self.row = 0
         else:
             # host path (gloo, or no process group at all): the pack kernels write page-locked host memory directly
             self.stream = None
             self._pin = [handle.pinned_bytes(self.cap) for _ in range(2)]
             self.src = [torch.from_numpy(a) for a in self._pin]
             ptrs = [a.ctypes.data for a in self._pin]
-            if self.active and self.rank == dst:
-                n = self.world * self.repeat
-                self.host = [torch.empty((n, self.cap), dtype=torch.uint8) for _ in range(2)]
+            self.recv = self.host = None
+            self.row = 0
         handle.set_packed_output(ptrs[0], ptrs[1], self.cap)
+
+    def _room(self, m):
+        """Rank dst: receive (nccl) and host buffers with rows of at least m bytes for world x repeat parts, two sets (one per result
+        slot).  Sized to twice the first batch's largest part; a later batch that needs more first waits for the gathers in flight."""
+        if m <= self.row:
+            return
+        while self.pending:
+            self._done = self._finish(self.pending.pop(0))
+        self.row = min(self.cap, max(2 * m, 1 << 20))
+        self.row = (self.row + 255) & ~255
+        n = self.world * self.repeat
+        if self.nccl:
+            dev = self.src[0].device
+            self.recv = [torch.empty((n, self.row), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.host = [torch.empty((n, self.row), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        else:
+            self.host = [torch.empty((n, self.row), dtype=torch.uint8) for _ in range(2)]
 
     def close(self):
         self.drain()
@@ -237,6 +253,8 @@ class PackedGather:
             sizes = [int(x.item()) for x in lst]
         mark("sizes")
         n = self.world * self.repeat
+        if self.rank == self.dst:
+            self._room((max(sizes) + 255) & ~255)
         if self.nccl:
             with torch.cuda.stream(self.stream):
                 m = (max(sizes) + 255) & ~255
