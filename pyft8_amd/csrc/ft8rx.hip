@@ -761,6 +761,8 @@ int ft8rx_set_packed_output(ft8rx_handle* h, void* d_buf0, void* d_buf1, uint64_
     for (int k = 0; k < 2; k++) {               // page-locked host memory is addressed through its device pointer
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, in[k]) != hipSuccess) { (void)hipGetLastError(); set_err(h, "ft8rx_set_packed_output: buffer %d is neither device nor page-locked host memory", k); return -1; }
+        if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeHost && at.type != hipMemoryTypeManaged) {      // e.g. plain malloc memory: the kernels could not write it
+            set_err(h, "ft8rx_set_packed_output: buffer %d is ordinary host memory; use device memory or ft8rx_alloc_host", k); return -1; }
         dev[k] = (unsigned char*)(at.type == hipMemoryTypeHost ? at.devicePointer : in[k]);
         if (!dev[k] || ((uintptr_t)dev[k] & 15)) { set_err(h, "ft8rx_set_packed_output: buffer %d is not device-accessible / 16-byte aligned", k); return -1; }
     }

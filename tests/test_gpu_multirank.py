@@ -205,6 +205,10 @@ def test_packed_results_equal_the_numpy_twin_of_fetch():
         assert hdr["overflow"] and hdr["bytes"] == len(_lib.pack_results(*res)) and not dev[which][32 + 16 * B:].any()
         with pytest.raises(_lib.Ft8rxError):
             _lib.Packed(dev[which].cpu().numpy())
+        # ordinary (pageable) host memory is refused: the kernels could not write it
+        plain = [np.zeros(cap, np.uint8) for _ in range(2)]
+        with pytest.raises(_lib.Ft8rxError, match="packed_output"):
+            h.set_packed_output(plain[0].ctypes.data, plain[1].ctypes.data, cap)
         # off again
         h.set_packed_output(None, None, 0)
         h.enqueue(ptr, B)
