@@ -186,6 +186,11 @@ int  ft8rx_set_packed_output(ft8rx_handle* h, void* d_buf0, void* d_buf1, uint64
 /* The packed output of the batch the last ft8rx_fetch_results / _view / ft8rx_decode_batch call returned (that call has waited for
  * it): which of the two buffers (0 / 1) and a copy of its header.  -1 if no packed output was set when that batch was enqueued. */
 int  ft8rx_packed_results(ft8rx_handle* h, int32_t* which, ft8rx_packed_header* header);
+/* A consumer that reads packed buffer `which` (0 / 1) ASYNCHRONOUSLY on a stream of its own (an RCCL send) hands over a HIP event
+ * (hipEvent_t) recorded on that stream behind its last read: the next batch that packs into this buffer -- two enqueues later --
+ * makes its pack kernels wait for the event on the device.  One pending fence per buffer; the event must stay alive until that
+ * batch has been enqueued.  NULL clears it. */
+int  ft8rx_packed_output_fence(ft8rx_handle* h, int which, void* hip_event);
 /* Host side (no GPU needed): messages of frames [frame_lo, frame_lo + n_frames) of a packed buffer, as ft8rx_package_batch renders
  * them from the dense arrays (n_threads / table / flags as there); out [n_frames][max_msgs].  Returns -1 for a malformed or
  * overflowed buffer. */

@@ -331,6 +331,13 @@ class Handle:
         self._chk(L.ft8rx_set_packed_output(self._h, C.c_void_p(buf0 or None), C.c_void_p(buf1 or None), C.c_uint64(int(cap_bytes))),
                   "ft8rx_set_packed_output")
 
+    def packed_fence(self, which, hip_event):
+        """ft8rx_packed_output_fence: the next batch that packs into buffer `which` waits (on the device) for this HIP event, e.g.
+        torch.cuda.Event(...).cuda_event recorded behind an asynchronous send of the buffer."""
+        L = self._L
+        L.ft8rx_packed_output_fence.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(L.ft8rx_packed_output_fence(self._h, int(which), C.c_void_p(hip_event or None)), "ft8rx_packed_output_fence")
+
     def packed_results(self):
         """ft8rx_packed_results: (which of the two packed buffers, its header as a dict) for the batch the last fetch returned."""
         which = C.c_int32()

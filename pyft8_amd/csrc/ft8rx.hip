@@ -121,6 +121,7 @@ struct ft8rx_handle {
     // pack kernels and a page-locked mirror of each slot's header
     unsigned char* pk_buf[2]; uint64_t pk_cap; uint64_t* d_pkneed; int32_t* d_pknrec;
     ft8rx_packed_header* h_pkhdr[2]; ft8rx_packed_header* d_pkhdr[2]; bool slot_packed[2]; int fetched_slot;
+    hipEvent_t pk_fence[2];                      // ft8rx_packed_output_fence: the consumer's "done reading this buffer" event
     // signal subtraction (extension, allocated on first use): float32 working copy, per-chunk partial sums, GFSK tables
     float* d_wf; double2* d_part; double* d_pulse; double* d_pc; ft8rx_subsig* d_sigs; int32_t* d_sigcnt; int sig_cap;
     float2 *d_zdec, *d_model, *d_adec; SubdCtx* d_subctx;      // decimated-baseband refinement (refine = 2), allocated on first use
@@ -291,7 +292,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
     h->d_colmask = nullptr; h->use_mask = false;
     h->pk_buf[0] = h->pk_buf[1] = nullptr; h->pk_cap = 0; h->d_pkneed = nullptr; h->d_pknrec = nullptr; h->fetched_slot = -1;
-    for (int k = 0; k < 2; k++) { h->h_pkhdr[k] = nullptr; h->d_pkhdr[k] = nullptr; h->slot_packed[k] = false; }
+    for (int k = 0; k < 2; k++) { h->h_pkhdr[k] = nullptr; h->d_pkhdr[k] = nullptr; h->slot_packed[k] = false; h->pk_fence[k] = nullptr; }
     h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr; h->d_ones = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
@@ -630,6 +631,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     }
     h->slot_packed[slot] = h->pk_buf[slot] != nullptr;
     if (h->slot_packed[slot]) {                              // packed results for a gather: header | frame table | kept records | used events
+        if (h->pk_fence[slot]) { HIPCHK(h, hipStreamWaitEvent(fin, h->pk_fence[slot], 0)); h->pk_fence[slot] = nullptr; }      // the consumer's asynchronous read of this buffer
         k_pack_count<<<B, 256, 0, fin>>>(h->s_rec[slot], h->s_ncand[slot], h->s_ev[slot], h->s_evcount[slot], h->d_pkneed, h->d_pknrec);
         k_pack_scan<<<1, 1024, 0, fin>>>(h->d_pknrec, h->s_ncand[slot], h->s_evcount[slot], B, mc, (unsigned long long)h->pk_cap, h->pk_buf[slot], h->d_pkhdr[slot]);
         k_pack_write<<<B, 256, 0, fin>>>(h->s_rec[slot], h->s_ev[slot], h->d_pkneed, B, h->pk_buf[slot]);
@@ -753,6 +755,7 @@ int ft8rx_set_packed_output(ft8rx_handle* h, void* d_buf0, void* d_buf1, uint64_
     if (!h) return -1;
     ENTER(h);                                   // batches in flight keep the buffers they were enqueued with
     HIPCHK(h, hipStreamSynchronize(h->copy_s));
+    h->pk_fence[0] = h->pk_fence[1] = nullptr;
     if (!d_buf0 && !d_buf1) { h->pk_buf[0] = h->pk_buf[1] = nullptr; h->pk_cap = 0; return 0; }
     if (!d_buf0 || !d_buf1 || d_buf0 == d_buf1 || cap_bytes < sizeof(ft8rx_packed_header)) {
         set_err(h, "ft8rx_set_packed_output: two distinct buffers of at least %zu bytes each are needed", sizeof(ft8rx_packed_header)); return -1; }
@@ -777,6 +780,12 @@ int ft8rx_set_packed_output(ft8rx_handle* h, void* d_buf0, void* d_buf1, uint64_
         }
     }
     h->pk_buf[0] = dev[0]; h->pk_buf[1] = dev[1]; h->pk_cap = cap_bytes;
+    return 0;
+}
+
+int ft8rx_packed_output_fence(ft8rx_handle* h, int which, void* hip_event) {
+    if (!h || which < 0 || which > 1) return -1;
+    h->pk_fence[which] = (hipEvent_t)hip_event;
     return 0;
 }
 

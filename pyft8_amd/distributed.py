@@ -154,7 +154,8 @@ class PackedGather:
         self.rank = dist.get_rank(group) if self.active else 0
         self.nccl = self.active and dist.get_backend(group) == "nccl"
         self.cap = (_lib.packed_capacity(self.B, handle.cfg.max_cands, per_frame) + 255) & ~255
-        self.pending = []                  # (slot, sizes, event-or-None) in submit order
+        self.pending = []                  # (slot, sizes, event-or-None, part stride) in submit order
+        self._fence = [None, None]         # keeps the event handed to ft8rx_packed_output_fence alive
         self.seconds = []                  # host time spent inside submit() per call (the size exchange blocks; the rest is asynchronous)
         self.phases = []                   # the same, split: header / wait_slot (the gather two batches ago) / sizes / issue
         # the byte counts are exchanged on the host (a gloo group next to the RCCL one): a device-side exchange would make every
@@ -267,6 +268,9 @@ class PackedGather:
                     self.host[slot].view(-1)[:n * m].copy_(flat[:n * m], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
+                # the pack kernels that next write this slot's buffer (two enqueues from now) wait for the send on the device
+                self._fence[slot] = ev
+                self.h.packed_fence(slot, ev.cuda_event)
                 mark("issue")
         else:
             m = max(sizes)
