@@ -218,6 +218,34 @@ def test_packed_results_equal_the_numpy_twin_of_fetch():
         h.close()
 
 
+def test_packed_results_edge_cases():
+    """Packed results for the shapes the config-1 test does not reach: frames with no candidate at all (silence) next to busy ones,
+    one-frame batches, max_cands = 256 (every lane of the pack kernels' masks in use), the wide-layout build, and extension knobs that
+    log many events per frame -- always byte-identical to the numpy twin of the same batch's fetch(), and rendering the same messages."""
+    import torch
+    from pyft8_amd import _lib, synth
+    busy = np.stack([synth.make_frame(9100 + i, n_signals=60, snr_range=(-6.0, 12.0)) for i in range(3)])
+    audio = np.concatenate([np.zeros((2, _lib.NSAMP), np.int16), busy, np.zeros((1, _lib.NSAMP), np.int16)])
+    cases = [dict(), dict(max_cands=256, sync_score_min=60.0), dict(f0_hi=1888), dict(osd_triple=20, osd_max_hd=40, bp_iters_b=30)]
+    for kw in cases:
+        for B in (len(audio), 1):
+            h = _lib.Handle(_lib.default_config(**kw), max_frames=B)
+            cap = _lib.packed_capacity(B, h.cfg.max_cands)
+            dev = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            h.set_packed_output(dev[0].data_ptr(), dev[1].data_ptr(), cap)
+            res = h.decode_batch(audio[2:2 + B] if B == 1 else audio)
+            which, hdr = h.packed_results()
+            want = _lib.pack_results(*res)
+            got = dev[which][:hdr["bytes"]].cpu().numpy()
+            assert hdr["bytes"] == len(want) and got.tobytes() == want.tobytes(), (kw, B)
+            pk = _lib.Packed(got)
+            if B > 1:
+                assert int(pk.frames["n_rec"][0]) == 0 and int(pk.frames["n_cand"][0]) == 0 and int(pk.frames["n_rec"][2]) > 20
+            m1, m2 = _lib.package_batch(*res), _lib.package_packed(pk)
+            assert m1[0].tobytes() == m2[0].tobytes() and np.array_equal(m1[1], m2[1]) and int(m1[1].sum()) >= (10 if B > 1 else 3)
+            h.close()
+
+
 def test_eight_ranks_one_gpu_gloo_uneven_total():
     """What the 8-GPU node will run cold, at world size 8 on the one GPU of a test box (gloo; RCCL refuses several ranks per device):
     bench.py's whole N > 1 flow with an UNEVEN total (8 x 16 + 3 frames: shard() gives the first three ranks one more), per-rank
