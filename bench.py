@@ -227,9 +227,9 @@ def place_rank(local_rank, world, bus_id_of):
 
 
 OTHER_CONFIGS = {      # BASELINE.json configs 2-4 per GPU, as `--config N` runs them; steps chosen so that the un-overlapped last fetch weighs < 2 %
-    2: dict(frames=4096, signals=50, snr=(-10.0, 10.0), knobs=dict(bp_iters_b=30, osd_single=30, osd_double=2), steps=4,
+    2: dict(frames=4096, signals=50, snr=(-10.0, 10.0), knobs=dict(bp_iters_b=30, osd_single=30, osd_double=2), steps=6,
             what="4096 frames, LDPC BP 30 iterations + OSD depth 2"),
-    3: dict(frames=8192, signals=50, snr=(-10.0, 10.0), knobs={}, steps=3, what="one rank's 8192-frame shard of the 65 536-frame job, Receiver defaults"),
+    3: dict(frames=8192, signals=50, snr=(-10.0, 10.0), knobs={}, steps=5, what="one rank's 8192-frame shard of the 65 536-frame job, Receiver defaults"),
     4: dict(frames=2048, signals=10, snr=(-24.0, -20.0), knobs=dict(osd_triple=30, osd_max_hd=32), steps=24,
             what="2048 frames per GPU, 10 signals at -24..-20 dB, OSD order 3 over 30 positions with the distance gate at 32"),
 }
