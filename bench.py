@@ -263,6 +263,11 @@ def run_other_config(n, device, rank, pk_threads, streams):
         msgs, mcnt = steps(c["steps"])
         h.sync()
         dt = time.perf_counter() - t0
+        t1 = time.perf_counter()                     # kernels only (no D2H wait, no host layer), pipelined over the chunk streams like the timed loop
+        for _ in range(c["steps"]):
+            h.enqueue(d_audio.data_ptr(), B)
+        h.sync()
+        kernel_only = B * c["steps"] / (time.perf_counter() - t1)
         h.set_profiling(True)
         samples = {}
         for _ in range(3):
@@ -276,7 +281,7 @@ def run_other_config(n, device, rank, pk_threads, streams):
         achieved = ALG_BYTES[dom] * B / (acc[dom] * 1e-3) / 1e9
         return {"workload": c["what"], "value": B * c["steps"] / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / c["steps"], "steps": c["steps"],
                 "frames_per_gpu": B, "messages_per_frame": float(mcnt.mean()), "stage_ms": {k: round(v, 4) for k, v in acc.items()},
-                "kernels_only_frames_per_s": B / (sum(acc.values()) * 1e-3),
+                "kernels_only_frames_per_s": kernel_only, "stage_sum_frames_per_s": B / (sum(acc.values()) * 1e-3),
                 "roofline": {"kernel": dom, "kernel_ms": acc[dom], "achieved": achieved, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "traffic": pmc_traffic(dom, n), "whole_path_frac": B * c["steps"] / dt * ALG_BYTES_FRAME / 1e9 / HBM_PEAK_GBS},
                 "setup_s": round(setup_s, 2)}
