@@ -1197,6 +1197,12 @@ def test_streaming_incremental_delivery_like_manage_cycle():
         h0 = int(round((d["tsec"] - (int(d["tweaks"].split("t:")[1].split()[0]) / 200.0 if "t:" in d["tweaks"] else 0.0)) * 25))
         t_payload = (h0 + 4 + 4 * 72 + 4) * 0.04                      # arrival of the hop after the last payload symbol
         assert t_payload - 1e-9 <= t <= max(t_payload, 12.0) + 0.2 + 0.04 + 1e-9, (t, t_payload, d["tsec"], d["tweaks"])      # (first pass: hop 300 = 12.0 s)
+    # stop() released both GPU handles; the receiver re-creates what a later call needs
+    assert rx._h is None and rx._live is None
+    again = rx.decode_frames(audio[None])
+    assert [" ".join(m["msg_tuple"]) for m in again[0]] == ref_txt and rx._h is not None
+    rx.close()
+    assert rx._h is None
     print(f"incremental: {len(early)} of {len(ref_txt)} messages before the end of the cycle, at " + ", ".join(f"{t:.1f}" for t in sorted({t for t, _ in early})) + " s")
 
 
