@@ -459,7 +459,7 @@ def main():
         if gather is not None:
             gather.submit()
             if args.render_gathered and rank == 0:
-                parts = gather.collect() if len(gather.pending) > 1 else None      # the batch before: its gather has landed
+                parts = gather.collect() if gather.outstanding() > 1 else None      # the batch before: its gather has landed
                 for pk in parts or []:
                     rendered[0] += int(_lib.package_packed(pk, n_threads=pk_threads)[1].sum())
         return _lib.package_batch(*view, n_threads=pk_threads)

@@ -146,6 +146,8 @@ class PackedGather:
     a later batch needs more), not from the capacity.  repeat > 1 (measurement aid) gathers every batch `repeat` times into distinct
     buffers: rank dst's receive + D2H load of `repeat` ranks in a one-rank group."""
 
+    MIN_ROW = 1 << 20          # smallest receive row rank dst allocates (bytes); tests lower it to reach the growth path with small frames
+
     def __init__(self, handle, n_frames, dst=0, group=None, force=False, per_frame=None, repeat=1):
         from . import _lib
         self._lib, self.h, self.B, self.dst, self.group, self.repeat = _lib, handle, int(n_frames), dst, group, max(1, int(repeat))
@@ -156,6 +158,7 @@ class PackedGather:
         self.cap = (_lib.packed_capacity(self.B, handle.cfg.max_cands, per_frame) + 255) & ~255
         self.pending = []                  # (slot, sizes, event-or-None, part stride) in submit order
         self._fence = [None, None]         # keeps the event handed to ft8rx_packed_output_fence alive
+        self.ready, self._last = [], None  # completed gathers not collected yet (oldest first); the most recent result
         self.seconds = []                  # host time spent inside submit() per call (the size exchange blocks; the rest is asynchronous)
         self.phases = []                   # the same, split: header / wait_slot (the gather two batches ago) / sizes / issue
         # the byte counts are exchanged on the host (a gloo group next to the RCCL one): a device-side exchange would make every
@@ -192,8 +195,8 @@ class PackedGather:
         if m <= self.row:
             return
         while self.pending:
-            self._done = self._finish(self.pending.pop(0))
-        self.row = min(self.cap, max(2 * m, 1 << 20))
+            self._retire()
+        self.row = min(self.cap, max(2 * m, self.MIN_ROW))
         self.row = (self.row + 255) & ~255
         n = self.world * self.repeat
         if self.nccl:
@@ -233,7 +236,7 @@ class PackedGather:
             raise self._lib.Ft8rxError(f"PackedGather: a batch needs {hdr['bytes']} packed bytes, the buffers hold {self.cap} (raise per_frame)")
         mark("header")
         while any(p[0] == slot for p in self.pending):          # the gather that last used this slot's buffers
-            self._done = self._finish(self.pending.pop(0))
+            self._retire()
         mark("wait_slot")
         self.phases.append(ph)
         nbytes = int(hdr["bytes"])
@@ -283,17 +286,30 @@ class PackedGather:
         self.pending.append((slot, sizes, ev, m))
         self.seconds.append(time.perf_counter() - t0)
 
+    def _retire(self):
+        """Complete the oldest gather in flight; its result waits in self.ready (the two most recent are kept) until collected."""
+        res = self._finish(self.pending.pop(0))
+        self.ready.append(res)
+        del self.ready[:-2]
+        self._last = res
+        return res
+
+    def outstanding(self):
+        """Gathers submitted and not yet collected (in flight or completed)."""
+        return len(self.pending) + len(self.ready)
+
     def collect(self):
         """Rank dst: the per-rank Packed views of the OLDEST submitted batch not collected yet (valid until two more submits);
-        other ranks: None.  Waits for that gather."""
-        if not self.pending:
-            return getattr(self, "_done", None)
-        return self._finish(self.pending.pop(0))
+        other ranks: None.  Waits for that gather if it is still in flight; with nothing outstanding: the last result again."""
+        if not self.ready and self.pending:
+            self._retire()
+        if self.ready:
+            return self.ready.pop(0)
+        return self._last
 
     def drain(self):
         """Wait for every gather in flight; -> the last one's result (as collect)."""
-        out = getattr(self, "_done", None)
         while self.pending:
-            out = self._finish(self.pending.pop(0))
-        self._done = out
-        return out
+            self._retire()
+        self.ready.clear()
+        return self._last

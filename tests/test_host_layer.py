@@ -510,24 +510,37 @@ rank, world = dist.get_rank(), dist.get_world_size()
 pool = np.load(sys.argv[2])
 total, nb = int(sys.argv[4]), 3                                 # `total` frames per batch over the ranks (uneven), nb batches
 start, count = shard(total, rank, world)
+grow = len(sys.argv) > 5 and sys.argv[5] == "grow"
 def batch(k):                                                   # global frame g of batch k = pool frame (g + 5 k) % n
     idx = [(start + i + 5 * k) % len(pool["cnt"]) for i in range(count)]
+    if grow and k == 0:
+        idx = [0] * count                                       # the smallest frame only: the later batches need > 2x its bytes
     return pool["rec"][idx], pool["cnt"][idx], pool["ev"][idx], pool["evc"][idx]
 h = FakeHandle([batch(k) for k in range(nb)])
-g = PackedGather(h, shard(total, 0, world)[1], dst=0)
+if grow:
+    PackedGather.MIN_ROW = 1024                                 # rank 0's receive rows start at twice the first batch's largest part
+g = PackedGather(h, shard(total, 0, world)[1], dst=0, repeat=2 if grow else 1)
+rows = []
 got = []
 for k in range(nb):                                             # the bench loop's order: fetch k, submit k, (collect k - 1)
     h.fetch()
     g.submit()
+    rows.append(g.row)
     if k > 0:
         parts = g.collect()
         if rank == 0:
+            parts = parts[:world]                               # (repeat = 2 delivers every part twice)
             got.append([[" ".join(x.decode() for x in m["f"]) for m in ms[:n]] for p in parts for ms, n in zip(*_lib.package_packed(p))])
             assert [p.n_frames for p in parts] == [shard(total, r, world)[1] for r in range(world)]
         else:
             assert parts is None
 parts = g.drain()
 if rank == 0:
+    assert len(parts) == world * (2 if grow else 1)
+    if grow:
+        assert rows[1] > rows[0] > 0, rows                      # the receive buffers were re-allocated while a gather was in flight
+        assert all(a.buf.tobytes() == b.buf.tobytes() for a, b in zip(parts[:world], parts[world:]))
+    parts = parts[:world]
     got.append([[" ".join(x.decode() for x in m["f"]) for m in ms[:n]] for p in parts for ms, n in zip(*_lib.package_packed(p))])
     json.dump(got, open(sys.argv[3], "w"))
 g.close()
@@ -535,11 +548,12 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,total", [(2, 5), (8, 8 * 2 + 3)])
-def test_packed_gather_gloo_uneven_shards(tmp_path, world, total):
+@pytest.mark.parametrize("world,total,mode", [(2, 5, ""), (8, 8 * 2 + 3, ""), (3, 7, "grow")])
+def test_packed_gather_gloo_uneven_shards(tmp_path, world, total, mode):
     """PackedGather over gloo at world sizes 2 and 8 (the rank-count-dependent paths: uneven shard() blocks, byte counts that differ
     per rank, padded gather, two gathers in flight) on CPU with a stand-in handle that packs oracle records: rank 0 ends up with every
-    rank's frames in shard order, batch after batch, and renders the golden messages from the packed form."""
+    rank's frames in shard order, batch after batch, and renders the golden messages from the packed form.  "grow": the first batch is
+    small, so rank 0's receive buffers (sized from the byte counts seen) are re-allocated while a gather is in flight; repeat = 2."""
     from pyft8_amd import _lib
     names = ["synth_200000", "test_09", "synth_100000", "test_08", "synth_000000"]
     rec, cnt, ev, evc = _dense_goldens(names)
@@ -548,13 +562,13 @@ def test_packed_gather_gloo_uneven_shards(tmp_path, world, total):
     script.write_text(_PACKED_WORKER)
     out = tmp_path / "out.json"
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                           "--master-port", str(29640 + world), str(script), ROOT, str(tmp_path / "pool.npz"), str(out), str(total)],
+                           "--master-port", str(29640 + world), str(script), ROOT, str(tmp_path / "pool.npz"), str(out), str(total), mode],
                           env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1"), timeout=900, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
     got = json.load(open(out))
     want = [[" ".join(m["msg_tuple"]) for m in load_golden(nm)[2]["messages"]] for nm in names]
     assert len(got) == 3
     for k, batch in enumerate(got):
-        assert batch == [want[(g + 5 * k) % len(names)] for g in range(total)], k
+        assert batch == [want[0 if (mode == "grow" and k == 0) else (g + 5 * k) % len(names)] for g in range(total)], k
 
 
 def test_every_kernel_exists_once():
