@@ -129,6 +129,28 @@ r2, c2, e2, ec2 = pk.expand()
 dec = res[0]["status"] == _lib.ST_DECODED
 assert np.array_equal(c2, res[1]) and np.array_equal(ec2, res[3]) and r2[dec].tobytes() == res[0][dec].tobytes()      # fetch()'s decoded set, byte for byte
 g.close()
+# batch sizes that change from call to call (smaller batches reuse the same pack buffers; the receive rows grow when a larger one comes),
+# collected either at once or one batch late
+rng = np.random.default_rng(3)
+PackedGather.MIN_ROW = 4096
+g = PackedGather(h, B, dst=0, force=True, repeat=2)
+queue = []
+for k in range(24):
+    n = int(rng.integers(1, 40)) if k < 6 else int(rng.integers(1, B + 1))
+    h.enqueue(ptr, n)
+    res = h.fetch(n)
+    g.submit()
+    queue.append(_lib.pack_results(*res))
+    if k % 3 == 0 or g.outstanding() > 1:
+        parts = g.collect()
+        w = queue.pop(0)
+        assert len(parts) == 2 and all(p.buf.tobytes() == w.tobytes() for p in parts), k
+while queue:
+    parts = g.collect()
+    w = queue.pop(0)
+    assert all(p.buf.tobytes() == w.tobytes() for p in parts)
+assert g.outstanding() == 0
+g.close()
 via_host = gather_results(*want, dst=0, force=True)             # host arrays through the same backend (one H2D per array)
 assert via_host[0].tobytes() == want[0].tobytes() and np.array_equal(via_host[1], want[1])
 # a zero-copy view of the same batch is the same bytes
