@@ -450,9 +450,32 @@ def main():
     # clock stops.  Every rank renders the messages of its own shard (the host layer scales with the ranks); rank 0 holds the
     # packed form of all shards and can render any frame from it (--render-gathered does, for all of them, inside the step).
     gather = None
+    gather_disabled = None
     if (world > 1 or args.force_gather) and not args.no_gather:
         from pyft8_amd.distributed import PackedGather
-        gather = PackedGather(h, max(shard_counts), dst=0, force=args.force_gather, repeat=args.gather_repeat)
+        # set the gather up and push ONE batch through it before anything is timed; if that fails on any rank (a transport missing on
+        # this box, ...) every rank drops the gather -- agreed through one all_reduce -- and the run is still measured, with the reason
+        # in the line, instead of dying inside the timed loop
+        err = None
+        try:
+            gather = PackedGather(h, max(shard_counts), dst=0, force=args.force_gather, repeat=args.gather_repeat)
+            h.enqueue(d_audio.data_ptr(), B)
+            h.fetch_view(B)
+            gather.submit()
+            gather.drain()
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([0 if err else 1], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.int32)
+        if dist.is_initialized() and world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            gather_disabled = err or "the gather failed on another rank"
+            try:
+                if gather is not None:
+                    h.set_packed_output(None, None, 0)
+            except Exception:
+                pass
+            gather = None
     rendered = [0]
 
     def host_side(view):
@@ -563,6 +586,8 @@ def main():
     # the gather ran inside the timed steps; here (outside) rank 0 checks what arrived: one packed part per rank, rank 0's own part
     # against its local results (decoded set byte for byte, messages rendered from the packed form = from the dense arrays)
     gather_note = "single rank: nothing to gather" if not args.no_gather else "gather left out (--no-gather)"
+    if gather_disabled:
+        gather_note = f"GATHER DISABLED, value is without it: {gather_disabled}"
     gather_info = None
     if gather is not None:
         try:
