@@ -465,6 +465,110 @@ static float fine_score_block(const cpx* z, int tb, int sym0) {
     return (float)(s1 + W6 * s2);
 }
 
+/* Score of a NON-ZERO frequency tweak (receiver.py:147-161, 197-206) straight from the spectrum slice, without its time series.
+ * The reference forms z = ifft(S) and scores |fft(z[i0 : i0 + 32])[t]| on the 7 symbols of the middle Costas block.  Substituting one
+ * transform into the other (an exact identity, every one of the 1000 non-zero bins included):
+ *     T[s][t] = 1/3200 sum_k X[k] e^{2 pi i k nb0 / 3200} D(k - 100 t) e^{2 pi i k s / 100},     D(m) = sum_{n < 32} e^{2 pi i n m / 3200},
+ * k = -150 .. 849 the rolled slice's bins (X = tapered spectrum), nb0 = tb + 32 * 36 the block's first sample, s = 0 .. 6.  The last factor
+ * has period 100 in k, so with k = r + 100 j:  H[t][r] = PhR[r] sum_j (X[k] PhJ[j]) D(k - 100 t),  T[s][t] = 1/3200 sum_r H[t][r] E[s][r].
+ * Contract (kernels/fine_sync.hpp: fine_fscore does exactly this, on 100 + 112 lanes):
+ *   tables in double, rounded once: D[m] (m = 0 .. 849; D(-m) = conj D(m)), E[s][r] = e^{2 pi i ((r s) mod 100) / 100};
+ *   PhR[r] = conj W3200[(r nb0) mod 3200], PhJ[j] = conj W3200[100 ((j nb0) mod 32)], W3200 the FFT's twiddle table;
+ *   a[q] = cmul(X[k_q], PhJ[j_q]), q = 0 .. 9 ascending in k (the first and the last are the tapered bins: fp64 product, rounded once);
+ *   H: complex multiply-adds in ascending q, each component  fma(a.re, w.re, fma(-/+ a.im, w.im, acc))  (the named fmas below), then cmul by PhR;
+ *   T: 16 partial sums per (s, t) over r = c, c + 16, ... (s = 0: plain adds, E = 1), combined as the binary tree
+ *      ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) ... ; |T| from the components scaled by 1/3200; fp64 on / off sums as in fine_score_block. */
+static cpx g_D32[850], g_E100[7][100];
+static int g_fs_ok = 0;
+static void make_fscore_tables(void) {
+    for (int m = 0; m < 850; m++) {
+        double re = 0.0, im = 0.0;
+        for (int n = 0; n < 32; n++) { const double a = 2.0 * M_PI * (double)n * (double)m / 3200.0; re += cos(a); im += sin(a); }
+        g_D32[m].re = (float)re; g_D32[m].im = (float)im;
+    }
+    for (int s = 0; s < 7; s++) for (int r = 0; r < 100; r++) {
+        const double a = 2.0 * M_PI * (double)((r * s) % 100) / 100.0;
+        g_E100[s][r].re = (float)cos(a); g_E100[s][r].im = (float)sin(a);
+    }
+    g_fs_ok = 1;
+}
+static float fine_fscore(const float* spec, int fb, int nb0) {
+    if (!g_taper_ok) make_taper();
+    if (!g_fs_ok) make_fscore_tables();
+    const cpx* S = (const cpx*)spec;
+    const cpx* W = get_twiddle(3200);
+    cpx PhR[100], PhJ[11], H[7][100];
+    for (int r = 0; r < 100; r++) { const cpx w = W[(r * nb0) % 3200]; PhR[r].re = w.re; PhR[r].im = -w.im; }
+    for (int i = 0; i < 11; i++) { const int j = i - 2; const int x = (((j * nb0) % 32) + 32) % 32; const cpx w = W[100 * x]; PhJ[i].re = w.re; PhJ[i].im = -w.im; }
+    for (int r = 0; r < 100; r++) {
+        const int jlo = r < 50 ? -1 : -2;
+        cpx a[10];
+        for (int q = 0; q < 10; q++) {
+            const int k = r + 100 * (jlo + q);
+            cpx x = S[fb + k];
+            if (q == 0) { const double t = g_taper[k + 150]; x.re = (float)((double)x.re * t); x.im = (float)((double)x.im * t); }
+            if (q == 9) { const double t = g_taper[k - 750]; x.re = (float)((double)x.re * t); x.im = (float)((double)x.im * t); }
+            a[q] = cmul(x, PhJ[q + jlo + 2]);
+        }
+        for (int t = 0; t < 7; t++) {
+            float hx = 0.0f, hy = 0.0f;
+            for (int q = 0; q < 10; q++) {
+                const int d = jlo + q - t, m = r + 100 * d;
+                if (d >= 0) {
+                    const cpx w = g_D32[m];
+                    hx = fmaf(a[q].re, w.re, fmaf(-a[q].im, w.im, hx));
+                    hy = fmaf(a[q].re, w.im, fmaf(a[q].im, w.re, hy));
+                } else {
+                    const cpx w = g_D32[-m];
+                    hx = fmaf(a[q].re, w.re, fmaf(a[q].im, w.im, hx));
+                    hy = fmaf(a[q].im, w.re, fmaf(-a[q].re, w.im, hy));
+                }
+            }
+            cpx h; h.re = hx; h.im = hy;
+            H[t][r] = cmul(h, PhR[r]);
+        }
+    }
+    float mag[7][7];
+    for (int t = 0; t < 7; t++) {
+        cpx part[7][16];
+        for (int c = 0; c < 16; c++) {
+            cpx acc[7];
+            for (int s = 0; s < 7; s++) { acc[s].re = 0.0f; acc[s].im = 0.0f; }
+            for (int i = 0; i < 7; i++) {
+                const int r = c + 16 * i;
+                if (r >= 100) continue;
+                const cpx h = H[t][r];
+                acc[0].re = acc[0].re + h.re; acc[0].im = acc[0].im + h.im;
+                for (int s = 1; s < 7; s++) {
+                    const cpx e = g_E100[s][r];
+                    acc[s].re = fmaf(h.re, e.re, fmaf(-h.im, e.im, acc[s].re));
+                    acc[s].im = fmaf(h.re, e.im, fmaf(h.im, e.re, acc[s].im));
+                }
+            }
+            for (int s = 0; s < 7; s++) part[s][c] = acc[s];
+        }
+        for (int s = 0; s < 7; s++) {
+            float q4[4][2];
+            for (int g = 0; g < 4; g++) {
+                const cpx* p = &part[s][4 * g];
+                q4[g][0] = (p[0].re + p[1].re) + (p[2].re + p[3].re);
+                q4[g][1] = (p[0].im + p[1].im) + (p[2].im + p[3].im);
+            }
+            const float tr = (q4[0][0] + q4[1][0]) + (q4[2][0] + q4[3][0]), ti = (q4[0][1] + q4[1][1]) + (q4[2][1] + q4[3][1]);
+            const float re = tr * 0.0003125f, im = ti * 0.0003125f;
+            mag[s][t] = sqrtf(re * re + im * im);
+        }
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int a = 0; a < 7; a++) {
+        double off = 0.0;
+        for (int b = 0; b < 7; b++) if (b != COSTAS[a]) off += (double)mag[a][b];
+        s1 += (double)mag[a][COSTAS[a]];
+        s2 += off;
+    }
+    return (float)(s1 + W6 * s2);
+}
+
 void ft8o_fine_grid(const float* spec, const ft8o_config* c, int fb, int tb, float* grid, float* score) {
     cpx* z = (cpx*)malloc(sizeof(cpx) * 3200);
     fine_zsig(spec, c, fb, z);
@@ -486,10 +590,10 @@ int ft8o_fine(const float* spec, const ft8o_config* c, int f0_idx, int h0_idx, i
         if (i == 0 || sc > best) { best = sc; tt = -8 + 2 * i; }
     }
     int ft = 0;
+    const float score_f0 = best;                                     /* f = 0: the time scan's own series and offset */
     for (int i = 0; i < 9; i++) {                                    /* range(-32,33,8) */
         int f = -32 + 8 * i;
-        fine_zsig(spec, c, fb0 + f, z);
-        float sc = fine_score(z, tb0 + tt);
+        float sc = (f == 0) ? score_f0 : fine_fscore(spec, fb0 + f, tb0 + tt + 32 * 36);
         if (i == 0 || sc > best) { best = sc; ft = f; }
     }
     fine_zsig(spec, c, fb0 + ft, z);

@@ -351,6 +351,12 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     host_twiddle(320, 320, w);     rc |= upload(h, &h->T.W320, w);
     host_twiddle(192000, FT8RX_SPEC_BINS, w); rc |= upload(h, &h->T.WR192k, w);
     host_twiddle(32, 32, w);       rc |= upload(h, &h->T.W32, w);
+    {   // tables of the frequency-domain fine score (kernels/fine_sync.hpp: fine_fscore; oracle/ft8_oracle.c: make_fscore_tables -- same formulas)
+        std::vector<cpx> d32(850), e100(700);
+        for (int m = 0; m < 850; m++) { double re = 0.0, im = 0.0; for (int n = 0; n < 32; n++) { const double a = 2.0 * M_PI * (double)n * (double)m / 3200.0; re += cos(a); im += sin(a); } d32[m] = make_float2((float)re, (float)im); }
+        for (int sidx = 0; sidx < 7; sidx++) for (int r = 0; r < 100; r++) { const double a = 2.0 * M_PI * (double)((r * sidx) % 100) / 100.0; e100[sidx * 100 + r] = make_float2((float)cos(a), (float)sin(a)); }
+        rc |= upload(h, &h->T.D32, d32); rc |= upload(h, &h->T.E100, e100);
+    }
     if (rc) { g_create_err = h->err; ft8rx_destroy(h); return -2; }
     // LDPC tables
     bool ok = true;

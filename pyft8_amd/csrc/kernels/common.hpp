@@ -17,6 +17,8 @@ struct Tables {
     const cpx* WR192k;       // [FT8RX_SPEC_BINS]
     const cpx* W32;
     const double* taper;     // [100]
+    const cpx* D32;          // [850]  D(m) = sum_{n<32} e^{+2 pi i n m / 3200}: the 32-sample Dirichlet kernel of the frequency-domain fine score
+    const cpx* E100;         // [7][100] e^{+2 pi i r s / 100}
 };
 
 __device__ __constant__ int d_COSTAS[7] = {3, 1, 4, 0, 6, 5, 2};

@@ -243,6 +243,129 @@ FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, const cpx* wq, float* m
 }
 
 #ifdef FT8RX_ILP_UNIT
+// ---- score of a NON-ZERO frequency tweak straight from the spectrum slice, without its time series (round 4) ----
+// The reference forms z = ifft(S) and scores |fft(z[i0 : i0 + 32])[t]| on the 7 symbols of the middle Costas block (receiver.py:186-206).
+// Substituting one transform into the other -- an exact identity, all 1000 non-zero bins included --
+//   T[s][t] = 1/3200 sum_k X[k] Phi[k] D(k - 100 t) e^{2 pi i k s / 100},   Phi[k] = e^{2 pi i k nb0 / 3200},   D(m) = sum_{n<32} e^{2 pi i n m / 3200},
+// with k = -150 .. 849 the rolled slice's bins, nb0 = the block's first sample.  The last factor has period 100 in k, so with k = r + 100 j:
+//   H[t][r] = PhR[r] sum_j (X[k] PhJ[j]) D(k - 100 t)        (step 1: lane per residue r, 10 bins, 7 tones; every D value loaded once)
+//   T[s][t] = 1/3200 sum_r H[t][r] E[s][r]                   (step 2: 16 lanes per tone, a DPP row sum)
+// 7.7 k complex multiply-adds instead of a pruned 3200-point IFFT and seven symbol DFTs: k_fine 2.50 -> 1.62 ms per 256 frames.  The
+// arithmetic (operation order, named fmas, the reduction tree) is the contract of oracle/ft8_oracle.c: fine_fscore -- bit-exact.
+// Tables in the IFFT image (dead between the time scan and the final transform): D (850), E (7 x 100), PhR (100), PhJ (11: j = -2 .. 8),
+// H (7 x 100), 7 x 8 magnitudes.
+#define FS_D 0
+#define FS_E 850
+#define FS_PHR 1550
+#define FS_PHJ 1650
+#define FS_H 1664
+#define FS_MAG 2364
+FT8_DEV void fscore_prepare(cpx* zi, const Tables& T, int nb0, int tid) {
+    for (int i = tid; i < 850; i += FINE_NT) zi[FS_D + i] = T.D32[i];
+    for (int i = tid; i < 700; i += FINE_NT) zi[FS_E + i] = T.E100[i];
+    if (tid < 100) { const cpx w = T.W3200[(tid * nb0) % 3200]; zi[FS_PHR + tid] = make_float2(w.x, -w.y); }
+    if (tid < 11) { const int j = tid - 2; const int x = (((j * nb0) % 32) + 32) % 32; const cpx w = T.W3200[100 * x]; zi[FS_PHJ + tid] = make_float2(w.x, -w.y); }
+    __syncthreads();
+}
+template <int JLO>
+FT8_DEV void fscore_p1(const cpx* S, int off, const double* __restrict__ taper, const cpx* zi, cpx* H, int r) {
+    cpx a[10];
+#pragma unroll
+    for (int q = 0; q < 10; q++) {
+        const int k = r + 100 * (JLO + q);
+        cpx x = S[off + k];
+        if (q == 0) x = fine_taper(x, taper[k + 150]);
+        if (q == 9) x = fine_taper(x, taper[k - 750]);
+        const cpx w = zi[FS_PHJ + q + JLO + 2];
+        a[q] = make_float2(__builtin_fmaf(x.x, w.x, -(x.y * w.y)), __builtin_fmaf(x.x, w.y, x.y * w.x));
+    }
+    const cpx* Dp = zi + FS_D + r;
+    const cpx* Dn = zi + FS_D - r;
+    const cpx ph = zi[FS_PHR + r];
+    // H_t = sum_q a[q] D(k_q - 100 t), q ascending; walked by d = j - t so that every D value is loaded once (19 loads for the 70 terms):
+    // for a given tone the terms still arrive in ascending q
+    float hx[7], hy[7];
+#pragma unroll
+    for (int t = 0; t < 7; t++) { hx[t] = 0.0f; hy[t] = 0.0f; }
+#pragma unroll
+    for (int d = JLO - 6; d <= JLO + 9; d++) {
+        const cpx w = (d >= 0) ? Dp[100 * (d >= 0 ? d : 0)] : Dn[100 * (d < 0 ? -d : 0)];
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+            const int q = d + t - JLO;
+            if (q >= 0 && q < 10) {
+                if (d >= 0) {
+                    hx[t] = __builtin_fmaf(a[q].x, w.x, __builtin_fmaf(-a[q].y, w.y, hx[t]));
+                    hy[t] = __builtin_fmaf(a[q].x, w.y, __builtin_fmaf(a[q].y, w.x, hy[t]));
+                } else {                                         // D(-m) = conj(D(m))
+                    hx[t] = __builtin_fmaf(a[q].x, w.x, __builtin_fmaf(a[q].y, w.y, hx[t]));
+                    hy[t] = __builtin_fmaf(a[q].y, w.x, __builtin_fmaf(-a[q].x, w.y, hy[t]));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 7; t++)
+        H[t * 100 + r] = make_float2(__builtin_fmaf(hx[t], ph.x, -(hy[t] * ph.y)), __builtin_fmaf(hx[t], ph.y, hy[t] * ph.x));
+}
+FT8_DEV float row16_sum(float v) {                 // sum over the 16 lanes of a DPP row, the same value on every lane: ((p0+p1)+(p2+p3)) + ... as a binary tree
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));      // quad_perm:[1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));      // quad_perm:[2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));     // row_half_mirror (quads hold equal values)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));     // row_mirror (halves hold equal values)
+    return v;
+}
+FT8_DEV float fine_fscore(const cpx* S, int off, const Tables& T, cpx* zi, double* dsum, int tid) {
+    cpx* H = zi + FS_H;
+    float* mags = reinterpret_cast<float*>(zi + FS_MAG);
+    const int lane = tid & 63;
+    if (lane < 50) { if (tid < 64) fscore_p1<-2>(S, off, T.taper, zi, H, 50 + lane); else fscore_p1<-1>(S, off, T.taper, zi, H, lane); }
+    __syncthreads();
+    {
+        const int c = tid & 15, t = tid >> 4;
+        cpx acc[7];
+#pragma unroll
+        for (int s = 0; s < 7; s++) acc[s] = make_float2(0.0f, 0.0f);
+        const int tt_ = t < 7 ? t : 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int r = c + 16 * i;
+            if (i < 6 || c < 4) {
+                const cpx h = H[tt_ * 100 + r];
+                acc[0] = cadd(acc[0], h);
+#pragma unroll
+                for (int s = 1; s < 7; s++) {
+                    const cpx e = zi[FS_E + s * 100 + r];
+                    acc[s].x = __builtin_fmaf(h.x, e.x, __builtin_fmaf(-h.y, e.y, acc[s].x));
+                    acc[s].y = __builtin_fmaf(h.x, e.y, __builtin_fmaf(h.y, e.x, acc[s].y));
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 7; s++) { acc[s].x = row16_sum(acc[s].x); acc[s].y = row16_sum(acc[s].y); }
+        if (t < 7 && c < 7) {
+            cpx v = acc[0];
+#pragma unroll
+            for (int s = 1; s < 7; s++) v = (c == s) ? acc[s] : v;
+            const float re = v.x * FINE_INV, im = v.y * FINE_INV;
+            mags[c * 8 + t] = sqrtf(re * re + im * im);
+        }
+    }
+    __syncthreads();
+    if (tid < 7) {
+        const int cc = d_COSTAS[tid];
+        double off_ = 0.0, on = 0.0;
+#pragma unroll
+        for (int b = 0; b < 7; b++) { const double m = (double)mags[tid * 8 + b]; on = (b == cc) ? m : on; off_ += (b == cc) ? 0.0 : m; }
+        dsum[tid * 2] = on; dsum[tid * 2 + 1] = off_;
+    }
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 7; a++) { s1 += dsum[a * 2]; s2 += dsum[a * 2 + 1]; }
+    return (float)(s1 + W6 * s2);
+}
+
 FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
                             const int32_t* __restrict__ ncand, float* __restrict__ llr0, const Tables& T, const ft8rx_config& cfg,
                             const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
@@ -325,37 +448,21 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     }
     // --- frequency tweaks: range(-32,33,8)
     float best = 0.0f; int ft = 0;
+    fscore_prepare(z, T, tb0 + tt + 32 * 36, tid);            // the time scan is done with the series: the image takes the tables of the frequency scan
 #pragma unroll 1
     for (int i = 0; i < 9; i++) {
         const int fcur = -32 + 8 * i;
-        float s;
-        if (fcur == 0) s = score_f0;             // same series, same offset: identical value
-        else {
-            fine_fft(S, 182 + fcur, z, w400, T, tid, tb0 + tt + 32 * 36, tb0 + tt + 32 * 43 FT_PASS);
-            if (tid < 64) {                       // 7 symbols x 4 lanes on wavefront 0
-                const int qd = tid >> 2, n2 = tid & 3;
-                const bool valid = qd < 7;
-                float mag[8];
-                fine_sym_quad<7>(z, tb0 + tt + 32 * (36 + (valid ? qd : 0)), n2, wq, mag);
-                if (valid && n2 == 0) {
-                    const int c = d_COSTAS[qd];
-                    double off = 0.0, on = 0.0;
-#pragma unroll
-                    for (int b = 0; b < 7; b++) { const double m = (double)mag[b]; on = (b == c) ? m : on; off += (b == c) ? 0.0 : m; }
-                    dsum[qd * 2] = on; dsum[qd * 2 + 1] = off;
-                }
-            }
-            FT(11);
-            __syncthreads();
-            FT(12);
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-            for (int a = 0; a < 7; a++) { s1 += dsum[a * 2]; s2 += dsum[a * 2 + 1]; }
-            s = (float)(s1 + W6 * s2);
-        }
+        const float s = (fcur == 0) ? score_f0                  // same series, same offset: identical value
+                                    : fine_fscore(S, 182 + fcur, T, z, dsum, tid);
         if (i == 0 || s > best) { best = s; ft = fcur; }
     }
-    fine_fft(S, 182 + ft, z, w400, T, tid, 0, 3200 FT_PASS);   // full series for the 79 x 8 grid
+    {   // full series for the 79 x 8 grid.  Nothing thread-specific of the first transform (addresses, twiddles) is to stay alive across the
+        // frequency scan for this one: with the plain `tid` the compiler keeps them, and spills 340 B around the scan (k_fine 2.29 instead of 1.62 ms)
+        int tid2 = tid;
+        asm volatile("" : "+v"(tid2));
+        fine_fft(S, 182 + ft, z, w400, T, tid2, 0, 3200 FT_PASS);
+        sym32_twiddles(w32, tid2 & 3, wq);
+    }
     // the 21 Costas symbols first (84 quad tasks: one round), then the gate; the 58 payload symbols (two rounds) only for the
     // candidates that pass it -- 59 % of the candidates stop here (tools/ladder_stats.py)
     {
