@@ -454,6 +454,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         const int fcur = -32 + 8 * i;
         const float s = (fcur == 0) ? score_f0                  // same series, same offset: identical value
                                     : fine_fscore(S, 182 + fcur, T, z, dsum, tid);
+        FT(11);
         if (i == 0 || s > best) { best = s; ft = fcur; }
     }
     {   // full series for the 79 x 8 grid.  Nothing thread-specific of the first transform (addresses, twiddles) is to stay alive across the

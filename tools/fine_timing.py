@@ -1,4 +1,4 @@
-"""Where the cycles of one fine-sync IFFT go (timing-only build of libft8rx.so with -DFINE_TIMING, see kernels/fine_sync.hpp):
+"""Where the cycles of a fine-sync candidate go (timing-only build of libft8rx.so with -DFINE_TIMING, see kernels/fine_sync.hpp):
 wave 0 of every k_fine block accumulates shader cycles between marks.  Usage on the GPU box:
     python -c "from pyft8_amd import _lib; _lib.build_variant('build/ab/fine_timing.so', ['-DFINE_TIMING'])"
     FT8RX_LIB=build/ab/fine_timing.so python tools/fine_timing.py"""
@@ -13,7 +13,7 @@ from pyft8_amd import _lib  # noqa: E402
 
 NAMES = ["(outside fft: scoring tail of the previous step, loop)", "stage 1: slice loads, radix-8, twiddles, LDS stores", "barrier", "stage 2: LDS loads",
          "barrier", "stage 2: [4,4] butterflies + LDS stores", "barrier", "stage 3: LDS loads", "barrier", "stage 3: [5,5] (pruned) + LDS stores",
-         "barrier", "scoring: 7 symbol DFTs on wave 0", "barrier", "final grid, Costas gate, LLRs"]
+         "barrier", "frequency scan: table set-up + the eight frequency-domain scores (round 4; before: 7 symbol DFTs on wave 0 per tweak)", "(unused)", "final grid, Costas gate, LLRs"]
 
 
 def main():
