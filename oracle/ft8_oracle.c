@@ -469,26 +469,41 @@ static float fine_score_block(const cpx* z, int tb, int sym0) {
  * The reference forms z = ifft(S) and scores |fft(z[i0 : i0 + 32])[t]| on the 7 symbols of the middle Costas block.  Substituting one
  * transform into the other (an exact identity, every one of the 1000 non-zero bins included):
  *     T[s][t] = 1/3200 sum_k X[k] e^{2 pi i k nb0 / 3200} D(k - 100 t) e^{2 pi i k s / 100},     D(m) = sum_{n < 32} e^{2 pi i n m / 3200},
- * k = -150 .. 849 the rolled slice's bins (X = tapered spectrum), nb0 = tb + 32 * 36 the block's first sample, s = 0 .. 6.  The last factor
- * has period 100 in k, so with k = r + 100 j:  H[t][r] = PhR[r] sum_j (X[k] PhJ[j]) D(k - 100 t),  T[s][t] = 1/3200 sum_r H[t][r] E[s][r].
+ * k = -150 .. 849 the rolled slice's bins (X = tapered spectrum), nb0 = tb + 32 * 36 the block's first sample, s = 0 .. 6.
+ * Two facts make it cheap.  (1) With m = r + 100 d, 0 <= r < 100, the Dirichlet kernel factors into a phase and a REAL number:
+ *     D(m) = e^{i pi 31 r / 3200} g^d K(m),   g = e^{-i pi / 32},   K(m) = sin(pi r / 100) / sin(pi m / 3200)   (K(0) = 32, K(100 d) = 0),
+ * so with k = r + 100 j the inner sum is a correlation of the phased bins with a real kernel,
+ *     H[t][r] = sum_j b[k] K(k - 100 t),     b[k] = X[k] Phi[k],     Phi[k] = e^{2 pi i k nb0 / 3200} e^{i pi (31 r - 100 j) / 3200}
+ * -- the factor g^{-t} left over has modulus 1 and only |T| is used, so it is dropped.  (2) e^{2 pi i k s / 100} has period 100 in k and
+ * E[s][100 - r] = conj E[s][r], so T[s][t] = 1/3200 (H[t][0] + (-1)^s H[t][50] + sum_{p=1..49} (cos_ps P_p + i sin_ps M_p)),
+ * P = H[t][p] + H[t][100 - p], M = H[t][p] - H[t][100 - p]: four real multiply-adds per pair.
  * Contract (kernels/fine_sync.hpp: fine_fscore does exactly this, on 100 + 112 lanes):
- *   tables in double, rounded once: D[m] (m = 0 .. 849; D(-m) = conj D(m)), E[s][r] = e^{2 pi i ((r s) mod 100) / 100};
- *   PhR[r] = conj W3200[(r nb0) mod 3200], PhJ[j] = conj W3200[100 ((j nb0) mod 32)], W3200 the FFT's twiddle table;
- *   a[q] = cmul(X[k_q], PhJ[j_q]), q = 0 .. 9 ascending in k (the first and the last are the tapered bins: fp64 product, rounded once);
- *   H: complex multiply-adds in ascending q, each component  fma(a.re, w.re, fma(-/+ a.im, w.im, acc))  (the named fmas below), then cmul by PhR;
- *   T: 16 partial sums per (s, t) over r = c, c + 16, ... (s = 0: plain adds, E = 1), combined as the binary tree
- *      ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) ... ; |T| from the components scaled by 1/3200; fp64 on / off sums as in fine_score_block. */
-static cpx g_D32[850], g_E100[7][100];
+ *   tables in double, rounded once: K[m] (m = -800 .. 899), (cos, sin)[s][q] (q = 0: (1, 0); q = 50: ((-1)^s, 0)), G[k] = e^{i pi (31 r - 100 j) / 3200};
+ *   Phi[k] = cmul(conj W3200[(k nb0) mod 3200], G[k]), W3200 the FFT's twiddle table;
+ *   b[q] = cmul(X[k_q], Phi[k_q]), q = 0 .. 9 ascending in k (the first and the last are the tapered bins: fp64 product, rounded once);
+ *   H: per component  fma(b, K, acc)  in ascending q;
+ *   T: 16 partial sums per (s, t) over the items q = c, c + 16, ... of {r = 0, pairs 1 .. 49, r = 50} (the singles pair with zero):
+ *      s = 0 adds P; s >= 1:  re = fma(P.re, cos, fma(-M.im, sin, re)), im = fma(P.im, cos, fma(M.re, sin, im));  the partials combined as
+ *      the binary tree ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) ... ; |T| from the components scaled by 1/3200; fp64 on / off sums as in fine_score_block. */
+static float g_K32[1700];
+static cpx g_CS100[6][51], g_G1000[1000];
 static int g_fs_ok = 0;
 static void make_fscore_tables(void) {
-    for (int m = 0; m < 850; m++) {
-        double re = 0.0, im = 0.0;
-        for (int n = 0; n < 32; n++) { const double a = 2.0 * M_PI * (double)n * (double)m / 3200.0; re += cos(a); im += sin(a); }
-        g_D32[m].re = (float)re; g_D32[m].im = (float)im;
+    for (int m = -800; m < 900; m++) {
+        const int r = ((m % 100) + 100) % 100;
+        g_K32[m + 800] = (r == 0) ? (m == 0 ? 32.0f : 0.0f) : (float)(sin(M_PI * (double)r / 100.0) / sin(M_PI * (double)m / 3200.0));
     }
-    for (int s = 0; s < 7; s++) for (int r = 0; r < 100; r++) {
-        const double a = 2.0 * M_PI * (double)((r * s) % 100) / 100.0;
-        g_E100[s][r].re = (float)cos(a); g_E100[s][r].im = (float)sin(a);
+    for (int s = 1; s < 7; s++) for (int q = 0; q <= 50; q++) {
+        const double a = 2.0 * M_PI * (double)((q * s) % 100) / 100.0;
+        cpx v; v.re = (float)cos(a); v.im = (float)sin(a);
+        if (q == 0) { v.re = 1.0f; v.im = 0.0f; }
+        if (q == 50) { v.re = (s & 1) ? -1.0f : 1.0f; v.im = 0.0f; }
+        g_CS100[s - 1][q] = v;
+    }
+    for (int k = -150; k < 850; k++) {
+        const int r = ((k % 100) + 100) % 100, j = (k - r) / 100;
+        const double a = M_PI * (31.0 * (double)r - 100.0 * (double)j) / 3200.0;
+        g_G1000[k + 150].re = (float)cos(a); g_G1000[k + 150].im = (float)sin(a);
     }
     g_fs_ok = 1;
 }
@@ -497,35 +512,31 @@ static float fine_fscore(const float* spec, int fb, int nb0) {
     if (!g_fs_ok) make_fscore_tables();
     const cpx* S = (const cpx*)spec;
     const cpx* W = get_twiddle(3200);
-    cpx PhR[100], PhJ[11], H[7][100];
-    for (int r = 0; r < 100; r++) { const cpx w = W[(r * nb0) % 3200]; PhR[r].re = w.re; PhR[r].im = -w.im; }
-    for (int i = 0; i < 11; i++) { const int j = i - 2; const int x = (((j * nb0) % 32) + 32) % 32; const cpx w = W[100 * x]; PhJ[i].re = w.re; PhJ[i].im = -w.im; }
+    cpx Phi[1000];
+    cpx H[7][100];
+    for (int k = -150; k < 850; k++) {
+        const cpx w = W[(((k * nb0) % 3200) + 3200) % 3200];
+        cpx wc; wc.re = w.re; wc.im = -w.im;
+        Phi[k + 150] = cmul(wc, g_G1000[k + 150]);
+    }
     for (int r = 0; r < 100; r++) {
         const int jlo = r < 50 ? -1 : -2;
-        cpx a[10];
+        cpx b[10];
         for (int q = 0; q < 10; q++) {
             const int k = r + 100 * (jlo + q);
             cpx x = S[fb + k];
             if (q == 0) { const double t = g_taper[k + 150]; x.re = (float)((double)x.re * t); x.im = (float)((double)x.im * t); }
             if (q == 9) { const double t = g_taper[k - 750]; x.re = (float)((double)x.re * t); x.im = (float)((double)x.im * t); }
-            a[q] = cmul(x, PhJ[q + jlo + 2]);
+            b[q] = cmul(x, Phi[k + 150]);
         }
         for (int t = 0; t < 7; t++) {
             float hx = 0.0f, hy = 0.0f;
             for (int q = 0; q < 10; q++) {
-                const int d = jlo + q - t, m = r + 100 * d;
-                if (d >= 0) {
-                    const cpx w = g_D32[m];
-                    hx = fmaf(a[q].re, w.re, fmaf(-a[q].im, w.im, hx));
-                    hy = fmaf(a[q].re, w.im, fmaf(a[q].im, w.re, hy));
-                } else {
-                    const cpx w = g_D32[-m];
-                    hx = fmaf(a[q].re, w.re, fmaf(a[q].im, w.im, hx));
-                    hy = fmaf(a[q].im, w.re, fmaf(-a[q].re, w.im, hy));
-                }
+                const float kv = g_K32[r + 100 * (jlo + q - t) + 800];
+                hx = fmaf(b[q].re, kv, hx);
+                hy = fmaf(b[q].im, kv, hy);
             }
-            cpx h; h.re = hx; h.im = hy;
-            H[t][r] = cmul(h, PhR[r]);
+            H[t][r].re = hx; H[t][r].im = hy;
         }
     }
     float mag[7][7];
@@ -534,15 +545,19 @@ static float fine_fscore(const float* spec, int fb, int nb0) {
         for (int c = 0; c < 16; c++) {
             cpx acc[7];
             for (int s = 0; s < 7; s++) { acc[s].re = 0.0f; acc[s].im = 0.0f; }
-            for (int i = 0; i < 7; i++) {
-                const int r = c + 16 * i;
-                if (r >= 100) continue;
-                const cpx h = H[t][r];
-                acc[0].re = acc[0].re + h.re; acc[0].im = acc[0].im + h.im;
+            for (int i = 0; i < 4; i++) {
+                const int q = c + 16 * i;
+                if (q > 50) continue;
+                const cpx h1 = H[t][q];
+                cpx h2; h2.re = 0.0f; h2.im = 0.0f;
+                if (q != 0 && q != 50) h2 = H[t][100 - q];
+                cpx P, M;
+                P.re = h1.re + h2.re; P.im = h1.im + h2.im; M.re = h1.re - h2.re; M.im = h1.im - h2.im;
+                acc[0].re = acc[0].re + P.re; acc[0].im = acc[0].im + P.im;
                 for (int s = 1; s < 7; s++) {
-                    const cpx e = g_E100[s][r];
-                    acc[s].re = fmaf(h.re, e.re, fmaf(-h.im, e.im, acc[s].re));
-                    acc[s].im = fmaf(h.re, e.im, fmaf(h.im, e.re, acc[s].im));
+                    const cpx e = g_CS100[s - 1][q];
+                    acc[s].re = fmaf(P.re, e.re, fmaf(-M.im, e.im, acc[s].re));
+                    acc[s].im = fmaf(P.im, e.re, fmaf(M.re, e.im, acc[s].im));
                 }
             }
             for (int s = 0; s < 7; s++) part[s][c] = acc[s];

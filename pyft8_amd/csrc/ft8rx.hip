@@ -352,10 +352,25 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     host_twiddle(192000, FT8RX_SPEC_BINS, w); rc |= upload(h, &h->T.WR192k, w);
     host_twiddle(32, 32, w);       rc |= upload(h, &h->T.W32, w);
     {   // tables of the frequency-domain fine score (kernels/fine_sync.hpp: fine_fscore; oracle/ft8_oracle.c: make_fscore_tables -- same formulas)
-        std::vector<cpx> d32(850), e100(700);
-        for (int m = 0; m < 850; m++) { double re = 0.0, im = 0.0; for (int n = 0; n < 32; n++) { const double a = 2.0 * M_PI * (double)n * (double)m / 3200.0; re += cos(a); im += sin(a); } d32[m] = make_float2((float)re, (float)im); }
-        for (int sidx = 0; sidx < 7; sidx++) for (int r = 0; r < 100; r++) { const double a = 2.0 * M_PI * (double)((r * sidx) % 100) / 100.0; e100[sidx * 100 + r] = make_float2((float)cos(a), (float)sin(a)); }
-        rc |= upload(h, &h->T.D32, d32); rc |= upload(h, &h->T.E100, e100);
+        std::vector<float> k32(1700);
+        std::vector<cpx> cs(306), g1000(1000);
+        for (int m = -800; m < 900; m++) {
+            const int r = ((m % 100) + 100) % 100;
+            k32[m + 800] = (r == 0) ? (m == 0 ? 32.0f : 0.0f) : (float)(sin(M_PI * (double)r / 100.0) / sin(M_PI * (double)m / 3200.0));
+        }
+        for (int sidx = 1; sidx < 7; sidx++) for (int q = 0; q <= 50; q++) {
+            const double a = 2.0 * M_PI * (double)((q * sidx) % 100) / 100.0;
+            cpx v = make_float2((float)cos(a), (float)sin(a));
+            if (q == 0) v = make_float2(1.0f, 0.0f);
+            if (q == 50) v = make_float2((sidx & 1) ? -1.0f : 1.0f, 0.0f);
+            cs[(sidx - 1) * 51 + q] = v;
+        }
+        for (int k = -150; k < 850; k++) {
+            const int r = ((k % 100) + 100) % 100, j = (k - r) / 100;
+            const double a = M_PI * (31.0 * (double)r - 100.0 * (double)j) / 3200.0;
+            g1000[k + 150] = make_float2((float)cos(a), (float)sin(a));
+        }
+        rc |= upload(h, &h->T.K32, k32); rc |= upload(h, &h->T.CS100, cs); rc |= upload(h, &h->T.G1000, g1000);
     }
     if (rc) { g_create_err = h->err; ft8rx_destroy(h); return -2; }
     // LDPC tables

@@ -17,8 +17,9 @@ struct Tables {
     const cpx* WR192k;       // [FT8RX_SPEC_BINS]
     const cpx* W32;
     const double* taper;     // [100]
-    const cpx* D32;          // [850]  D(m) = sum_{n<32} e^{+2 pi i n m / 3200}: the 32-sample Dirichlet kernel of the frequency-domain fine score
-    const cpx* E100;         // [7][100] e^{+2 pi i r s / 100}
+    const float* K32;        // [1700] K(m), m = -800 .. 899: the REAL factor of the 32-sample Dirichlet kernel, sin(pi (m mod 100) / 100) / sin(pi m / 3200) (fine_fscore)
+    const cpx* CS100;        // [6][51] (cos, sin)(2 pi q s / 100), s = 1 .. 6, q = 0 .. 50
+    const cpx* G1000;        // [1000] e^{i pi (31 r - 100 j) / 3200} for the slice bin k = r + 100 j = -150 .. 849
 };
 
 __device__ __constant__ int d_COSTAS[7] = {3, 1, 4, 0, 6, 5, 2};

@@ -21,11 +21,11 @@
 // accumulates the shader cycles between consecutive marks into an LDS table and flushes it to g_fine_t[] once at the end.
 #ifdef FINE_TIMING
 __device__ unsigned long long g_fine_t[32];
-#define FT_DECL __shared__ unsigned long long ft_l[16]; if (tid < 16) ft_l[tid] = 0; __syncthreads(); unsigned long long ft_prev = __builtin_readcyclecounter();
+#define FT_DECL __shared__ unsigned long long ft_l[32]; if (tid < 32) ft_l[tid] = 0; __syncthreads(); unsigned long long ft_prev = __builtin_readcyclecounter();
 #define FT_ARG , unsigned long long& ft_prev, unsigned long long* ft_l
 #define FT_PASS , ft_prev, ft_l
 #define FT(i) do { if (tid == 0) { unsigned long long ft_now = __builtin_readcyclecounter(); ft_l[i] += ft_now - ft_prev; ft_prev = __builtin_readcyclecounter(); } } while (0)
-#define FT_FLUSH do { __syncthreads(); if (tid < 16) atomicAdd(&g_fine_t[tid], ft_l[tid]); } while (0)
+#define FT_FLUSH do { __syncthreads(); if (tid < 32) atomicAdd(&g_fine_t[tid], ft_l[tid]); } while (0)
 #else
 #define FT_DECL
 #define FT_ARG
@@ -246,67 +246,82 @@ FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, const cpx* wq, float* m
 // ---- score of a NON-ZERO frequency tweak straight from the spectrum slice, without its time series (round 4) ----
 // The reference forms z = ifft(S) and scores |fft(z[i0 : i0 + 32])[t]| on the 7 symbols of the middle Costas block (receiver.py:186-206).
 // Substituting one transform into the other -- an exact identity, all 1000 non-zero bins included --
-//   T[s][t] = 1/3200 sum_k X[k] Phi[k] D(k - 100 t) e^{2 pi i k s / 100},   Phi[k] = e^{2 pi i k nb0 / 3200},   D(m) = sum_{n<32} e^{2 pi i n m / 3200},
-// with k = -150 .. 849 the rolled slice's bins, nb0 = the block's first sample.  The last factor has period 100 in k, so with k = r + 100 j:
-//   H[t][r] = PhR[r] sum_j (X[k] PhJ[j]) D(k - 100 t)        (step 1: lane per residue r, 10 bins, 7 tones; every D value loaded once)
-//   T[s][t] = 1/3200 sum_r H[t][r] E[s][r]                   (step 2: 16 lanes per tone, a DPP row sum)
-// 7.7 k complex multiply-adds instead of a pruned 3200-point IFFT and seven symbol DFTs: k_fine 2.50 -> 1.62 ms per 256 frames.  The
-// arithmetic (operation order, named fmas, the reduction tree) is the contract of oracle/ft8_oracle.c: fine_fscore -- bit-exact.
-// Tables in the IFFT image (dead between the time scan and the final transform): D (850), E (7 x 100), PhR (100), PhJ (11: j = -2 .. 8),
-// H (7 x 100), 7 x 8 magnitudes.
-#define FS_D 0
-#define FS_E 850
-#define FS_PHR 1550
-#define FS_PHJ 1650
-#define FS_H 1664
-#define FS_MAG 2364
-FT8_DEV void fscore_prepare(cpx* zi, const Tables& T, int nb0, int tid) {
-    for (int i = tid; i < 850; i += FINE_NT) zi[FS_D + i] = T.D32[i];
-    for (int i = tid; i < 700; i += FINE_NT) zi[FS_E + i] = T.E100[i];
-    if (tid < 100) { const cpx w = T.W3200[(tid * nb0) % 3200]; zi[FS_PHR + tid] = make_float2(w.x, -w.y); }
-    if (tid < 11) { const int j = tid - 2; const int x = (((j * nb0) % 32) + 32) % 32; const cpx w = T.W3200[100 * x]; zi[FS_PHJ + tid] = make_float2(w.x, -w.y); }
+//   T[s][t] = 1/3200 sum_k X[k] e^{2 pi i k nb0 / 3200} D(k - 100 t) e^{2 pi i k s / 100},   D(m) = sum_{n<32} e^{2 pi i n m / 3200},
+// k = -150 .. 849 the rolled slice's bins, nb0 = the block's first sample.  With m = r + 100 d (0 <= r < 100) the Dirichlet kernel is a phase
+// times a REAL number, D(m) = e^{i pi 31 r / 3200} g^d K(m), g = e^{-i pi / 32}, K(m) = sin(pi r / 100) / sin(pi m / 3200); the last factor of T
+// has period 100 in k and E[s][100 - r] = conj E[s][r].  So with k = r + 100 j:
+//   b[k]    = X[k] Phi[k],  Phi[k] = e^{2 pi i k nb0 / 3200} e^{i pi (31 r - 100 j) / 3200}   (per lane: the 10 phases of its bins, in registers)
+//   H[t][r] = sum_j b[k] K(k - 100 t)          (step 1: lane per residue r, 10 bins, 7 tones, a complex-by-REAL correlation; K loaded once per d = j - t)
+//   T[s][t] = 1/3200 (H[t][0] + (-1)^s H[t][50] + sum_{p=1..49} cos_ps (H[t][p] + H[t][100-p]) + i sin_ps (H[t][p] - H[t][100-p]))
+//                                              (step 2: 16 lanes per tone, 51 items, four real multiply-adds per item and symbol, a DPP row sum)
+// -- the factor g^{-t} left over has modulus 1 and only |T| is scored.  3.5 k + 2.4 k complex-multiply equivalents instead of a pruned
+// 3200-point IFFT and seven symbol DFTs.  The arithmetic (operation order, named fmas, the reduction tree) is the contract of
+// oracle/ft8_oracle.c: fine_fscore -- bit-exact.
+// What a lane of step 1 needs besides the slice is the same for every tweak of a candidate and lives in registers: its 16 values of K
+// (FsLane::k, loaded before the time scan is scored so that the latency hides), its 10 phases Phi (after the time tweak is known) and
+// its taper value.  In the IFFT image (dead between the time scan and the final transform), in complex slots: (cos, sin) (6 x 51),
+// H (2 x 7 x 100, double-buffered), 8 x 7 x 8 magnitudes.
+#define FS_CS 0
+#define FS_H 306
+#define FS_MAG 1706
+struct FsLane {
+    float k[16];        // K(r + 100 d), d = jlo - 6 .. jlo + 9
+    cpx g[10];          // G[k_q], then Phi[k_q] = cmul(conj W3200[(k_q nb0) mod 3200], G[k_q]), k_q = r + 100 (jlo + q)
+    double tap;         // taper of the lane's first and last bin (the same value: k_0 + 150 = k_9 - 750)
+    cpx cs[3];          // this thread's part of the (cos, sin) table on its way to the image
+    int r, jlo;
+};
+FT8_DEV void fscore_fetch(FsLane& L, const Tables& T, int tid) {            // request everything that does not depend on the time tweak
+    const int lane = tid & 63;
+    const int ln = lane < 50 ? lane : 0;                                     // (lanes 50 .. 63 of a wave idle in step 1)
+    L.r = tid < 64 ? 50 + ln : ln;
+    L.jlo = tid < 64 ? -2 : -1;
+#pragma unroll
+    for (int u = 0; u < 16; u++) L.k[u] = T.K32[800 + L.r + 100 * (L.jlo - 6 + u)];
+#pragma unroll
+    for (int q = 0; q < 10; q++) L.g[q] = T.G1000[L.r + 100 * (L.jlo + q) + 150];
+    L.tap = T.taper[tid < 64 ? ln : 50 + ln];
+#pragma unroll
+    for (int u = 0; u < 3; u++) { const int i = tid + FINE_NT * u; L.cs[u] = T.CS100[i < 306 ? i : 0]; }
+}
+FT8_DEV void fscore_prepare(FsLane& L, cpx* zi, const Tables& T, int nb0, int tid) {
+    cpx w[10];
+#pragma unroll
+    for (int q = 0; q < 10; q++) { const int k = L.r + 100 * (L.jlo + q); w[q] = T.W3200[(((k * nb0) % 3200) + 3200) % 3200]; }
+#pragma unroll
+    for (int u = 0; u < 3; u++) { const int i = tid + FINE_NT * u; if (i < 306) zi[FS_CS + i] = L.cs[u]; }
+#pragma unroll
+    for (int q = 0; q < 10; q++) L.g[q] = cmul(make_float2(w[q].x, -w[q].y), L.g[q]);
     __syncthreads();
 }
-template <int JLO>
-FT8_DEV void fscore_p1(const cpx* S, int off, const double* __restrict__ taper, const cpx* zi, cpx* H, int r) {
-    cpx a[10];
+FT8_DEV void fscore_p1(const cpx* S, int off, const FsLane& L, cpx* H, int tid FT_ARG) {
+    cpx b[10];
 #pragma unroll
     for (int q = 0; q < 10; q++) {
-        const int k = r + 100 * (JLO + q);
-        cpx x = S[off + k];
-        if (q == 0) x = fine_taper(x, taper[k + 150]);
-        if (q == 9) x = fine_taper(x, taper[k - 750]);
-        const cpx w = zi[FS_PHJ + q + JLO + 2];
-        a[q] = make_float2(__builtin_fmaf(x.x, w.x, -(x.y * w.y)), __builtin_fmaf(x.x, w.y, x.y * w.x));
+        cpx x = S[off + L.r + 100 * (L.jlo + q)];
+        if (q == 0 || q == 9) x = fine_taper(x, L.tap);
+        b[q] = cmul(x, L.g[q]);
     }
-    const cpx* Dp = zi + FS_D + r;
-    const cpx* Dn = zi + FS_D - r;
-    const cpx ph = zi[FS_PHR + r];
-    // H_t = sum_q a[q] D(k_q - 100 t), q ascending; walked by d = j - t so that every D value is loaded once (19 loads for the 70 terms):
-    // for a given tone the terms still arrive in ascending q
+    FT(16);
+    // H_t = sum_q b[q] K(k_q - 100 t), q ascending; walked by d = j - t = jlo - 6 + u so that every K value is used from its register:
+    // q = u + t - 6, and for a given tone the terms still arrive in ascending q
     float hx[7], hy[7];
 #pragma unroll
     for (int t = 0; t < 7; t++) { hx[t] = 0.0f; hy[t] = 0.0f; }
 #pragma unroll
-    for (int d = JLO - 6; d <= JLO + 9; d++) {
-        const cpx w = (d >= 0) ? Dp[100 * (d >= 0 ? d : 0)] : Dn[100 * (d < 0 ? -d : 0)];
+    for (int u = 0; u < 16; u++) {
 #pragma unroll
         for (int t = 0; t < 7; t++) {
-            const int q = d + t - JLO;
+            const int q = u + t - 6;
             if (q >= 0 && q < 10) {
-                if (d >= 0) {
-                    hx[t] = __builtin_fmaf(a[q].x, w.x, __builtin_fmaf(-a[q].y, w.y, hx[t]));
-                    hy[t] = __builtin_fmaf(a[q].x, w.y, __builtin_fmaf(a[q].y, w.x, hy[t]));
-                } else {                                         // D(-m) = conj(D(m))
-                    hx[t] = __builtin_fmaf(a[q].x, w.x, __builtin_fmaf(a[q].y, w.y, hx[t]));
-                    hy[t] = __builtin_fmaf(a[q].y, w.x, __builtin_fmaf(-a[q].x, w.y, hy[t]));
-                }
+                hx[t] = __builtin_fmaf(b[q].x, L.k[u], hx[t]);
+                hy[t] = __builtin_fmaf(b[q].y, L.k[u], hy[t]);
             }
         }
     }
+    FT(17);
 #pragma unroll
-    for (int t = 0; t < 7; t++)
-        H[t * 100 + r] = make_float2(__builtin_fmaf(hx[t], ph.x, -(hy[t] * ph.y)), __builtin_fmaf(hx[t], ph.y, hy[t] * ph.x));
+    for (int t = 0; t < 7; t++) H[t * 100 + L.r] = make_float2(hx[t], hy[t]);
 }
 FT8_DEV float row16_sum(float v) {                 // sum over the 16 lanes of a DPP row, the same value on every lane: ((p0+p1)+(p2+p3)) + ... as a binary tree
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));      // quad_perm:[1,0,3,2]
@@ -315,32 +330,41 @@ FT8_DEV float row16_sum(float v) {                 // sum over the 16 lanes of a
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));     // row_mirror (halves hold equal values)
     return v;
 }
-FT8_DEV float fine_fscore(const cpx* S, int off, const Tables& T, cpx* zi, double* dsum, int tid) {
-    cpx* H = zi + FS_H;
-    float* mags = reinterpret_cast<float*>(zi + FS_MAG);
+// The 49 magnitudes of tweak number n (n = 0 .. 7 in scan order) -> mags[n][s * 8 + t].  H is double-buffered by the parity of n, so ONE
+// barrier per tweak is enough: a wave writes H[n & 1] for tweak n + 2 only after it has passed the barrier of tweak n + 1, which the
+// other wave reaches after it has read H[n & 1] for tweak n.  The scores are formed after the scan, for all tweaks at once.
+FT8_DEV void fine_fscore(const cpx* S, int off, const FsLane& L, cpx* zi, int n, int tid FT_ARG) {
+    cpx* H = zi + FS_H + (n & 1) * 700;
+    float* mags = reinterpret_cast<float*>(zi + FS_MAG) + n * 56;
     const int lane = tid & 63;
-    if (lane < 50) { if (tid < 64) fscore_p1<-2>(S, off, T.taper, zi, H, 50 + lane); else fscore_p1<-1>(S, off, T.taper, zi, H, lane); }
+    if (lane < 50) fscore_p1(S, off, L, H, tid FT_PASS);
+    FT(11);
     __syncthreads();
+    FT(12);
     {
         const int c = tid & 15, t = tid >> 4;
         cpx acc[7];
 #pragma unroll
         for (int s = 0; s < 7; s++) acc[s] = make_float2(0.0f, 0.0f);
-        const int tt_ = t < 7 ? t : 0;
+        const cpx* Ht = H + (t < 7 ? t : 0) * 100;
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const int r = c + 16 * i;
-            if (i < 6 || c < 4) {
-                const cpx h = H[tt_ * 100 + r];
-                acc[0] = cadd(acc[0], h);
+        for (int i = 0; i < 4; i++) {
+            const int q = c + 16 * i;                          // item: r = 0 | the pairs (p, 100 - p), p = 1 .. 49 | r = 50
+            if (i < 3 || c < 3) {
+                const cpx h1 = Ht[q];
+                cpx h2 = Ht[100 - q - ((i == 0 && c == 0) ? 1 : 0)];       // (in-range address for q = 0; zeroed below)
+                if ((i == 0 && c == 0) || (i == 3 && c == 2)) h2 = make_float2(0.0f, 0.0f);     // the singles pair with zero
+                const cpx P = make_float2(h1.x + h2.x, h1.y + h2.y), M = make_float2(h1.x - h2.x, h1.y - h2.y);
+                acc[0] = cadd(acc[0], P);
 #pragma unroll
                 for (int s = 1; s < 7; s++) {
-                    const cpx e = zi[FS_E + s * 100 + r];
-                    acc[s].x = __builtin_fmaf(h.x, e.x, __builtin_fmaf(-h.y, e.y, acc[s].x));
-                    acc[s].y = __builtin_fmaf(h.x, e.y, __builtin_fmaf(h.y, e.x, acc[s].y));
+                    const cpx e = zi[FS_CS + (s - 1) * 51 + q];
+                    acc[s].x = __builtin_fmaf(P.x, e.x, __builtin_fmaf(-M.y, e.y, acc[s].x));
+                    acc[s].y = __builtin_fmaf(P.y, e.x, __builtin_fmaf(M.x, e.y, acc[s].y));
                 }
             }
         }
+        FT(19);
 #pragma unroll
         for (int s = 0; s < 7; s++) { acc[s].x = row16_sum(acc[s].x); acc[s].y = row16_sum(acc[s].y); }
         if (t < 7 && c < 7) {
@@ -351,19 +375,7 @@ FT8_DEV float fine_fscore(const cpx* S, int off, const Tables& T, cpx* zi, doubl
             mags[c * 8 + t] = sqrtf(re * re + im * im);
         }
     }
-    __syncthreads();
-    if (tid < 7) {
-        const int cc = d_COSTAS[tid];
-        double off_ = 0.0, on = 0.0;
-#pragma unroll
-        for (int b = 0; b < 7; b++) { const double m = (double)mags[tid * 8 + b]; on = (b == cc) ? m : on; off_ += (b == cc) ? 0.0 : m; }
-        dsum[tid * 2] = on; dsum[tid * 2 + 1] = off_;
-    }
-    __syncthreads();
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 7; a++) { s1 += dsum[a * 2]; s2 += dsum[a * 2 + 1]; }
-    return (float)(s1 + W6 * s2);
+    FT(14);
 }
 
 FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
@@ -422,6 +434,8 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     double* dsum = reinterpret_cast<double*>(mg);              // [8][7][2] (on, off); mg is free until the final grid
     // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
     fine_fft(S, 182, z, w400, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43 FT_PASS);   // the 8 time tweaks of the middle Costas block
+    FsLane L;
+    fscore_fetch(L, T, tid);                                   // the frequency scan's constants: requested here, used after the time scan
 #pragma unroll 1
     for (int r = 0; r < (224 + FINE_NT - 1) / FINE_NT; r++) {
         const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
@@ -439,24 +453,50 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     }
     __syncthreads();
     int tt = -8; float score_f0 = 0.0f;
-    for (int ti = 0; ti < 8; ti++) {                           // every thread: same values, same result
+    {   // lane ti (mod 8) of every wave sums the block at time tweak ti; the first maximum (np.argmax) is then picked from the 8 lanes
+        const int ti = tid & 7;
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int a = 0; a < 7; a++) { s1 += dsum[(ti * 7 + a) * 2]; s2 += dsum[(ti * 7 + a) * 2 + 1]; }
         const float sct = (float)(s1 + W6 * s2);
-        if (ti == 0 || sct > score_f0) { score_f0 = sct; tt = -8 + 2 * ti; }     // first maximum (np.argmax)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sct), u));
+            if (u == 0 || v > score_f0) { score_f0 = v; tt = -8 + 2 * u; }
+        }
     }
     // --- frequency tweaks: range(-32,33,8)
     float best = 0.0f; int ft = 0;
-    fscore_prepare(z, T, tb0 + tt + 32 * 36, tid);            // the time scan is done with the series: the image takes the tables of the frequency scan
+    fscore_prepare(L, z, T, tb0 + tt + 32 * 36, tid);         // the time scan is done with the series: the image takes the tables of the frequency scan
+    FT(18);
 #pragma unroll 1
-    for (int i = 0; i < 9; i++) {
-        const int fcur = -32 + 8 * i;
-        const float s = (fcur == 0) ? score_f0                  // same series, same offset: identical value
-                                    : fine_fscore(S, 182 + fcur, T, z, dsum, tid);
-        FT(11);
-        if (i == 0 || s > best) { best = s; ft = fcur; }
+    for (int n = 0; n < 8; n++) {                              // tweak 0 is the time scan's winner: same series, same offset, identical value
+        fine_fscore(S, 182 - 32 + 8 * (n < 4 ? n : n + 1), L, z, n, tid FT_PASS);
+        FT(15);
     }
+    __syncthreads();
+    if (tid < 56) {                                            // (on, off) of symbol a of tweak n: the contract of the time scan, b ascending in fp64
+        const int n = tid / 7, a = tid - 7 * n, c = d_COSTAS[a];
+        const float* mags = reinterpret_cast<const float*>(z + FS_MAG) + n * 56 + a * 8;
+        double off = 0.0, on = 0.0;
+#pragma unroll
+        for (int b = 0; b < 7; b++) { const double m = (double)mags[b]; on = (b == c) ? m : on; off += (b == c) ? 0.0 : m; }
+        dsum[tid * 2] = on; dsum[tid * 2 + 1] = off;
+    }
+    __syncthreads();
+    {   // lane n (mod 8) of every wave sums tweak n; the first maximum in scan order, the winner of the time scan at its place in the middle
+        const int n = tid & 7;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 7; a++) { s1 += dsum[(n * 7 + a) * 2]; s2 += dsum[(n * 7 + a) * 2 + 1]; }
+        const float sct = (float)(s1 + W6 * s2);
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const float v = (i == 4) ? score_f0 : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sct), i < 4 ? i : i - 1));
+            if (i == 0 || v > best) { best = v; ft = -32 + 8 * i; }
+        }
+    }
+    FT(20);
     {   // full series for the 79 x 8 grid.  Nothing thread-specific of the first transform (addresses, twiddles) is to stay alive across the
         // frequency scan for this one: with the plain `tid` the compiler keeps them, and spills 340 B around the scan (k_fine 2.29 instead of 1.62 ms)
         int tid2 = tid;

@@ -25,6 +25,14 @@ template <int OP> __global__ void k(float* out, int iters) {
                                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); }
             if (OP == 5) { asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8"
                                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(c2)); }
+            if (OP == 7) { asm volatile("v_pk_fma_f32 %0, %0, %8, %8 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n v_pk_fma_f32 %1, %1, %8, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n v_pk_fma_f32 %2, %2, %8, %8 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n v_pk_fma_f32 %3, %3, %8, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n v_pk_fma_f32 %4, %4, %8, %8 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n v_pk_fma_f32 %5, %5, %8, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n v_pk_fma_f32 %6, %6, %8, %8 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n v_pk_fma_f32 %7, %7, %8, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+                                        : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(c2)); }
+            if (OP == 8) { asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9"
+                                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2.y)); }
+            if (OP == 9) { asm volatile("v_fma_f32 %0, %8, %9, %0\n v_fma_f32 %1, %8, %9, %1\n v_fma_f32 %2, %8, %9, %2\n v_fma_f32 %3, %8, %9, %3\n v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_fma_f32 %7, %8, %9, %7"
+                                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2.y)); }
+            if (OP == 10) { asm volatile("v_fma_f32 %0, %8, %9, %1\n v_fma_f32 %1, %8, %9, %2\n v_fma_f32 %2, %8, %9, %3\n v_fma_f32 %3, %8, %9, %4\n v_fma_f32 %4, %8, %9, %5\n v_fma_f32 %5, %8, %9, %6\n v_fma_f32 %6, %8, %9, %7\n v_fma_f32 %7, %8, %9, %0"
+                                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2.y)); }
             if (OP == 6) { asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4"
                                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(c2)); }
         }
@@ -63,5 +71,9 @@ int main() {
     run<4>("v_mov_b32", REP);
     run<5>("v_pk_mul_f32", REP);
     run<6>("v_add_f64", REP / 2);
+    run<7>("v_pk_fma_f32 op_sel", REP);
+    run<8>("v_fmac_f32", REP);
+    run<9>("v_fma_f32 d=s2", REP);
+    run<10>("v_fma_f32 3 src", REP);
     return 0;
 }
