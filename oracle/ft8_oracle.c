@@ -474,30 +474,33 @@ static float fine_score_block(const cpx* z, int tb, int sym0) {
  *     D(m) = e^{i pi 31 r / 3200} g^d K(m),   g = e^{-i pi / 32},   K(m) = sin(pi r / 100) / sin(pi m / 3200)   (K(0) = 32, K(100 d) = 0),
  * so with k = r + 100 j the inner sum is a correlation of the phased bins with a real kernel,
  *     H[t][r] = sum_j b[k] K(k - 100 t),     b[k] = X[k] Phi[k],     Phi[k] = e^{2 pi i k nb0 / 3200} e^{i pi (31 r - 100 j) / 3200}
- * -- the factor g^{-t} left over has modulus 1 and only |T| is used, so it is dropped.  (2) e^{2 pi i k s / 100} has period 100 in k and
- * E[s][100 - r] = conj E[s][r], so T[s][t] = 1/3200 (H[t][0] + (-1)^s H[t][50] + sum_{p=1..49} (cos_ps P_p + i sin_ps M_p)),
- * P = H[t][p] + H[t][100 - p], M = H[t][p] - H[t][100 - p]: four real multiply-adds per pair.
+ * -- the factor g^{-t} left over has modulus 1 and only |T| is used, so it is dropped.  (2) e^{2 pi i k s / 100} has period 100 in k, and
+ * the four residues p, 100 - p, 50 - p, 50 + p share one (cos, sin) = (cos, sin)(2 pi p s / 100) up to signs: with P_x = H[t][x] + H[t][100 - x],
+ * M_x = H[t][x] - H[t][100 - x],
+ *     T[s][t] = 1/3200 sum_{p = 0 .. 25} cos_ps (P_p + (-1)^s P_{50-p}) + i sin_ps (M_p - (-1)^s M_{50-p})
+ * (p = 0 stands for the residues 0 and 50, p = 25 for the pair 25, 75 alone): four real multiply-adds per item, symbol and tone.
  * Contract (kernels/fine_sync.hpp: fine_fscore does exactly this, on 100 + 112 lanes):
- *   tables in double, rounded once: K[m] (m = -800 .. 899), (cos, sin)[s][q] (q = 0: (1, 0); q = 50: ((-1)^s, 0)), G[k] = e^{i pi (31 r - 100 j) / 3200};
+ *   tables in double, rounded once: K[m] (m = -800 .. 899), (cos, sin)[s][p] (p = 0: (1, 0)), G[k] = e^{i pi (31 r - 100 j) / 3200};
  *   Phi[k] = cmul(conj W3200[(k nb0) mod 3200], G[k]), W3200 the FFT's twiddle table;
  *   b[q] = cmul(X[k_q], Phi[k_q]), q = 0 .. 9 ascending in k (the first and the last are the tapered bins: fp64 product, rounded once);
  *   H: per component  fma(b, K, acc)  in ascending q;
- *   T: 16 partial sums per (s, t) over the items q = c, c + 16, ... of {r = 0, pairs 1 .. 49, r = 50} (the singles pair with zero):
- *      s = 0 adds P; s >= 1:  re = fma(P.re, cos, fma(-M.im, sin, re)), im = fma(P.im, cos, fma(M.re, sin, im));  the partials combined as
- *      the binary tree ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) ... ; |T| from the components scaled by 1/3200; fp64 on / off sums as in fine_score_block. */
+ *   T: 16 partial sums per (s, t) over the items p = c, c + 16: h1 = H[p], h2 = H[100 - p], h3 = H[50 - p], h4 = H[50 + p] (p = 0: h2 = h4 = 0;
+ *      p = 25: h3 = h4 = 0); P = h1 + h2, M = h1 - h2, P' = h3 + h4, M' = h3 - h4; A = P + P', B = P - P', C = M - M', D = M + M';
+ *      s = 0 adds A; even s:  re = fma(A.re, cos, fma(-C.im, sin, re)), im = fma(A.im, cos, fma(C.re, sin, im));  odd s: the same with B, D;
+ *      the partials combined as the binary tree ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) ... ; |T| from the components scaled by 1/3200;
+ *      fp64 on / off sums as in fine_score_block. */
 static float g_K32[1700];
-static cpx g_CS100[6][51], g_G1000[1000];
+static cpx g_CS100[6][26], g_G1000[1000];
 static int g_fs_ok = 0;
 static void make_fscore_tables(void) {
     for (int m = -800; m < 900; m++) {
         const int r = ((m % 100) + 100) % 100;
         g_K32[m + 800] = (r == 0) ? (m == 0 ? 32.0f : 0.0f) : (float)(sin(M_PI * (double)r / 100.0) / sin(M_PI * (double)m / 3200.0));
     }
-    for (int s = 1; s < 7; s++) for (int q = 0; q <= 50; q++) {
+    for (int s = 1; s < 7; s++) for (int q = 0; q <= 25; q++) {
         const double a = 2.0 * M_PI * (double)((q * s) % 100) / 100.0;
         cpx v; v.re = (float)cos(a); v.im = (float)sin(a);
         if (q == 0) { v.re = 1.0f; v.im = 0.0f; }
-        if (q == 50) { v.re = (s & 1) ? -1.0f : 1.0f; v.im = 0.0f; }
         g_CS100[s - 1][q] = v;
     }
     for (int k = -150; k < 850; k++) {
@@ -545,19 +548,25 @@ static float fine_fscore(const float* spec, int fb, int nb0) {
         for (int c = 0; c < 16; c++) {
             cpx acc[7];
             for (int s = 0; s < 7; s++) { acc[s].re = 0.0f; acc[s].im = 0.0f; }
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < 2; i++) {
                 const int q = c + 16 * i;
-                if (q > 50) continue;
+                if (q > 25) continue;
+                const cpx zero = {0.0f, 0.0f};
                 const cpx h1 = H[t][q];
-                cpx h2; h2.re = 0.0f; h2.im = 0.0f;
-                if (q != 0 && q != 50) h2 = H[t][100 - q];
-                cpx P, M;
+                const cpx h2 = (q == 0) ? zero : H[t][100 - q];
+                const cpx h3 = (q == 25) ? zero : H[t][50 - q];
+                const cpx h4 = (q == 0 || q == 25) ? zero : H[t][50 + q];
+                cpx P, M, P2, M2, A, B, C, D;
                 P.re = h1.re + h2.re; P.im = h1.im + h2.im; M.re = h1.re - h2.re; M.im = h1.im - h2.im;
-                acc[0].re = acc[0].re + P.re; acc[0].im = acc[0].im + P.im;
+                P2.re = h3.re + h4.re; P2.im = h3.im + h4.im; M2.re = h3.re - h4.re; M2.im = h3.im - h4.im;
+                A.re = P.re + P2.re; A.im = P.im + P2.im; B.re = P.re - P2.re; B.im = P.im - P2.im;
+                C.re = M.re - M2.re; C.im = M.im - M2.im; D.re = M.re + M2.re; D.im = M.im + M2.im;
+                acc[0].re = acc[0].re + A.re; acc[0].im = acc[0].im + A.im;
                 for (int s = 1; s < 7; s++) {
                     const cpx e = g_CS100[s - 1][q];
-                    acc[s].re = fmaf(P.re, e.re, fmaf(-M.im, e.im, acc[s].re));
-                    acc[s].im = fmaf(P.im, e.re, fmaf(M.re, e.im, acc[s].im));
+                    const cpx X = (s & 1) ? B : A, Y = (s & 1) ? D : C;
+                    acc[s].re = fmaf(X.re, e.re, fmaf(-Y.im, e.im, acc[s].re));
+                    acc[s].im = fmaf(X.im, e.re, fmaf(Y.re, e.im, acc[s].im));
                 }
             }
             for (int s = 0; s < 7; s++) part[s][c] = acc[s];

@@ -353,17 +353,16 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     host_twiddle(32, 32, w);       rc |= upload(h, &h->T.W32, w);
     {   // tables of the frequency-domain fine score (kernels/fine_sync.hpp: fine_fscore; oracle/ft8_oracle.c: make_fscore_tables -- same formulas)
         std::vector<float> k32(1700);
-        std::vector<cpx> cs(306), g1000(1000);
+        std::vector<cpx> cs(156), g1000(1000);
         for (int m = -800; m < 900; m++) {
             const int r = ((m % 100) + 100) % 100;
             k32[m + 800] = (r == 0) ? (m == 0 ? 32.0f : 0.0f) : (float)(sin(M_PI * (double)r / 100.0) / sin(M_PI * (double)m / 3200.0));
         }
-        for (int sidx = 1; sidx < 7; sidx++) for (int q = 0; q <= 50; q++) {
+        for (int sidx = 1; sidx < 7; sidx++) for (int q = 0; q <= 25; q++) {
             const double a = 2.0 * M_PI * (double)((q * sidx) % 100) / 100.0;
             cpx v = make_float2((float)cos(a), (float)sin(a));
             if (q == 0) v = make_float2(1.0f, 0.0f);
-            if (q == 50) v = make_float2((sidx & 1) ? -1.0f : 1.0f, 0.0f);
-            cs[(sidx - 1) * 51 + q] = v;
+            cs[(sidx - 1) * 26 + q] = v;
         }
         for (int k = -150; k < 850; k++) {
             const int r = ((k % 100) + 100) % 100, j = (k - r) / 100;

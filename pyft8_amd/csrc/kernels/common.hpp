@@ -18,7 +18,7 @@ struct Tables {
     const cpx* W32;
     const double* taper;     // [100]
     const float* K32;        // [1700] K(m), m = -800 .. 899: the REAL factor of the 32-sample Dirichlet kernel, sin(pi (m mod 100) / 100) / sin(pi m / 3200) (fine_fscore)
-    const cpx* CS100;        // [6][51] (cos, sin)(2 pi q s / 100), s = 1 .. 6, q = 0 .. 50
+    const cpx* CS100;        // [6][26] (cos, sin)(2 pi p s / 100), s = 1 .. 6, p = 0 .. 25
     const cpx* G1000;        // [1000] e^{i pi (31 r - 100 j) / 3200} for the slice bin k = r + 100 j = -150 .. 849
 };
 

@@ -252,23 +252,24 @@ FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, const cpx* wq, float* m
 // has period 100 in k and E[s][100 - r] = conj E[s][r].  So with k = r + 100 j:
 //   b[k]    = X[k] Phi[k],  Phi[k] = e^{2 pi i k nb0 / 3200} e^{i pi (31 r - 100 j) / 3200}   (per lane: the 10 phases of its bins, in registers)
 //   H[t][r] = sum_j b[k] K(k - 100 t)          (step 1: lane per residue r, 10 bins, 7 tones, a complex-by-REAL correlation; K loaded once per d = j - t)
-//   T[s][t] = 1/3200 (H[t][0] + (-1)^s H[t][50] + sum_{p=1..49} cos_ps (H[t][p] + H[t][100-p]) + i sin_ps (H[t][p] - H[t][100-p]))
-//                                              (step 2: 16 lanes per tone, 51 items, four real multiply-adds per item and symbol, a DPP row sum)
+//   T[s][t] = 1/3200 sum_{p=0..25} cos_ps (P_p + (-1)^s P_{50-p}) + i sin_ps (M_p - (-1)^s M_{50-p}),   P_x, M_x = H[t][x] +- H[t][100-x]
+//                                              (step 2: 16 lanes per tone, 26 items of four residues, four real multiply-adds per item and
+//                                               symbol, a DPP row sum)
 // -- the factor g^{-t} left over has modulus 1 and only |T| is scored.  3.5 k + 2.4 k complex-multiply equivalents instead of a pruned
 // 3200-point IFFT and seven symbol DFTs.  The arithmetic (operation order, named fmas, the reduction tree) is the contract of
 // oracle/ft8_oracle.c: fine_fscore -- bit-exact.
 // What a lane of step 1 needs besides the slice is the same for every tweak of a candidate and lives in registers: its 16 values of K
 // (FsLane::k, loaded before the time scan is scored so that the latency hides), its 10 phases Phi (after the time tweak is known) and
-// its taper value.  In the IFFT image (dead between the time scan and the final transform), in complex slots: (cos, sin) (6 x 51),
+// its taper value.  In the IFFT image (dead between the time scan and the final transform), in complex slots: (cos, sin) (6 x 26),
 // H (2 x 7 x 100, double-buffered), 8 x 7 x 8 magnitudes.
 #define FS_CS 0
-#define FS_H 306
-#define FS_MAG 1706
+#define FS_H 156
+#define FS_MAG 1556
 struct FsLane {
     float k[16];        // K(r + 100 d), d = jlo - 6 .. jlo + 9
     cpx g[10];          // G[k_q], then Phi[k_q] = cmul(conj W3200[(k_q nb0) mod 3200], G[k_q]), k_q = r + 100 (jlo + q)
     double tap;         // taper of the lane's first and last bin (the same value: k_0 + 150 = k_9 - 750)
-    cpx cs[3];          // this thread's part of the (cos, sin) table on its way to the image
+    cpx cs[2];          // this thread's part of the (cos, sin) table on its way to the image
     int r, jlo;
 };
 FT8_DEV void fscore_fetch(FsLane& L, const Tables& T, int tid) {            // request everything that does not depend on the time tweak
@@ -282,14 +283,18 @@ FT8_DEV void fscore_fetch(FsLane& L, const Tables& T, int tid) {            // r
     for (int q = 0; q < 10; q++) L.g[q] = T.G1000[L.r + 100 * (L.jlo + q) + 150];
     L.tap = T.taper[tid < 64 ? ln : 50 + ln];
 #pragma unroll
-    for (int u = 0; u < 3; u++) { const int i = tid + FINE_NT * u; L.cs[u] = T.CS100[i < 306 ? i : 0]; }
+    for (int u = 0; u < 2; u++) { const int i = tid + FINE_NT * u; L.cs[u] = T.CS100[i < 156 ? i : 0]; }
 }
 FT8_DEV void fscore_prepare(FsLane& L, cpx* zi, const Tables& T, int nb0, int tid) {
     cpx w[10];
+    {   // W3200[(k_q nb0) mod 3200], k_q = r + 100 (jlo + q): one reduction for the lane's first bin, then steps of (100 nb0) mod 3200
+        const int step = (((100 * nb0) % 3200) + 3200) % 3200;
+        int idx = ((((L.r + 100 * L.jlo) * nb0) % 3200) + 3200) % 3200;
 #pragma unroll
-    for (int q = 0; q < 10; q++) { const int k = L.r + 100 * (L.jlo + q); w[q] = T.W3200[(((k * nb0) % 3200) + 3200) % 3200]; }
+        for (int q = 0; q < 10; q++) { w[q] = T.W3200[idx]; idx += step; idx -= (idx >= 3200) ? 3200 : 0; }
+    }
 #pragma unroll
-    for (int u = 0; u < 3; u++) { const int i = tid + FINE_NT * u; if (i < 306) zi[FS_CS + i] = L.cs[u]; }
+    for (int u = 0; u < 2; u++) { const int i = tid + FINE_NT * u; if (i < 156) zi[FS_CS + i] = L.cs[u]; }
 #pragma unroll
     for (int q = 0; q < 10; q++) L.g[q] = cmul(make_float2(w[q].x, -w[q].y), L.g[q]);
     __syncthreads();
@@ -348,19 +353,26 @@ FT8_DEV void fine_fscore(const cpx* S, int off, const FsLane& L, cpx* zi, int n,
         for (int s = 0; s < 7; s++) acc[s] = make_float2(0.0f, 0.0f);
         const cpx* Ht = H + (t < 7 ? t : 0) * 100;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int q = c + 16 * i;                          // item: r = 0 | the pairs (p, 100 - p), p = 1 .. 49 | r = 50
-            if (i < 3 || c < 3) {
-                const cpx h1 = Ht[q];
-                cpx h2 = Ht[100 - q - ((i == 0 && c == 0) ? 1 : 0)];       // (in-range address for q = 0; zeroed below)
-                if ((i == 0 && c == 0) || (i == 3 && c == 2)) h2 = make_float2(0.0f, 0.0f);     // the singles pair with zero
+        for (int i = 0; i < 2; i++) {
+            const int p = c + 16 * i;                          // item: the residues p, 100 - p, 50 - p, 50 + p (p = 0: 0 and 50; p = 25: 25 and 75)
+            if (i < 1 || c < 10) {
+                const bool first = (i == 0 && c == 0), last = (i == 1 && c == 9);
+                const cpx zero = make_float2(0.0f, 0.0f);
+                const cpx h1 = Ht[p];
+                cpx h2 = Ht[first ? 99 : 100 - p], h3 = Ht[50 - p], h4 = Ht[50 + p];
+                if (first) { h2 = zero; h4 = zero; }
+                if (last) { h3 = zero; h4 = zero; }
                 const cpx P = make_float2(h1.x + h2.x, h1.y + h2.y), M = make_float2(h1.x - h2.x, h1.y - h2.y);
-                acc[0] = cadd(acc[0], P);
+                const cpx P2 = make_float2(h3.x + h4.x, h3.y + h4.y), M2 = make_float2(h3.x - h4.x, h3.y - h4.y);
+                const cpx A = make_float2(P.x + P2.x, P.y + P2.y), B = make_float2(P.x - P2.x, P.y - P2.y);
+                const cpx C = make_float2(M.x - M2.x, M.y - M2.y), D = make_float2(M.x + M2.x, M.y + M2.y);
+                acc[0] = cadd(acc[0], A);
 #pragma unroll
                 for (int s = 1; s < 7; s++) {
-                    const cpx e = zi[FS_CS + (s - 1) * 51 + q];
-                    acc[s].x = __builtin_fmaf(P.x, e.x, __builtin_fmaf(-M.y, e.y, acc[s].x));
-                    acc[s].y = __builtin_fmaf(P.y, e.x, __builtin_fmaf(M.x, e.y, acc[s].y));
+                    const cpx e = zi[FS_CS + (s - 1) * 26 + p];
+                    const cpx X = (s & 1) ? B : A, Y = (s & 1) ? D : C;
+                    acc[s].x = __builtin_fmaf(X.x, e.x, __builtin_fmaf(-Y.y, e.y, acc[s].x));
+                    acc[s].y = __builtin_fmaf(X.y, e.x, __builtin_fmaf(Y.x, e.y, acc[s].y));
                 }
             }
         }
