@@ -53,11 +53,11 @@ ALG_FLOP_FINE = 0.78e9
 VALU_PEAK_TFLOPS = 157.3
 # executed fp32 operations of k_fine per candidate (counted from the kernel; an fma counts 2): the pruned IFFT of the
 # time scan 140 k (radix-8 pass with its zero inputs left out 29 k + [4,4] stage 54 k + [5,5] stage with the last pass pruned 57 k) + its 56
-# symbol DFTs on lane quads (0.6 k each); EIGHT FREQUENCY-DOMAIN SCORES since round 4 (per residue 17 complex multiplies and 70 complex
-# multiply-adds, x 100 residues = 66 k; then 7 tones x 100 residues x 6 multiply-adds + 1 add = 35 k: 101 k each, against 140 k + 7 x 0.6 k for
-# the pruned IFFT + symbol DFTs they replace); the full final IFFT 160 k; final grid: 21 Costas symbols always, the 58 payload symbols for the
-# 41 % of candidates that pass the gate (45 symbols on average)
-EXEC_FLOP_FINE_CAND = 140e3 + 56 * 0.6e3 + 8 * 101e3 + 160e3 + 45 * 0.6e3
+# symbol DFTs on lane quads (0.6 k each); EIGHT FREQUENCY-DOMAIN SCORES since round 4 (per residue 10 complex multiplies and 70
+# complex-by-real multiply-adds, x 100 residues = 34 k; then per tone 26 items of four residues, 16 adds + 6 symbols x 4 fmas each, x 7 tones
+# = 12 k, + the 16-lane sums 1.5 k: 48 k each, against 140 k + 7 x 0.6 k for the pruned IFFT + symbol DFTs they replace); the full final IFFT
+# 160 k; final grid: 21 Costas symbols always, the 58 payload symbols for the 41 % of candidates that pass the gate (45 symbols on average)
+EXEC_FLOP_FINE_CAND = 140e3 + 56 * 0.6e3 + 8 * 48e3 + 160e3 + 45 * 0.6e3
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py, collected by tools/collect_profiles.sh),
 # by BASELINE configuration (the exact command `bench.py --config N`; config 1 = the default command)
 PMC_PROFILES = {1: os.path.join(ROOT, "profiles", "pmc_latest.json"), 2: os.path.join(ROOT, "profiles", "pmc_config2_latest.json"),
@@ -714,7 +714,7 @@ def main():
                                   "fine_candidates_per_launch": n_fine,
                                   "note": "algorithmic fp32 flops of the reference-shaped dataflow (SURVEY 8d: 1.3 GFLOP/frame, "
                                           "fine sync 0.78 G of 18 full IFFTs); the kernel executes two IFFTs and eight frequency-domain scores "
-                                          "per candidate (1.17 MFLOP), fused multiply-adds only where the arithmetic contract names them (the "
+                                          "per candidate (0.74 MFLOP), fused multiply-adds only where the arithmetic contract names them (the "
                                           "frequency-domain scores are almost all fma: its ceiling lies between the plain-op and the fma rate)"}},
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "other_configs": other,
