@@ -15,7 +15,7 @@ NAMES = ["(outside fft: scoring tail of the previous step, loop)", "stage 1: sli
          "barrier", "stage 2: [4,4] butterflies + LDS stores", "barrier", "stage 3: LDS loads", "barrier", "stage 3: [5,5] (pruned) + LDS stores",
          "barrier", "  step 1: H stores", "  barrier after step 1",
          "final grid, Costas gate, LLRs", "  step 2: DPP row sums, magnitudes", "  (loop)",
-         "  step 1: slice + phase loads, taper, 10 complex multiplies", "  step 1: the 70 complex-by-real multiply-adds (16 K loads)", "time-scan scores + table set-up of the frequency scan",
+         "  step 1: slice + phase loads, taper, 10 complex multiplies", "  step 1: the 70 complex-by-real multiply-adds (K in registers)", "time-scan scores + table set-up of the frequency scan",
          "  step 2: the multiply-adds (H, cos / sin loads)", "scores of the eight tweaks (after the scan), first maximum"]
 
 
