@@ -480,7 +480,7 @@ static float fine_score_block(const cpx* z, int tb, int sym0) {
  *     T[s][t] = 1/3200 sum_{p = 0 .. 25} cos_ps (P_p + (-1)^s P_{50-p}) + i sin_ps (M_p - (-1)^s M_{50-p})
  * (p = 0 stands for the residues 0 and 50, p = 25 for the pair 25, 75 alone): four real multiply-adds per item, symbol and tone.
  * Contract (kernels/fine_sync.hpp: fine_fscore does exactly this, on 100 + 112 lanes):
- *   tables in double, rounded once: K[m] (m = -800 .. 899), (cos, sin)[s][p] (p = 0: (1, 0)), G[k] = e^{i pi (31 r - 100 j) / 3200};
+ *   tables in double, rounded once: K[m] (m = -900 .. 899), (cos, sin)[s][p] (p = 0: (1, 0)), G[k] = e^{i pi (31 r - 100 j) / 3200};
  *   Phi[k] = cmul(conj W3200[(k nb0) mod 3200], G[k]), W3200 the FFT's twiddle table;
  *   b[q] = cmul(X[k_q], Phi[k_q]), q = 0 .. 9 ascending in k (the first and the last are the tapered bins: fp64 product, rounded once);
  *   H: per component  fma(b, K, acc)  in ascending q;
@@ -489,14 +489,16 @@ static float fine_score_block(const cpx* z, int tb, int sym0) {
  *      s = 0 adds A; even s:  re = fma(A.re, cos, fma(-C.im, sin, re)), im = fma(A.im, cos, fma(C.re, sin, im));  odd s: the same with B, D;
  *      the partials combined as the binary tree ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) ... ; |T| from the components scaled by 1/3200;
  *      fp64 on / off sums as in fine_score_block. */
-static float g_K32[1700];
+static float g_K32[1800];                       /* K(m), m = -900 .. 899 */
+static cpx g_TW100[100];                        /* e^{-2 pi i m / 100} */
 static cpx g_CS100[6][26], g_G1000[1000];
 static int g_fs_ok = 0;
 static void make_fscore_tables(void) {
-    for (int m = -800; m < 900; m++) {
+    for (int m = -900; m < 900; m++) {
         const int r = ((m % 100) + 100) % 100;
-        g_K32[m + 800] = (r == 0) ? (m == 0 ? 32.0f : 0.0f) : (float)(sin(M_PI * (double)r / 100.0) / sin(M_PI * (double)m / 3200.0));
+        g_K32[m + 900] = (r == 0) ? (m == 0 ? 32.0f : 0.0f) : (float)(sin(M_PI * (double)r / 100.0) / sin(M_PI * (double)m / 3200.0));
     }
+    for (int m = 0; m < 100; m++) { const double a = -2.0 * M_PI * (double)m / 100.0; g_TW100[m].re = (float)cos(a); g_TW100[m].im = (float)sin(a); }
     for (int s = 1; s < 7; s++) for (int q = 0; q <= 25; q++) {
         const double a = 2.0 * M_PI * (double)((q * s) % 100) / 100.0;
         cpx v; v.re = (float)cos(a); v.im = (float)sin(a);
@@ -535,7 +537,7 @@ static float fine_fscore(const float* spec, int fb, int nb0) {
         for (int t = 0; t < 7; t++) {
             float hx = 0.0f, hy = 0.0f;
             for (int q = 0; q < 10; q++) {
-                const float kv = g_K32[r + 100 * (jlo + q - t) + 800];
+                const float kv = g_K32[r + 100 * (jlo + q - t) + 900];
                 hx = fmaf(b[q].re, kv, hx);
                 hy = fmaf(b[q].im, kv, hy);
             }
@@ -593,6 +595,101 @@ static float fine_fscore(const float* spec, int fb, int nb0) {
     return (float)(s1 + W6 * s2);
 }
 
+/* The final 79 x 8 grid of magnitudes, also straight from the spectrum slice (round 4, third step).  Same identity as fine_fscore with
+ * nb0 = tb, the first sample of symbol 0, and eight tones:  H[t][r] = sum_j b[k] K(k - 100 t)  (b = X Phi, ascending k, fma(b, K, acc)),
+ *     |T[s][t]| = 1/3200 | sum_{r < 100} H[t][r] e^{2 pi i r s / 100} |,   s = 0 .. 78,
+ * the sum over r as the forward 100-point DFT of conj H (its magnitude is the same), 100 = 10 x 10:
+ *     r = 10 r1 + r2, s = s1 + 10 s2:   A[r2][s1] = DFT10_{r1}(conj H[10 r1 + r2])[s1] * TW[r2 s1]   (TW[m] = e^{-2 pi i m / 100}; s1 = 0: no multiply)
+ *                                       T[s1 + 10 s2] = DFT10_{r2}(A[r2][s1])[s2]
+ * DFT10 (forward) by the prime-factor map: a0[n] = x[2n mod 10] + x[(5 + 2n) mod 10], a1[n] = their difference, n = 0 .. 4; dft5 of both;
+ * y[6 k mod 10] = a0[k], y[(5 + 6 k) mod 10] = a1[k].  Magnitude: re = T.re * (1/3200), im = T.im * (1/3200), sqrtf(re re + im im).
+ * The reference clamps a symbol's first sample to [0, 3168] (receiver.py:189-195: fine_symbol above): every symbol with tb + 32 s < 0
+ * reads the samples 0 .. 31, every one with tb + 32 s > 3168 the samples 3168 .. 3199.  Those get the grid row of position p = 0 / 3168:
+ * H with nb0 = p, |T[t]| = 1/3200 |sum_r H[t][r]| as 16 partial sums over r = c, c + 16, ... combined as the binary tree of fine_fscore. */
+static void fscore_H(const cpx* S, int fb, int nb0, int ntone, cpx H[8][100]) {
+    const cpx* W = get_twiddle(3200);
+    for (int r = 0; r < 100; r++) {
+        const int jlo = r < 50 ? -1 : -2;
+        cpx b[10];
+        for (int q = 0; q < 10; q++) {
+            const int k = r + 100 * (jlo + q);
+            cpx x = S[fb + k];
+            if (q == 0) { const double t = g_taper[k + 150]; x.re = (float)((double)x.re * t); x.im = (float)((double)x.im * t); }
+            if (q == 9) { const double t = g_taper[k - 750]; x.re = (float)((double)x.re * t); x.im = (float)((double)x.im * t); }
+            const cpx w = W[(int)((((long long)k * nb0) % 3200 + 3200) % 3200)];
+            cpx wc; wc.re = w.re; wc.im = -w.im;
+            b[q] = cmul(x, cmul(wc, g_G1000[k + 150]));
+        }
+        for (int t = 0; t < ntone; t++) {
+            float hx = 0.0f, hy = 0.0f;
+            for (int q = 0; q < 10; q++) {
+                const float kv = g_K32[r + 100 * (jlo + q - t) + 900];
+                hx = fmaf(b[q].re, kv, hx);
+                hy = fmaf(b[q].im, kv, hy);
+            }
+            H[t][r].re = hx; H[t][r].im = hy;
+        }
+    }
+}
+static void dft10_fwd(const cpx* x, cpx* y) {
+    cpx a0[5], a1[5];
+    for (int n = 0; n < 5; n++) { const cpx u = x[(2 * n) % 10], v = x[(5 + 2 * n) % 10]; a0[n] = cadd(u, v); a1[n] = csub(u, v); }
+    dft5(a0); dft5(a1);
+    for (int k = 0; k < 5; k++) { y[(6 * k) % 10] = a0[k]; y[(5 + 6 * k) % 10] = a1[k]; }
+}
+static void fine_grid_freq(const float* spec, int fb, int tb, float* g /*[79][8]*/) {
+    if (!g_taper_ok) make_taper();
+    if (!g_fs_ok) make_fscore_tables();
+    const cpx* S = (const cpx*)spec;
+    static __thread cpx H[8][100], A[8][10][10];
+    fscore_H(S, fb, tb, 8, H);
+    for (int t = 0; t < 8; t++) {
+        for (int r2 = 0; r2 < 10; r2++) {
+            cpx x[10], y[10];
+            for (int r1 = 0; r1 < 10; r1++) { x[r1].re = H[t][10 * r1 + r2].re; x[r1].im = -H[t][10 * r1 + r2].im; }
+            dft10_fwd(x, y);
+            for (int s1 = 0; s1 < 10; s1++) A[t][s1][r2] = (s1 == 0) ? y[0] : cmul(y[s1], g_TW100[r2 * s1]);
+        }
+        for (int s1 = 0; s1 < 10; s1++) {
+            cpx y[10];
+            dft10_fwd(A[t][s1], y);
+            for (int s2 = 0; s2 < 8; s2++) {
+                const int s = s1 + 10 * s2;
+                if (s > 78) continue;
+                const float re = y[s2].re * 0.0003125f, im = y[s2].im * 0.0003125f;
+                g[8 * s + t] = sqrtf(re * re + im * im);
+            }
+        }
+    }
+    /* clamped symbols */
+    int s_lo = 0, s_hi = 78;
+    while (s_lo <= 78 && tb + 32 * s_lo < 0) s_lo++;                 /* symbols 0 .. s_lo - 1 read position 0 */
+    while (s_hi >= 0 && tb + 32 * s_hi > 3168) s_hi--;               /* symbols s_hi + 1 .. 78 read position 3168 */
+    for (int side = 0; side < 2; side++) {
+        if (side == 0 ? (s_lo == 0) : (s_hi == 78)) continue;
+        fscore_H(S, fb, side == 0 ? 0 : 3168, 8, H);
+        for (int t = 0; t < 8; t++) {
+            cpx part[16];
+            for (int c = 0; c < 16; c++) {
+                float ax = 0.0f, ay = 0.0f;
+                for (int i = 0; i < 7; i++) { const int r = c + 16 * i; if (r < 100) { ax = ax + H[t][r].re; ay = ay + H[t][r].im; } }
+                part[c].re = ax; part[c].im = ay;
+            }
+            float q4[4][2];
+            for (int q = 0; q < 4; q++) {
+                const cpx* p = &part[4 * q];
+                q4[q][0] = (p[0].re + p[1].re) + (p[2].re + p[3].re);
+                q4[q][1] = (p[0].im + p[1].im) + (p[2].im + p[3].im);
+            }
+            const float tr = (q4[0][0] + q4[1][0]) + (q4[2][0] + q4[3][0]), ti = (q4[0][1] + q4[1][1]) + (q4[2][1] + q4[3][1]);
+            const float re = tr * 0.0003125f, im = ti * 0.0003125f;
+            const float m = sqrtf(re * re + im * im);
+            if (side == 0) for (int s = 0; s < s_lo; s++) g[8 * s + t] = m;
+            else for (int s = s_hi + 1; s <= 78; s++) g[8 * s + t] = m;
+        }
+    }
+}
+
 void ft8o_fine_grid(const float* spec, const ft8o_config* c, int fb, int tb, float* grid, float* score) {
     cpx* z = (cpx*)malloc(sizeof(cpx) * 3200);
     fine_zsig(spec, c, fb, z);
@@ -620,10 +717,9 @@ int ft8o_fine(const float* spec, const ft8o_config* c, int f0_idx, int h0_idx, i
         float sc = (f == 0) ? score_f0 : fine_fscore(spec, fb0 + f, tb0 + tt + 32 * 36);
         if (i == 0 || sc > best) { best = sc; ft = f; }
     }
-    fine_zsig(spec, c, fb0 + ft, z);
-    float g[79 * 8];
-    for (int s = 0; s < 79; s++) fine_symbol(z, tb0 + tt, s, g + 8 * s);
     free(z);
+    float g[79 * 8];
+    fine_grid_freq(spec, fb0 + ft, tb0 + tt, g);
     if (sgrid) memcpy(sgrid, g, sizeof(g));
     *ttweak = tt; *ftweak = ft;
     int nm = 0;

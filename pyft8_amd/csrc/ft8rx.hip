@@ -352,11 +352,11 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     host_twiddle(192000, FT8RX_SPEC_BINS, w); rc |= upload(h, &h->T.WR192k, w);
     host_twiddle(32, 32, w);       rc |= upload(h, &h->T.W32, w);
     {   // tables of the frequency-domain fine score (kernels/fine_sync.hpp: fine_fscore; oracle/ft8_oracle.c: make_fscore_tables -- same formulas)
-        std::vector<float> k32(1700);
+        std::vector<float> k32(1800);
         std::vector<cpx> cs(156), g1000(1000);
-        for (int m = -800; m < 900; m++) {
+        for (int m = -900; m < 900; m++) {
             const int r = ((m % 100) + 100) % 100;
-            k32[m + 800] = (r == 0) ? (m == 0 ? 32.0f : 0.0f) : (float)(sin(M_PI * (double)r / 100.0) / sin(M_PI * (double)m / 3200.0));
+            k32[m + 900] = (r == 0) ? (m == 0 ? 32.0f : 0.0f) : (float)(sin(M_PI * (double)r / 100.0) / sin(M_PI * (double)m / 3200.0));
         }
         for (int sidx = 1; sidx < 7; sidx++) for (int q = 0; q <= 25; q++) {
             const double a = 2.0 * M_PI * (double)((q * sidx) % 100) / 100.0;
@@ -369,7 +369,9 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
             const double a = M_PI * (31.0 * (double)r - 100.0 * (double)j) / 3200.0;
             g1000[k + 150] = make_float2((float)cos(a), (float)sin(a));
         }
-        rc |= upload(h, &h->T.K32, k32); rc |= upload(h, &h->T.CS100, cs); rc |= upload(h, &h->T.G1000, g1000);
+        std::vector<cpx> tw100(100);
+        for (int m = 0; m < 100; m++) { const double a = -2.0 * M_PI * (double)m / 100.0; tw100[m] = make_float2((float)cos(a), (float)sin(a)); }
+        rc |= upload(h, &h->T.K32, k32); rc |= upload(h, &h->T.CS100, cs); rc |= upload(h, &h->T.G1000, g1000); rc |= upload(h, &h->T.TW100, tw100);
     }
     if (rc) { g_create_err = h->err; ft8rx_destroy(h); return -2; }
     // LDPC tables

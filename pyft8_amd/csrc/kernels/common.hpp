@@ -17,8 +17,9 @@ struct Tables {
     const cpx* WR192k;       // [FT8RX_SPEC_BINS]
     const cpx* W32;
     const double* taper;     // [100]
-    const float* K32;        // [1700] K(m), m = -800 .. 899: the REAL factor of the 32-sample Dirichlet kernel, sin(pi (m mod 100) / 100) / sin(pi m / 3200) (fine_fscore)
+    const float* K32;        // [1800] K(m), m = -900 .. 899: the REAL factor of the 32-sample Dirichlet kernel, sin(pi (m mod 100) / 100) / sin(pi m / 3200) (fine_fscore)
     const cpx* CS100;        // [6][26] (cos, sin)(2 pi p s / 100), s = 1 .. 6, p = 0 .. 25
+    const cpx* TW100;        // [100] e^{-2 pi i m / 100}: twiddles of the 10 x 10 residue transform of the final grid
     const cpx* G1000;        // [1000] e^{i pi (31 r - 100 j) / 3200} for the slice bin k = r + 100 j = -150 .. 849
 };
 

@@ -266,8 +266,9 @@ FT8_DEV void fine_sym_quad(const cpx* z, int i0, int n2, const cpx* wq, float* m
 #define FS_H 156
 #define FS_MAG 1556
 struct FsLane {
-    float k[16];        // K(r + 100 d), d = jlo - 6 .. jlo + 9
-    cpx g[10];          // G[k_q], then Phi[k_q] = cmul(conj W3200[(k_q nb0) mod 3200], G[k_q]), k_q = r + 100 (jlo + q)
+    float k[17];        // K(r + 100 d), d = jlo - 7 .. jlo + 9 (the first one only for tone 7 of the final grid)
+    cpx g0[10];         // G[k_q], k_q = r + 100 (jlo + q)
+    cpx g[10];          // Phi[k_q] = cmul(conj W3200[(k_q nb0) mod 3200], G[k_q]) for the current nb0
     double tap;         // taper of the lane's first and last bin (the same value: k_0 + 150 = k_9 - 750)
     cpx cs[2];          // this thread's part of the (cos, sin) table on its way to the image
     int r, jlo;
@@ -278,14 +279,14 @@ FT8_DEV void fscore_fetch(FsLane& L, const Tables& T, int tid) {            // r
     L.r = tid < 64 ? 50 + ln : ln;
     L.jlo = tid < 64 ? -2 : -1;
 #pragma unroll
-    for (int u = 0; u < 16; u++) L.k[u] = T.K32[800 + L.r + 100 * (L.jlo - 6 + u)];
+    for (int u = 0; u < 17; u++) L.k[u] = T.K32[900 + L.r + 100 * (L.jlo - 7 + u)];
 #pragma unroll
-    for (int q = 0; q < 10; q++) L.g[q] = T.G1000[L.r + 100 * (L.jlo + q) + 150];
+    for (int q = 0; q < 10; q++) L.g0[q] = T.G1000[L.r + 100 * (L.jlo + q) + 150];
     L.tap = T.taper[tid < 64 ? ln : 50 + ln];
 #pragma unroll
     for (int u = 0; u < 2; u++) { const int i = tid + FINE_NT * u; L.cs[u] = T.CS100[i < 156 ? i : 0]; }
 }
-FT8_DEV void fscore_prepare(FsLane& L, cpx* zi, const Tables& T, int nb0, int tid) {
+FT8_DEV void fscore_phases(FsLane& L, const Tables& T, int nb0) {          // the lane's ten phases for a block starting at sample nb0 (any sign)
     cpx w[10];
     {   // W3200[(k_q nb0) mod 3200], k_q = r + 100 (jlo + q): one reduction for the lane's first bin, then steps of (100 nb0) mod 3200
         const int step = (((100 * nb0) % 3200) + 3200) % 3200;
@@ -294,11 +295,16 @@ FT8_DEV void fscore_prepare(FsLane& L, cpx* zi, const Tables& T, int nb0, int ti
         for (int q = 0; q < 10; q++) { w[q] = T.W3200[idx]; idx += step; idx -= (idx >= 3200) ? 3200 : 0; }
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++) { const int i = tid + FINE_NT * u; if (i < 156) zi[FS_CS + i] = L.cs[u]; }
+    for (int q = 0; q < 10; q++) L.g[q] = cmul(make_float2(w[q].x, -w[q].y), L.g0[q]);
+}
+FT8_DEV void fscore_prepare(FsLane& L, cpx* zi, const Tables& T, int nb0, int tid) {
+    fscore_phases(L, T, nb0);
 #pragma unroll
-    for (int q = 0; q < 10; q++) L.g[q] = cmul(make_float2(w[q].x, -w[q].y), L.g[q]);
+    for (int u = 0; u < 2; u++) { const int i = tid + FINE_NT * u; if (i < 156) zi[FS_CS + i] = L.cs[u]; }
     __syncthreads();
 }
+// step 1 for NTONE tones (7: a frequency tweak's score; 8: the final grid)
+template <int NTONE>
 FT8_DEV void fscore_p1(const cpx* S, int off, const FsLane& L, cpx* H, int tid FT_ARG) {
     cpx b[10];
 #pragma unroll
@@ -308,16 +314,16 @@ FT8_DEV void fscore_p1(const cpx* S, int off, const FsLane& L, cpx* H, int tid F
         b[q] = cmul(x, L.g[q]);
     }
     FT(16);
-    // H_t = sum_q b[q] K(k_q - 100 t), q ascending; walked by d = j - t = jlo - 6 + u so that every K value is used from its register:
-    // q = u + t - 6, and for a given tone the terms still arrive in ascending q
-    float hx[7], hy[7];
+    // H_t = sum_q b[q] K(k_q - 100 t), q ascending; walked by d = j - t = jlo - 7 + u so that every K value is used from its register:
+    // q = u + t - 7, and for a given tone the terms still arrive in ascending q
+    float hx[NTONE], hy[NTONE];
 #pragma unroll
-    for (int t = 0; t < 7; t++) { hx[t] = 0.0f; hy[t] = 0.0f; }
+    for (int t = 0; t < NTONE; t++) { hx[t] = 0.0f; hy[t] = 0.0f; }
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
+    for (int u = 0; u < 17; u++) {
 #pragma unroll
-        for (int t = 0; t < 7; t++) {
-            const int q = u + t - 6;
+        for (int t = 0; t < NTONE; t++) {
+            const int q = u + t - 7;
             if (q >= 0 && q < 10) {
                 hx[t] = __builtin_fmaf(b[q].x, L.k[u], hx[t]);
                 hy[t] = __builtin_fmaf(b[q].y, L.k[u], hy[t]);
@@ -326,7 +332,16 @@ FT8_DEV void fscore_p1(const cpx* S, int off, const FsLane& L, cpx* H, int tid F
     }
     FT(17);
 #pragma unroll
-    for (int t = 0; t < 7; t++) H[t * 100 + L.r] = make_float2(hx[t], hy[t]);
+    for (int t = 0; t < NTONE; t++) H[t * 100 + L.r] = make_float2(hx[t], hy[t]);
+}
+// forward 10-point DFT by the prime-factor map (no twiddles between the radix-2 and the radix-5 part): oracle/ft8_oracle.c: dft10_fwd
+FT8_DEV void dft10_fwd(const cpx* x, cpx* y) {
+    cpx a0[5], a1[5];
+#pragma unroll
+    for (int n = 0; n < 5; n++) { const cpx u = x[(2 * n) % 10], v = x[(5 + 2 * n) % 10]; a0[n] = cadd(u, v); a1[n] = csub(u, v); }
+    dft<5>(a0); dft<5>(a1);
+#pragma unroll
+    for (int k = 0; k < 5; k++) { y[(6 * k) % 10] = a0[k]; y[(5 + 6 * k) % 10] = a1[k]; }
 }
 FT8_DEV float row16_sum(float v) {                 // sum over the 16 lanes of a DPP row, the same value on every lane: ((p0+p1)+(p2+p3)) + ... as a binary tree
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));      // quad_perm:[1,0,3,2]
@@ -342,7 +357,7 @@ FT8_DEV void fine_fscore(const cpx* S, int off, const FsLane& L, cpx* zi, int n,
     cpx* H = zi + FS_H + (n & 1) * 700;
     float* mags = reinterpret_cast<float*>(zi + FS_MAG) + n * 56;
     const int lane = tid & 63;
-    if (lane < 50) fscore_p1(S, off, L, H, tid FT_PASS);
+    if (lane < 50) fscore_p1<7>(S, off, L, H, tid FT_PASS);
     FT(11);
     __syncthreads();
     FT(12);
@@ -509,25 +524,64 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         }
     }
     FT(20);
-    {   // full series for the 79 x 8 grid.  Nothing thread-specific of the first transform (addresses, twiddles) is to stay alive across the
-        // frequency scan for this one: with the plain `tid` the compiler keeps them, and spills 340 B around the scan (k_fine 2.29 instead of 1.62 ms)
-        int tid2 = tid;
-        asm volatile("" : "+v"(tid2));
-        fine_fft(S, 182 + ft, z, w400, T, tid2, 0, 3200 FT_PASS);
-        sym32_twiddles(w32, tid2 & 3, wq);
-    }
-    // the 21 Costas symbols first (84 quad tasks: one round), then the gate; the 58 payload symbols (two rounds) only for the
-    // candidates that pass it -- 59 % of the candidates stop here (tools/ladder_stats.py)
+    // --- the 79 x 8 grid of the chosen tweaks, straight from the slice as well (oracle/ft8_oracle.c: fine_grid_freq): H for eight tones with
+    // nb0 = the first sample of symbol 0, then |sum_r H[t][r] e^{2 pi i r s / 100}| for s = 0 .. 78 as the forward 100-point DFT of conj H,
+    // 100 = 10 x 10 (r = 10 r1 + r2, s = s1 + 10 s2): 80 lanes transform the ten r1 of their (tone, r2), twiddle, 80 lanes the ten r2 of their
+    // (tone, s1).  No 3200-point transform, no symbol DFTs: 0.5 k instead of 1.4 k instructions per wave.
+    const int tb = tb0 + tt;
+    cpx* Hc = z;                       // [8][100]
+    cpx* Ab = z + 800;                 // [8][10 s1][10 r2]
     {
-        const int q = tid >> 2, n2 = tid & 3;
-        const bool valid = q < 21;
-        const int sy = valid ? 36 * (q / 7) + (q % 7) : 0;
-        float mag[8];
-        fine_sym_quad<8>(z, tb0 + tt + 32 * sy, n2, wq, mag);
-        if (valid && n2 == 0) {
+        const int t = (tid < 80) ? tid / 10 : 0, c10 = (tid < 80) ? tid - 10 * t : 0;
+        cpx tw[9];
 #pragma unroll
-            for (int b = 0; b < 8; b++) mg[sy * 8 + b] = mag[b];
+        for (int s1 = 1; s1 < 10; s1++) tw[s1 - 1] = T.TW100[c10 * s1];           // requested now, used after the first barrier
+        fscore_phases(L, T, tb);
+        if (lane < 50) fscore_p1<8>(S, 182 + ft, L, Hc, tid FT_PASS);
+        __syncthreads();
+        if (tid < 80) {                                                           // (tone t, r2 = c10): over r1
+            cpx x[10], y[10];
+#pragma unroll
+            for (int r1 = 0; r1 < 10; r1++) { const cpx h = Hc[t * 100 + 10 * r1 + c10]; x[r1] = make_float2(h.x, -h.y); }
+            dft10_fwd(x, y);
+            Ab[t * 100 + c10] = y[0];
+#pragma unroll
+            for (int s1 = 1; s1 < 10; s1++) Ab[t * 100 + 10 * s1 + c10] = cmul(y[s1], tw[s1 - 1]);
         }
+        __syncthreads();
+        if (tid < 80) {                                                           // (tone t, s1 = c10): over r2
+            cpx x[10], y[10];
+#pragma unroll
+            for (int r2 = 0; r2 < 10; r2++) x[r2] = Ab[t * 100 + 10 * c10 + r2];
+            dft10_fwd(x, y);
+#pragma unroll
+            for (int s2 = 0; s2 < 8; s2++) {
+                const int sy = c10 + 10 * s2;
+                const float re = y[s2].x * FINE_INV, im = y[s2].y * FINE_INV;
+                if (sy < 79) mg[sy * 8 + t] = sqrtf(re * re + im * im);
+            }
+        }
+    }
+    // the reference clamps a symbol's first sample to [0, 3168]: the symbols before sample 0 all read the samples 0 .. 31, symbol 78 beyond
+    // 3168 the last 32 -- their rows are the row of that position (block-uniform; a candidate has at most one of the two)
+    const int n_lo = (tb < 0) ? (31 - tb) / 32 : 0;                  // symbols 0 .. n_lo - 1 start before sample 0
+    const int s_hi = (3168 - tb) / 32;                               // the last symbol that still starts at or before 3168 (tb <= 702: >= 77)
+    if (n_lo > 0 || s_hi < 78) {
+        __syncthreads();                                             // the rows above are written, Hc is free
+        fscore_phases(L, T, n_lo > 0 ? 0 : 3168);
+        if (lane < 50) fscore_p1<8>(S, 182 + ft, L, Hc, tid FT_PASS);
+        __syncthreads();
+        const int c = tid & 15, t = tid >> 4;
+        float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            if (i < 6 || c < 4) { const cpx h = Hc[t * 100 + c + 16 * i]; ax = ax + h.x; ay = ay + h.y; }
+        }
+        ax = row16_sum(ax); ay = row16_sum(ay);
+        const float re = ax * FINE_INV, im = ay * FINE_INV;
+        const float m = sqrtf(re * re + im * im);
+        const int sy = (n_lo > 0) ? c : s_hi + 1 + c;
+        if ((n_lo > 0) ? (c < n_lo) : (sy <= 78)) mg[sy * 8 + t] = m;
     }
     __syncthreads();
     // --- Costas gate (receiver.py:164-167)
@@ -541,21 +595,6 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     if (tid < 64) { int nm = __popcll(__ballot(match)); if (tid == 0) ish[1] = nm; }
     __syncthreads();
     const int nsync = ish[1];
-    if (nsync > 6 || (trip && t_sgrid)) {                                      // block-uniform
-#pragma unroll 1
-        for (int r = 0; r < (232 + FINE_NT - 1) / FINE_NT; r++) {             // payload symbols (receiver.py:14)
-            const int task = tid + FINE_NT * r, j = task >> 2, n2 = task & 3;
-            const bool valid = j < 58;
-            const int sy = (int)d_PAYSYM[valid ? j : 0];
-            float mag[8];
-            fine_sym_quad<8>(z, tb0 + tt + 32 * sy, n2, wq, mag);
-            if (valid && n2 == 0) {
-#pragma unroll
-                for (int b = 0; b < 8; b++) mg[sy * 8 + b] = mag[b];
-            }
-        }
-        __syncthreads();
-    }
     if (trip && t_sgrid) for (int i = tid; i < 632; i += FINE_NT) t_sgrid[(size_t)bid * 632 + i] = mg[i];
     int ret = 1; float sd = 0.0f; int snr = 0;
     if (nsync <= 6) ret = 0;           // block-uniform
