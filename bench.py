@@ -55,9 +55,10 @@ VALU_PEAK_TFLOPS = 157.3
 # time scan 140 k (radix-8 pass with its zero inputs left out 29 k + [4,4] stage 54 k + [5,5] stage with the last pass pruned 57 k) + its 56
 # symbol DFTs on lane quads (0.6 k each); EIGHT FREQUENCY-DOMAIN SCORES since round 4 (per residue 10 complex multiplies and 70
 # complex-by-real multiply-adds, x 100 residues = 34 k; then per tone 26 items of four residues, 16 adds + 6 symbols x 4 fmas each, x 7 tones
-# = 12 k, + the 16-lane sums 1.5 k: 48 k each, against 140 k + 7 x 0.6 k for the pruned IFFT + symbol DFTs they replace); the full final IFFT
-# 160 k; final grid: 21 Costas symbols always, the 58 payload symbols for the 41 % of candidates that pass the gate (45 symbols on average)
-EXEC_FLOP_FINE_CAND = 140e3 + 56 * 0.6e3 + 8 * 48e3 + 160e3 + 45 * 0.6e3
+# = 12 k, + the 16-lane sums 1.5 k: 48 k each, against 140 k + 7 x 0.6 k for the pruned IFFT + symbol DFTs they replace); THE FINAL GRID
+# also from the slice (H for eight tones 38 k, 160 ten-point transforms + twiddles + magnitudes 26 k, and for the 30 % of candidates with
+# clamped symbols one more H pass: 76 k on average, against 160 k + 45 x 0.6 k for the full IFFT + symbol DFTs)
+EXEC_FLOP_FINE_CAND = 140e3 + 56 * 0.6e3 + 8 * 48e3 + 76e3
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py, collected by tools/collect_profiles.sh),
 # by BASELINE configuration (the exact command `bench.py --config N`; config 1 = the default command)
 PMC_PROFILES = {1: os.path.join(ROOT, "profiles", "pmc_latest.json"), 2: os.path.join(ROOT, "profiles", "pmc_config2_latest.json"),
@@ -705,16 +706,16 @@ def main():
                                   "whole_path_frac": value / world * ALG_FLOP_FRAME / 1e12 / VALU_PEAK_TFLOPS,
                                   "fine_achieved": ALG_FLOP_FINE * B / (acc["fine"] * 1e-3) / 1e12,
                                   "fine_frac": ALG_FLOP_FINE * B / (acc["fine"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
-                                  # what k_fine really executes: EXEC_FLOP_FINE_CAND fp32 mul/add per candidate that reaches it (10 pruned
-                                  # IFFTs + symbol DFTs), no FMA => its ceiling is half the FMA peak
+                                  # what k_fine really executes: EXEC_FLOP_FINE_CAND fp32 operations per candidate that reaches it (one pruned
+                                  # IFFT + frequency-domain scores and grid; an fma counts 2)
                                   "fine_executed_flop_per_launch": EXEC_FLOP_FINE_CAND * n_fine,
                                   "fine_executed_achieved": EXEC_FLOP_FINE_CAND * n_fine / (acc["fine"] * 1e-3) / 1e12,
                                   "fine_executed_frac_of_nofma_peak": EXEC_FLOP_FINE_CAND * n_fine / (acc["fine"] * 1e-3) / 1e12 / (VALU_PEAK_TFLOPS / 2),
                                   "fine_executed_frac_of_fma_peak": EXEC_FLOP_FINE_CAND * n_fine / (acc["fine"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                                   "fine_candidates_per_launch": n_fine,
                                   "note": "algorithmic fp32 flops of the reference-shaped dataflow (SURVEY 8d: 1.3 GFLOP/frame, "
-                                          "fine sync 0.78 G of 18 full IFFTs); the kernel executes two IFFTs and eight frequency-domain scores "
-                                          "per candidate (0.74 MFLOP), fused multiply-adds only where the arithmetic contract names them (the "
+                                          "fine sync 0.78 G of 18 full IFFTs); the kernel executes ONE pruned IFFT, eight frequency-domain scores and a frequency-domain grid "
+                                          "per candidate (0.63 MFLOP), fused multiply-adds only where the arithmetic contract names them (the "
                                           "frequency-domain scores are almost all fma: its ceiling lies between the plain-op and the fma rate)"}},
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "other_configs": other,
