@@ -1268,6 +1268,22 @@ int ft8rx_debug_fine_times(ft8rx_handle* h, unsigned long long* out32, int reset
 }
 #endif
 
+#ifdef OSD_TIMING
+int ft8rx_debug_osd_times(ft8rx_handle* h, unsigned long long* out16, int reset) {       // timing-only builds (tools/osd_timing.py)
+    if (!h) return -1;
+    ENTER(h);
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    std::vector<unsigned long long> all((size_t)32768 * 10);
+    if (out16) {
+        if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_osd_t), sizeof(unsigned long long) * all.size()) != hipSuccess) return -2;
+        for (int i = 0; i < 16; i++) out16[i] = 0;
+        for (size_t b = 0; b < 32768; b++) for (int i = 0; i < 10; i++) out16[i == 9 ? 15 : i] += all[b * 10 + i];
+    }
+    if (reset) { std::fill(all.begin(), all.end(), 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_osd_t), all.data(), sizeof(unsigned long long) * all.size()) != hipSuccess) return -2; }
+    return 0;
+}
+#endif
+
 int ft8rx_math_probe(ft8rx_handle* h, int which, const float* x, int n, float* y) {
     if (!h || !x || !y || n < 1) return -1;
     ENTER(h);

@@ -15,6 +15,18 @@
 //      rebuild the codeword, run the validity predicate and log the reference's unpack() call.
 // The trial list (order 0, single flips, the reference's restricted double flips, then the build's order-3 extension) is a
 // table built by the host from the configuration, in the reference's trial order (decoders.py:248-272).
+// Timing-only builds (-DOSD_TIMING, tools/osd_timing.py): lane 0 of every attempt accumulates the shader cycles between consecutive marks
+// and adds them to g_osd_t[] at the end.  Never defined in the product.
+#ifdef OSD_TIMING
+__device__ unsigned long long g_osd_t[32768][10];       // per block: plain adds by lane 0 of its one wave, summed by the host (no atomics in the timed code)
+#define OT_DECL unsigned long long ot_prev = __builtin_readcyclecounter();
+#define OT(i) do { const unsigned long long ot_now = __builtin_readcyclecounter(); if (lane == 0) g_osd_t[blockIdx.x & 32767][i] += ot_now - ot_prev; ot_prev = __builtin_readcyclecounter(); } while (0)
+#define OT_FLUSH do { if (lane == 0) g_osd_t[blockIdx.x & 32767][9] += 1ull; } while (0)
+#else
+#define OT_DECL
+#define OT(i) do { } while (0)
+#define OT_FLUSH do { } while (0)
+#endif
 FT8_DEV uint64_t shfl64(uint64_t v, int src) {
     uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
@@ -54,6 +66,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     __shared__ uint32_t hmw[3];
     __shared__ uint16_t fsyn[OSD_MAXFLIP + 2];             // [i] flip i, [OSD_MAXFLIP] = 0 ("no flip"), [OSD_MAXFLIP + 1] order-0 codeword
     int frame = 0, ci = 0, slot = 0; size_t vec = bid;
+    OT_DECL
     if (mode == 0) {
         slot = bid % 10; int c = bid / 10; frame = c / MAXC; ci = c % MAXC;
         if (ci >= ncand[frame]) return;
@@ -82,6 +95,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
         skey[i] = key;
     }
     __syncthreads();
+    OT(0);
 #ifndef OSD_TIMING_SKIP_SORT            /* timing-only builds (tools/ab_variants.sh): never defined in the product */
 #pragma unroll                          /* all 36 steps straight-line: positions and directions become constants, no scalar loop control */
     for (int size = 2; size <= 256; size <<= 1) {
@@ -110,6 +124,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     // still untouched systematic columns: about 40 % of the basis).  The scalar pipe issues one instruction per cycle per CU and
     // is this kernel's bottleneck (profiles/r02_notes.md), so the bookkeeping is kept to lock words and one accepted-position bit
     // per step; everything that can wait (hard-decision mask, flip rows, syndromes) is done afterwards on the vector side.
+    OT(1);
     const int ord0 = (int)(uint32_t)skey[lane], ord1 = (int)(uint32_t)skey[64 + lane], ord2 = (lane < 46) ? (int)(uint32_t)skey[128 + lane] : 0;
     const bool has2 = lane < 46;
     uint32_t x00 = d_G0T[ord0][0], x01 = d_G0T[ord0][1], x02 = d_G0T[ord0][2];
@@ -149,11 +164,13 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     // form cost 9 scalar instructions of loop control per step on the kernel's bottleneck pipe, this one 3
 #define OSD_RUN(XA, XB, XC, ACC, N) { lim = (k < 91) ? (N) : 0; for (int il = 0; il < lim; il++) { asm volatile("" : "+s"(il)); OSD_STEP(XA, XB, XC, ACC, il) } }
     int lim;
+    OT(2);
     OSD_RUN(x00, x01, x02, acc0, 64)
     OSD_RUN(x10, x11, x12, acc1, 64)
     OSD_RUN(x20, x21, x22, acc2, 46)
 #undef OSD_RUN
 #undef OSD_STEP
+    OT(3);
     // Every accepted column is now a unit vector (its pivot row).  Acceptance order = position order, so the accepted column at
     // position p is the kk-th accepted one with kk = number of accepted positions before p.
     const bool in0 = (acc0 >> lane) & 1ull, in1 = (acc1 >> lane) & 1ull, in2 = (acc2 >> lane) & 1ull;
@@ -184,6 +201,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     }
     __syncthreads();
     const uint32_t hm0 = hmw[0], hm1 = hmw[1], hm2 = hmw[2];
+    OT(4);
     // per column: bit i = flip i has a 1 in this column (i < 62), bit 63 = the order-0 codeword bit
     uint64_t f0 = (uint64_t)((__popc(x00 & hm0) + __popc(x01 & hm1) + __popc(x02 & hm2)) & 1) << 63,
              f1 = (uint64_t)((__popc(x10 & hm0) + __popc(x11 & hm1) + __popc(x12 & hm2)) & 1) << 63,
@@ -207,6 +225,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
         ftabB[ord0] = g0; ftabB[ord1] = g1; if (has2) ftabB[ord2] = g2;
     }
     __syncthreads();
+    OT(5);
     // CRC syndromes (the CRC is linear): lane i < min(nflip, 62) takes flip i, lane 63 the order-0 codeword (flips 62.. in a second round).  The lane gathers its word as a
     // 91-bit column set (bit `bitsel` of every ftab entry), then each of the 14 syndrome bits is a masked parity (d_SYNM)
     {
@@ -247,6 +266,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
         if (OSD_FLIPS_A + lane < nflip) fsyn[OSD_FLIPS_A + lane] = (uint16_t)sy;
     }
     __syncthreads();
+    OT(6);
     const unsigned syn_c = fsyn[OSD_MAXFLIP + 1];
     const uint64_t M1 = (1ull << 27) - 1, M2 = (1ull << 46) - 1;
     Att res; memset(&res, 0, sizeof(res)); res.n_its = -1;
@@ -299,7 +319,9 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
         }
         if (done) break;
     }
+    OT(7);
     if (lane == 0) attO[vec] = res;
+    OT_FLUSH;
 }
 
 
