@@ -36,6 +36,9 @@ extern "C" {
 #define FT8RX_MAX_F0     960
 #endif
 #define FT8RX_MAX_CANDS  256      /* upper bound for config.max_cands */
+#define FT8RX_MIN_H0     (-140)   /* bounds of config.h0_lo / h0_hi (search_time_range -6.1 .. +8.3 s; the reference's default is -2 .. +3 s): within them the */
+#define FT8RX_MAX_H0     220      /* middle Costas block of every candidate and time tweak lies inside the 3200-sample fine-sync series, where the     */
+                                  /* frequency-domain scores equal the reference's clamped reads (receiver.py:189-195) sample for sample                */
 #define FT8RX_EVENT_CAP  512      /* per-frame capacity of the CRC-pass event log */
 
 /* Receiver(...) kwargs (receiver.py:311-313) + module/decoder constants (receiver.py:30,78,91,95;

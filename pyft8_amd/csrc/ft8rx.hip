@@ -273,7 +273,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
 int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_handle** out) {
     if (!cfg || !out || max_frames < 1) { set_err(nullptr, "ft8rx_create: bad arguments"); return -1; }
     if (cfg->max_cands < 1 || cfg->max_cands > MAXC || cfg->f0_lo < 4 || cfg->f0_hi > FT8RX_MAX_F0 || cfg->f0_lo >= cfg->f0_hi ||
-        cfg->h0_hi <= cfg->h0_lo || cfg->h0_hi - cfg->h0_lo > 352 || cfg->bp_nc0_a > cfg->bp_nc0_b || cfg->bp_iters_a > cfg->bp_iters_b ||
+        cfg->h0_hi <= cfg->h0_lo || cfg->h0_hi - cfg->h0_lo > 352 || cfg->h0_lo < FT8RX_MIN_H0 || cfg->h0_hi > FT8RX_MAX_H0 || cfg->bp_nc0_a > cfg->bp_nc0_b || cfg->bp_iters_a > cfg->bp_iters_b ||
         cfg->osd_single < 0 || cfg->osd_single > OSD_MAXFLIP || cfg->osd_double < 0 || cfg->osd_double > OSD_MAXFLIP ||
         cfg->osd_triple < 0 || cfg->osd_triple > 40 || cfg->osd_max_hd < 0 || cfg->osd_max_hd > 174 ||
         osd_trial_table(cfg->osd_single, cfg->osd_double, cfg->osd_triple).size() > OSD_MAXTRIALS) {

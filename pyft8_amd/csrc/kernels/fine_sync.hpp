@@ -564,9 +564,9 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     }
     // the reference clamps a symbol's first sample to [0, 3168]: the symbols before sample 0 all read the samples 0 .. 31, symbol 78 beyond
     // 3168 the last 32 -- their rows are the row of that position (block-uniform; a candidate has at most one of the two)
-    const int n_lo = (tb < 0) ? (31 - tb) / 32 : 0;                  // symbols 0 .. n_lo - 1 start before sample 0
-    const int s_hi = (3168 - tb) / 32;                               // the last symbol that still starts at or before 3168 (tb <= 702: >= 77)
-    if (n_lo > 0 || s_hi < 78) {
+    const int n_lo = (tb < 0) ? min(79, (31 - tb) / 32) : 0;        // symbols 0 .. n_lo - 1 start before sample 0
+    const int s_up = (tb > 3168) ? 0 : min(79, (3168 - tb) / 32 + 1);  // symbols s_up .. 78 start beyond sample 3168 (default search range: at most symbol 78)
+    if (n_lo > 0 || s_up < 79) {
         __syncthreads();                                             // the rows above are written, Hc is free
         fscore_phases(L, T, n_lo > 0 ? 0 : 3168);
         if (lane < 50) fscore_p1<8>(S, 182 + ft, L, Hc, tid FT_PASS);
@@ -580,8 +580,8 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         ax = row16_sum(ax); ay = row16_sum(ay);
         const float re = ax * FINE_INV, im = ay * FINE_INV;
         const float m = sqrtf(re * re + im * im);
-        const int sy = (n_lo > 0) ? c : s_hi + 1 + c;
-        if ((n_lo > 0) ? (c < n_lo) : (sy <= 78)) mg[sy * 8 + t] = m;
+        if (n_lo > 0) { for (int sy = c; sy < n_lo; sy += 16) mg[sy * 8 + t] = m; }
+        else { for (int sy = s_up + c; sy < 79; sy += 16) mg[sy * 8 + t] = m; }
     }
     __syncthreads();
     // --- Costas gate (receiver.py:164-167)

@@ -981,6 +981,29 @@ def test_reduced_search_ranges():
         _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
 
 
+def test_wide_time_window_clamped_symbols():
+    """search_time_range far beyond the reference's default: candidates whose first symbols start before sample 0 (up to all of the
+    first Costas block and more) or whose last symbols start beyond sample 3168 of the fine-sync series -- the reference clamps those
+    reads (receiver.py:189-195), the frequency-domain grid takes their rows from the clamp position.  Two windows, because the span is
+    limited to 352 hops; records, events and LLR-dependent outcomes identical to the oracle."""
+    from pyft8_amd import _lib, synth
+    from pyft8_amd.receiver import config_from_kwargs
+    audio = synth.make_batch(61000, 3)
+    for tr in ((-6.0, 3.0), (-1.0, 8.2)):
+        cfg = config_from_kwargs(sync_score_min=70, max_cands=256, search_time_range=tr)
+        assert _lib.MIN_H0 <= cfg.h0_lo < cfg.h0_hi <= _lib.MAX_H0
+        h = _lib.Handle(cfg, max_frames=3)
+        rec, cnt, ev, evc = h.decode_batch(audio)
+        h.close()
+        ocfg = O.default_config(**_lib.fft_plans(), sync_score_min=70.0, max_cands=256, f0_lo=cfg.f0_lo, f0_hi=cfg.f0_hi, h0_lo=cfg.h0_lo, h0_hi=cfg.h0_hi)
+        n_edge = 0
+        for i in range(3):
+            _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
+            h0 = rec[i]["h0_idx"][:cnt[i]]
+            n_edge += int(((h0 < -4) | (h0 > 84)).sum())
+        assert n_edge > 50, n_edge           # the window really produced candidates with clamped symbols
+
+
 def test_device_synth_generator(H, ocfg):
     """frames generated on the GPU are valid FT8 (most truth messages decode, none false), have the
     right noise level, are deterministic, and decode identically on GPU and oracle."""
@@ -1213,6 +1236,10 @@ def test_error_paths_and_lifecycle():
         _lib.Handle(_lib.default_config(max_cands=1000))
     with pytest.raises(_lib.Ft8rxError, match="configuration"):
         _lib.Handle(_lib.default_config(f0_lo=0))
+    with pytest.raises(_lib.Ft8rxError, match="configuration"):
+        _lib.Handle(_lib.default_config(h0_lo=_lib.MIN_H0 - 1))            # the middle Costas block would leave the fine-sync series
+    with pytest.raises(_lib.Ft8rxError, match="configuration"):
+        _lib.Handle(_lib.default_config(h0_lo=100, h0_hi=_lib.MAX_H0 + 1))
     with pytest.raises(_lib.Ft8rxError, match="device"):
         _lib.Handle(device=99)
     h = _lib.Handle(max_frames=2)
