@@ -5,7 +5,8 @@
 
 // ------------------------------------------------------------------------------------ OSD (decoders.py:223-272)
 // One wavefront per attempt, three phases:
-//   1. reliability order: LDS bitonic network over 256 composite keys (fixed tie rule for the reference's unstable argsort);
+//   1. reliability order: bitonic network over 256 composite keys held in registers, exchanged by DPP / ds_swizzle / ds_bpermute (fixed tie
+//      rule for the reference's unstable argsort);
 //   2. most-reliable-basis Gauss-Jordan over GF(2) with the generator held COLUMN-wise: lane l owns columns l, 64+l, 128+l
 //      of G0 (91 row bits each, 3 x u32).  A visited column is broadcast to scalar registers; "independent of the accepted
 //      columns" is then a scalar test (any 1 in an unlocked row), the pivot row a scalar find-first-set, and the elimination
@@ -30,6 +31,26 @@ __device__ unsigned long long g_osd_t[32768][10];       // per block: plain adds
 FT8_DEV uint64_t shfl64(uint64_t v, int src) {
     uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
+}
+
+// the value of lane ^ S: quad permutes (DPP) for S = 1, 2, ds_swizzle (crossbar only, no address register) for 4, 8, 16, ds_bpermute for 32
+template <int S> FT8_DEV uint32_t osd_xlane(uint32_t v, int lane) {
+    if (S == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);          // quad_perm:[1,0,3,2]
+    if (S == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);          // quad_perm:[2,3,0,1]
+    if (S == 4 || S == 8 || S == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (S << 10));   // bit mode: lane ^ S within 32
+    return __shfl(v, lane ^ S);
+}
+// one compare-exchange step of the bitonic network between lanes S apart: this lane keeps the smaller key iff keep_min
+template <int S> FT8_DEV uint64_t osd_cx(uint64_t k, int lane, bool keep_min) {
+    const uint64_t o = ((uint64_t)osd_xlane<S>((uint32_t)(k >> 32), lane) << 32) | osd_xlane<S>((uint32_t)k, lane);
+    return ((k < o) == keep_min) ? k : o;
+}
+// the lane strides S, S/2, ..., 1 of one merge on NQ registers; up(q) = direction of block q
+template <int S, int NQ, typename UP> FT8_DEV void osd_merge_lanes(uint64_t* kq, int lane, UP up) {
+    const bool lower = (lane & S) == 0;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) kq[q] = osd_cx<S>(kq[q], lane, lower == up(q));
+    if constexpr (S > 1) osd_merge_lanes<S / 2, NQ>(kq, lane, up);
 }
 
 #define OSD_MAXFLIP 91            /* flip rows kept per attempt = all 91 basis positions (decoders.py:244-246 takes any count up to the basis size) */
@@ -84,34 +105,42 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     }
     __syncthreads();
     // ---- reliability order: |llr| descending, ties and NaNs (last) by index (fixed rule for np.argsort, decoders.py:226).
-    // Bitonic network over 256 composite keys ((~magnitude bits) << 32 | index) in LDS: 36 compare-exchange steps.
-    for (int i = lane; i < 256; i += 64) {
+    // Bitonic network over 256 composite keys ((~magnitude bits) << 32 | index), element 64 q + lane in register q of the lane: the steps
+    // between lanes are cross-lane exchanges, the strides 64 / 128 are register pairs of one lane -- no LDS image, no barriers (the LDS form
+    // spent 21 % of the kernel here, 36 barriers per attempt: profiles/r04_osd_timing.txt).  Register 3 would hold the 64 padding keys
+    // (~0): every step that involves it is resolved by hand below.
+    uint64_t kq[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int i = lane + 64 * q;
         uint64_t key = ~0ull;
         if (i < 174) {
             const float x = llr[i];
             const uint32_t k32 = (x != x) ? 0u : ((__float_as_uint(x) & 0x7fffffffu) + 1u);
             key = ((uint64_t)(0xFFFFFFFFu - k32) << 32) | (uint32_t)i;
         }
-        skey[i] = key;
+        kq[q] = key;
     }
-    __syncthreads();
     OT(0);
 #ifndef OSD_TIMING_SKIP_SORT            /* timing-only builds (tools/ab_variants.sh): never defined in the product */
-#pragma unroll                          /* all 36 steps straight-line: positions and directions become constants, no scalar loop control */
-    for (int size = 2; size <= 256; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-            for (int h2 = 0; h2 < 2; h2++) {
-                const int t = lane + 64 * h2;
-                const int pos = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
-                const uint64_t ka = skey[pos], kb = skey[pos + stride];
-                const bool up = ((pos & size) == 0);
-                if ((ka > kb) == up) { skey[pos] = kb; skey[pos + stride] = ka; }
-            }
-            __syncthreads();
-        }
-    }
+    // sizes 2 .. 64: the three real blocks, each in its own register; block q ends ascending for even q, descending for odd q
+    osd_merge_lanes<1, 3>(kq, lane, [&](int) { return (lane & 2) == 0; });
+    osd_merge_lanes<2, 3>(kq, lane, [&](int) { return (lane & 4) == 0; });
+    osd_merge_lanes<4, 3>(kq, lane, [&](int) { return (lane & 8) == 0; });
+    osd_merge_lanes<8, 3>(kq, lane, [&](int) { return (lane & 16) == 0; });
+    osd_merge_lanes<16, 3>(kq, lane, [&](int) { return (lane & 32) == 0; });
+    osd_merge_lanes<32, 3>(kq, lane, [&](int q) { return (q & 1) == 0; });
+    // size 128.  Blocks 0 (ascending) and 1 (descending) merge upwards: stride 64 is the register pair, then the lane strides.
+    { const uint64_t a = kq[0], b = kq[1]; const bool lt = a < b; kq[0] = lt ? a : b; kq[1] = lt ? b : a; }
+    osd_merge_lanes<32, 2>(kq, lane, [&](int) { return true; });
+    // Blocks 2 (ascending) and 3 (all padding) merge DOWNWARDS: the padding moves to block 2, block 3 becomes block 2 reversed.
+    uint64_t k3 = shfl64(kq[2], 63 - lane);
+    // size 256, upwards.  Stride 128: (block 0, padding) stays; (block 1, block 3) exchange.  Stride 64: (block 0, block 1) exchange;
+    // (padding, block 3) swap, i.e. block 2 := block 3.  Then the lane strides on blocks 0 .. 2.
+    { const uint64_t a = kq[1], b = k3; const bool lt = a < b; kq[1] = lt ? a : b; k3 = lt ? b : a; }
+    { const uint64_t a = kq[0], b = kq[1]; const bool lt = a < b; kq[0] = lt ? a : b; kq[1] = lt ? b : a; }
+    kq[2] = k3;
+    osd_merge_lanes<32, 3>(kq, lane, [&](int) { return true; });
 #endif
     // ---- Gauss-Jordan over GF(2), generator held column-wise in SORTED order: lane l of register set s owns the column at
     // reliability position 64 s + l (91 row bits: rows 0..63 as two u32, rows 64..90 in a third).  A row is "locked" once it has
@@ -125,7 +154,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     // is this kernel's bottleneck (profiles/r02_notes.md), so the bookkeeping is kept to lock words and one accepted-position bit
     // per step; everything that can wait (hard-decision mask, flip rows, syndromes) is done afterwards on the vector side.
     OT(1);
-    const int ord0 = (int)(uint32_t)skey[lane], ord1 = (int)(uint32_t)skey[64 + lane], ord2 = (lane < 46) ? (int)(uint32_t)skey[128 + lane] : 0;
+    const int ord0 = (int)(uint32_t)kq[0], ord1 = (int)(uint32_t)kq[1], ord2 = (lane < 46) ? (int)(uint32_t)kq[2] : 0;
     const bool has2 = lane < 46;
     uint32_t x00 = d_G0T[ord0][0], x01 = d_G0T[ord0][1], x02 = d_G0T[ord0][2];
     uint32_t x10 = d_G0T[ord1][0], x11 = d_G0T[ord1][1], x12 = d_G0T[ord1][2];
