@@ -1268,6 +1268,21 @@ int ft8rx_debug_fine_times(ft8rx_handle* h, unsigned long long* out32, int reset
 }
 #endif
 
+#ifdef BP_TIMING
+int ft8rx_debug_bp_times(ft8rx_handle* h, unsigned long long* out8, int reset) {         // timing-only builds (tools/bp_timing.py)
+    if (!h) return -1;
+    ENTER(h);
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    std::vector<unsigned long long> all((size_t)65536 * 8);
+    if (out8) {
+        if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_bp_t), sizeof(unsigned long long) * all.size()) != hipSuccess) return -2;
+        for (int i = 0; i < 8; i++) out8[i] = 0;
+        for (size_t b = 0; b < 65536; b++) for (int i = 0; i < 8; i++) out8[i] += all[b * 8 + i];
+    }
+    if (reset) { std::fill(all.begin(), all.end(), 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_bp_t), all.data(), sizeof(unsigned long long) * all.size()) != hipSuccess) return -2; }
+    return 0;
+}
+#endif
 #ifdef OSD_TIMING
 int ft8rx_debug_osd_times(ft8rx_handle* h, unsigned long long* out16, int reset) {       // timing-only builds (tools/osd_timing.py)
     if (!h) return -1;

@@ -18,6 +18,16 @@
 #ifndef BP_WV
 #define BP_WV 7          /* <= 72 VGPRs: 7 waves per SIMD; measured 1.76 -> 1.68 ms for both BP launches (profiles/r02_notes.md) */
 #endif
+// Timing-only builds (-DBP_TIMING, tools/bp_timing.py): lane 0 of every attempt adds the shader cycles between consecutive marks to a
+// per-block slot of g_bp_t[] (spread over 65536 slots: the atomics do not meet).  Never defined in the product.
+#ifdef BP_TIMING
+__device__ unsigned long long g_bp_t[65536][8];
+#define BT_DECL unsigned long long bt_prev = __builtin_readcyclecounter();
+#define BT(i) do { const unsigned long long bt_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_bp_t[blockIdx.x & 65535][i], bt_now - bt_prev); bt_prev = __builtin_readcyclecounter(); } while (0)
+#else
+#define BT_DECL
+#define BT(i) do { } while (0)
+#endif
 FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ llr_in, ft8rx_record* __restrict__ rec,
                         const int32_t* __restrict__ ncand, Att* __restrict__ attG, Att* __restrict__ attB,
                         float* __restrict__ saved, ft8rx_event* ev, int32_t* evcount, const ft8rx_config& cfg,
@@ -30,6 +40,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
     float* dl = tl;
     __shared__ float P[84];
     int frame = 0, ci = 0, ap = 0; size_t vec;
+    BT_DECL
     if (mode == 2) vec = bid;
     else {
         ap = bid % 5; int c = bid / 5; frame = c / MAXC; ci = c % MAXC;
@@ -78,6 +89,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
 #pragma unroll
     for (int i = 0; i < 9; i++) mc[i] = 0.0f;
     res.has_out = 1;
+    BT(0);
     for (int it = 0; it < max_iters; it++) {
         // parity of every check from the hard decisions
         const uint64_t h0 = __ballot(llr[lane] > 0.0f), h1 = __ballot(llr[64 + lane] > 0.0f),
@@ -98,6 +110,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
             if (r == 2) { res.ok = 1; res.lo = lo; res.hi = hi; res.n_its = (int16_t)it; res.has_out = 0; }
             break;      // success, or frozen state: the reference changes nothing from here on (decoders.py:161-164)
         }
+        BT(1);
         if (!tables) {                 // wave-uniform: first real iteration
             tables = true;
 #pragma unroll
@@ -117,6 +130,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
             const float v2c = llr[ev_[i]] - mc[i];
             tl[e] = ft8_tanhf(-v2c);
         }
+        BT(2);
         __syncthreads();
         {
             float Pp = tl[e00];
@@ -132,6 +146,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
                 P[c1] = Q;
             }
         }
+        BT(3);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -142,6 +157,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
             dl[e] = nm - mc[i];
             mc[i] = nm;
         }
+        BT(4);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 3; q++) {
@@ -153,7 +169,9 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
             }
         }
         __syncthreads();
+        BT(5);
     }
+    BT(6);
     if (res.ok) res.method = (mode == 0) ? FT8RX_M_LDPC_A : FT8RX_M_LDPC_B;
     if (mode == 2) {
         if (lane == 0) attB[vec] = res;

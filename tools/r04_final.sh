@@ -12,6 +12,8 @@ d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 print("5 min:", round(d["value"]), d["extra_steps"], round(d["extra_steps_frames_per_s"]))
 PY
 timeout 600 python3 -c "from pyft8_amd import _lib; _lib.build_variant('build/ab/fine_timing.so', ['-DFINE_TIMING'])" > /dev/null 2>&1 && FT8RX_LIB=build/ab/fine_timing.so timeout 300 python3 tools/fine_timing.py > "$OUT/r04_fine_timing.txt" 2>&1
+timeout 600 python3 -c "from pyft8_amd import _lib; _lib.build_variant('build/ab/osd_timing.so', ['-DOSD_TIMING'])" > /dev/null 2>&1 && FT8RX_LIB=build/ab/osd_timing.so timeout 300 python3 tools/osd_timing.py > "$OUT/r04_osd_timing.txt" 2>&1
+timeout 600 python3 -c "from pyft8_amd import _lib; _lib.build_variant('build/ab/bp_timing.so', ['-DBP_TIMING'])" > /dev/null 2>&1 && FT8RX_LIB=build/ab/bp_timing.so timeout 300 python3 tools/bp_timing.py > "$OUT/r04_bp_timing.txt" 2>&1
 timeout 900 bash tools/ab_streams.sh > "$OUT/r04_streams_ab.txt" 2>&1
 timeout 900 python3 bench.py > "$OUT/r04_bench_b256_default_final.json" 2> /dev/null
 python3 - "$OUT/r04_bench_b256_default_final.json" <<'PY'
