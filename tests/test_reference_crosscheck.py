@@ -30,6 +30,11 @@ if os.environ.get("PYFT8_REF_CROSSCHECK_WIDE"):          # the wide layouts (sea
     RECIPES = [dict(r, freq_range=(150.0, 5650.0)) for r in RECIPES]
     BASE = 7300000
 
+if os.environ.get("PYFT8_REF_CROSSCHECK_TIME"):          # wide time windows: candidates whose first / last symbols the reference reads clamped (receiver.py:189-195)
+    KWARGS = [dict(search_time_range=[-6.0, 3.0], sync_score_min=70), dict(search_time_range=[-1.0, 8.2], sync_score_min=70),
+              dict(search_time_range=[-5.0, 1.0]), dict(search_time_range=[2.0, 8.0], sync_score_min=60, max_cands=256)]
+    BASE = 7600000
+
 
 @pytest.mark.parametrize("k", range(N))
 def test_oracle_equals_reference_on_fresh_frame(k):
@@ -44,7 +49,7 @@ def test_oracle_equals_reference_on_fresh_frame(k):
     ocfg = O.default_config(sync_score_min=cfg.sync_score_min, max_cands=cfg.max_cands, f0_lo=cfg.f0_lo, f0_hi=cfg.f0_hi,
                             h0_lo=cfg.h0_lo, h0_hi=cfg.h0_hi)
     r = O.decode_frame(audio, ocfg)
-    # candidate list: same (f0, h0) set, same order -- except that two candidates whose sync scores agree to < 1e-6 relative may
+    # candidate list: same (f0, h0) set, same order -- except that two candidates whose sync scores agree to < 2e-6 relative may
     # swap places (the reference's score is a BLAS float32 sdot whose summation order is not reproducible; the contract sums in
     # fp64)
     ok, rk = [(c.f0_idx, c.h0_idx) for c in r["cands"]], [(f["f0_idx"], f["h0_idx"]) for f in tr.final]
@@ -57,7 +62,7 @@ def test_oracle_equals_reference_on_fresh_frame(k):
         if a != b:
             swapped = True
             print(f"frame {k}: candidates {a} / {b} swapped (scores {rsc[a]!r} / {rsc[b]!r})")
-            assert abs(rsc[a] - rsc[b]) <= 1e-6 * abs(rsc[a])
+            assert abs(rsc[a] - rsc[b]) <= 2e-6 * abs(rsc[a])        # (1.2e-6 seen once in 48 wide-time-window frames at sync_score_min = 70; an sdot of ~100 float32 terms is good to a few 1e-6)
     # Per-candidate outcomes.  Candidates whose outcome differs are classified; everything else must agree exactly.
     o_out = {kk: ((c.ipass, " ".join(O.HashTable().unpack(O.msg_int(c.msg_lo, c.msg_hi)) or ())) if c.status == 1 else None)
              for kk, c in zip(ok, r["cands"])}
