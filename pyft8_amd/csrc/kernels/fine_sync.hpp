@@ -539,6 +539,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         fscore_phases(L, T, tb);
         if (lane < 50) fscore_p1<8>(S, 182 + ft, L, Hc, tid FT_PASS);
         __syncthreads();
+        FT(21);
         if (tid < 80) {                                                           // (tone t, r2 = c10): over r1
             cpx x[10], y[10];
 #pragma unroll
@@ -549,6 +550,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
             for (int s1 = 1; s1 < 10; s1++) Ab[t * 100 + 10 * s1 + c10] = cmul(y[s1], tw[s1 - 1]);
         }
         __syncthreads();
+        FT(22);
         if (tid < 80) {                                                           // (tone t, s1 = c10): over r2
             cpx x[10], y[10];
 #pragma unroll
@@ -584,6 +586,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         else { for (int sy = s_up + c; sy < 79; sy += 16) mg[sy * 8 + t] = m; }
     }
     __syncthreads();
+    FT(23);
     // --- Costas gate (receiver.py:164-167)
     bool match = false;
     if (tid < 21) {
@@ -595,6 +598,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     if (tid < 64) { int nm = __popcll(__ballot(match)); if (tid == 0) ish[1] = nm; }
     __syncthreads();
     const int nsync = ish[1];
+    FT(24);
     if (trip && t_sgrid) for (int i = tid; i < 632; i += FINE_NT) t_sgrid[(size_t)bid * 632 + i] = mg[i];
     int ret = 1; float sd = 0.0f; int snr = 0;
     if (nsync <= 6) ret = 0;           // block-uniform
