@@ -478,6 +478,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
             dsum[(ti * 7 + a) * 2] = on; dsum[(ti * 7 + a) * 2 + 1] = off;
         }
     }
+    FT(25);
     __syncthreads();
     int tt = -8; float score_f0 = 0.0f;
     {   // lane ti (mod 8) of every wave sums the block at time tweak ti; the first maximum (np.argmax) is then picked from the 8 lanes
@@ -492,6 +493,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
             if (u == 0 || v > score_f0) { score_f0 = v; tt = -8 + 2 * u; }
         }
     }
+    FT(26);
     // --- frequency tweaks: range(-32,33,8)
     float best = 0.0f; int ft = 0;
     fscore_prepare(L, z, T, tb0 + tt + 32 * 36, tid);         // the time scan is done with the series: the image takes the tables of the frequency scan

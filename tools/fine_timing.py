@@ -15,10 +15,10 @@ NAMES = ["(outside fft: scoring tail of the previous step, loop)", "stage 1: sli
          "barrier", "stage 2: [4,4] butterflies + LDS stores", "barrier", "stage 3: LDS loads", "barrier", "stage 3: [5,5] (pruned) + LDS stores",
          "barrier", "  step 1: H stores", "  barrier after step 1",
          "LLRs of the candidates that pass the gate (41 %), records", "  step 2: DPP row sums, magnitudes", "  (loop)",
-         "  step 1: slice + phase loads, taper, 10 complex multiplies", "  step 1: the 70 complex-by-real multiply-adds (K in registers)", "time-scan scores + table set-up of the frequency scan",
+         "  step 1: slice + phase loads, taper, 10 complex multiplies", "  step 1: the 70 complex-by-real multiply-adds (K in registers)", "phases of the frequency scan (table loads after the time tweak is known), (cos, sin) table, barrier",
          "  step 2: the multiply-adds (H, cos / sin loads)", "scores of the eight tweaks (after the scan), first maximum",
          "final grid: phases + H for eight tones (incl. its barrier)", "final grid: first round of 10-point transforms + twiddles, barrier", "final grid: second round, magnitudes; clamped rows (30 % of the candidates); barrier",
-         "Costas gate"]
+         "Costas gate", "time scan: requests of the scan's constants, 56 symbol DFTs on lane quads, (on, off) sums", "time scan: barrier, block scores, first maximum"]
 
 
 def main():
@@ -35,7 +35,7 @@ def main():
     h.enqueue(ptr, B); h.sync()
     L.ft8rx_debug_fine_times(h._h, out.ctypes.data, 0)
     rec, cnt, ev, evc = h.fetch(B)
-    tot = float(out[:25].sum())
+    tot = float(out[:27].sum())
     print(f"k_fine, {B} frames: cycles of wave 0 summed over all blocks (share of the total)")
     for i, n in enumerate(NAMES):
         print(f"  {i:2d} {n:<58s} {int(out[i]):>16,d}  {100 * out[i] / tot:5.1f} %")
