@@ -230,15 +230,15 @@ def place_rank(local_rank, world, bus_id_of):
 
 
 OTHER_CONFIGS = {      # BASELINE.json configs 2-4 per GPU, as `--config N` runs them; steps chosen so that the un-overlapped last fetch weighs < 2 %
-    2: dict(frames=4096, signals=50, snr=(-10.0, 10.0), knobs=dict(bp_iters_b=30, osd_single=30, osd_double=2), steps=6,
+    2: dict(frames=4096, signals=50, snr=(-10.0, 10.0), knobs=dict(bp_iters_b=30, osd_single=30, osd_double=2), steps=14,
             what="4096 frames, LDPC BP 30 iterations + OSD depth 2"),
-    3: dict(frames=8192, signals=50, snr=(-10.0, 10.0), knobs={}, steps=5, what="one rank's 8192-frame shard of the 65 536-frame job, Receiver defaults"),
+    3: dict(frames=8192, signals=50, snr=(-10.0, 10.0), knobs={}, steps=10, what="one rank's 8192-frame shard of the 65 536-frame job, Receiver defaults"),
     4: dict(frames=2048, signals=10, snr=(-24.0, -20.0), knobs=dict(osd_triple=30, osd_max_hd=32), steps=24,
             what="2048 frames per GPU, 10 signals at -24..-20 dB, OSD order 3 over 30 positions with the distance gate at 32"),
 }
 
 
-def run_other_config(n, device, rank, pk_threads, streams):
+def run_other_config(n, device, rank, pk_threads, streams, subbatch=None):
     """A short run of BASELINE config n on this GPU, measured like the headline: pipelined steps to rendered messages, then per-stage
     HIP-event times of whole-batch launches.  -> the dict nested under other_configs[n]."""
     import torch
@@ -250,6 +250,8 @@ def run_other_config(n, device, rank, pk_threads, streams):
     h = _lib.Handle(cfg=cfg, device=device, max_frames=B)
     try:
         h.set_streams(streams)
+        if subbatch is not None:
+            h.set_subbatch(subbatch)
         d_audio = torch.empty((B, _lib.NSAMP), dtype=torch.int16, device="cuda")
         h.synth_frames(d_audio.data_ptr(), rank * 1000000, B, n_signals=c["signals"], snr_range=c["snr"])
         setup_s = time.perf_counter() - t_setup
@@ -324,6 +326,8 @@ def main():
     ap.add_argument("--bp-iters", type=int, default=None, help="extension knob: iterations of the second BP stage (reference 20; config 2: 30)")
     ap.add_argument("--osd", type=int, nargs=2, default=None, metavar=("SINGLE", "DOUBLE"), help="extension knob: osd_012 flip counts (reference 30 2)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams a batch is cut across (1 = one chain of whole-batch launches)")
+    ap.add_argument("--subbatch", type=int, default=None, help="frames per kernel chain inside a stream's share of a batch (ft8rx_set_subbatch; "
+                    "default: the library's 128; 0 = the whole share in one chain, the round-4 behaviour)")
     ap.add_argument("--config", type=int, default=None, choices=(1, 2, 3, 4), help="BASELINE.json configuration preset (per GPU): 1 = 256 frames; "
                     "2 = 4096 frames, BP 30 iterations, OSD depth 2; 3 = 8192 frames per GPU (65 536 over 8 GPUs) + record gather; "
                     "4 = 2048 frames per GPU (16 384 over 8), <= 10 signals at -24..-20 dB, OSD order 3 over 30 positions with the distance gate at 32")
@@ -420,6 +424,8 @@ def main():
     reference_knobs = (cfg.bp_iters_b, cfg.osd_single, cfg.osd_double, cfg.osd_triple, cfg.osd_max_hd) == (20, 30, 2, 0, 0)
     h = _lib.Handle(cfg=cfg, device=local, max_frames=B)
     h.set_streams(args.streams)
+    if args.subbatch is not None:
+        h.set_subbatch(args.subbatch)
     if args.host_synth:
         uniq = min(args.unique, B)
         frames = make_frames(frame0, uniq, args.signals, tuple(args.snr))
@@ -662,7 +668,7 @@ def main():
         torch.cuda.empty_cache()
         for n in (2, 3, 4):
             try:
-                other[str(n)] = run_other_config(n, local, rank, pk_threads, args.streams)
+                other[str(n)] = run_other_config(n, local, rank, pk_threads, args.streams, args.subbatch)
             except Exception as e:                    # informational: never lose the line over it
                 other[str(n)] = {"error": f"{type(e).__name__}: {e}"}
 

@@ -202,6 +202,11 @@ int  ft8rx_package_packed(const void* packed, uint64_t bytes, int frame_lo, int 
 /* per-kernel HIP-event timing of the most recent enqueue (enable before enqueue). names/ms: up to 16 */
 /* number of HIP streams a batch is cut across (1..8, default 2: measured best, profiles/r02_notes.md); profiling mode always uses one */
 int  ft8rx_set_streams(ft8rx_handle* h, int n);
+/* frames per kernel chain inside a stream's share of a batch (default FT8RX_SUBBATCH_DEFAULT; 0 = the whole share in one chain): a
+ * large batch runs as a sequence of cache-sized sub-batches, each through the whole path before the next starts, so that a stage
+ * reads what the stage before it wrote from L2 / MALL instead of HBM.  Records, events and messages do not depend on it. */
+#define FT8RX_SUBBATCH_DEFAULT 128
+int  ft8rx_set_subbatch(ft8rx_handle* h, int frames);
 /* how the fine-stage BP attempts of a batch are launched; records and messages are identical either way:
  * 0 (default) = in the reference's ladder order (receiver.py:84-98) as three launches, candidates that are decided dropping out in
  *     between -- least work, highest throughput;

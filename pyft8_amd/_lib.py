@@ -365,6 +365,10 @@ class Handle:
     def set_streams(self, n):
         self._chk(self._L.ft8rx_set_streams(self._h, int(n)), "ft8rx_set_streams")
 
+    def set_subbatch(self, frames):
+        """Frames per kernel chain inside a stream's share of a batch (ft8rx_set_subbatch; default 128, 0 = the whole share at once)."""
+        self._chk(self._L.ft8rx_set_subbatch(self._h, int(frames)), "ft8rx_set_subbatch")
+
     def set_ladder_mode(self, mode):
         """0 (default) = fine-stage BP in ladder order, three launches (throughput); 1 = one launch for the five AP variants (latency)."""
         self._chk(self._L.ft8rx_set_ladder_mode(self._h, int(mode)), "ft8rx_set_ladder_mode")

@@ -79,6 +79,7 @@ struct ft8rx_handle {
     hipStream_t stream;
     int n_streams;                       // chunks of a batch run their kernel chains on separate streams
     int ladder_mode;                     // fine-stage BP launches: 0 = ladder order (three launches), 1 = one launch (ft8rx_set_ladder_mode)
+    int sub_frames;                      // frames per kernel chain inside a chunk (ft8rx_set_subbatch; 0 = the whole chunk in one chain)
     hipStream_t sub[8];
     hipEvent_t ev_fork, ev_join[8];
     hipStream_t copy_s;              // host-to-device chunk copies of ft8rx_decode_batch, in order, never queued behind kernels
@@ -283,7 +284,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     if (device < 0 || device >= ndev) { set_err(nullptr, "ft8rx_create: device %d out of range (%d devices)", device, ndev); return -1; }
     ft8rx_handle* h = new ft8rx_handle();
     h->cfg = *cfg; h->device = device; h->max_frames = max_frames; h->stream = nullptr; h->profiling = false; h->n_stage = 0;
-    h->n_streams = 2; h->ladder_mode = 0; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
+    h->n_streams = 2; h->ladder_mode = 0; h->sub_frames = FT8RX_SUBBATCH_DEFAULT; h->ev_fork = nullptr; for (int i = 0; i < 8; i++) { h->sub[i] = nullptr; h->ev_join[i] = nullptr; }
     h->copy_s = nullptr; h->slot_evpending[0] = h->slot_evpending[1] = false; h->h2d_s = nullptr; h->d_audio = nullptr; h->d_audio2 = nullptr; for (int i = 0; i < 16; i++) h->ev_chunk[i] = nullptr;
     for (int k = 0; k < 2; k++) { h->ev_comp[k] = h->ev_done[k] = nullptr; h->h_rec[k] = nullptr; h->h_cnt[k] = nullptr; h->h_ev[k] = nullptr; h->h_evc[k] = nullptr; h->h_evpacked[k] = nullptr; h->d_evpacked[k] = nullptr; h->d_evoffs[k] = nullptr; h->slot_B[k] = 0; }
     h->slot_enq = h->slot_fetch = h->inflight = 0; h->last_slot = -1;
@@ -518,6 +519,17 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
 #undef STAGE
 }
 
+// A chunk's frames go through the WHOLE chain in cache-sized sub-batches, one after the other on the chunk's stream: a sub-batch's dB
+// grid (1.47 MB per frame) is then still in L2 / the 256 MB MALL when k_sync, k_topk and k_grid_llr read it, and the four-step scratch
+// and cycle spectrum that later overlay it are too when k_cyc_bc / k_fine read them -- a 4096-frame chunk's grid is 6 GB and every
+// stage of it came from HBM (k_spectrogram 0.36 -> 0.42 ms per 256 frames, profiles/r04_batch_sweep.txt).  Every workspace is indexed
+// by frame and the chunk's work-list counters are re-zeroed by each chain's k_topk, so consecutive sub-batches on one stream need
+// nothing but stream order.  Results do not depend on the partition (tests/test_gpu_parity.py: test_subbatch_partition_invariance).
+static void enqueue_chunk(ft8rx_handle* h, const int16_t* d_audio, int f0, int n, hipStream_t s, int slot, int chunk) {
+    const int sub = (h->sub_frames > 0 && h->sub_frames < n) ? h->sub_frames : n;
+    for (int o = 0; o < n; o += sub) enqueue_chain(h, d_audio, f0 + o, (o + sub <= n) ? sub : n - o, s, false, slot, chunk);
+}
+
 // Launch one batch: audio either resident on the device (host_audio == nullptr) or copied from the host in chunks.
 //   profiling mode / small batches: one chain on the main stream (per-stage events bracket whole-batch launches);
 //   otherwise the batch is cut into chunks whose chains overlap on the sub-streams -- the ladder kernels (BP, OSD, fine sync)
@@ -587,7 +599,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
             hipStream_t s = chunk_stream(k);
             HIPCHK(h, hipStreamWaitEvent(s, h->ev_done[slot], 0));          // the slot's previous results have left the device
             if (pipelined) HIPCHK(h, hipStreamWaitEvent(s, h->ev_chunk[0], 0));
-            if (n > 0) enqueue_chain(h, d_audio, f0, n, s, false, slot, k);
+            if (n > 0) enqueue_chunk(h, d_audio, f0, n, s, slot, k);
             HIPCHK(h, hipEventRecord(h->ev_cdone[slot][k], s));
             HIPCHK(h, hipStreamWaitEvent(h->copy_s, h->ev_cdone[slot][k], 0));
         }
@@ -597,7 +609,8 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));          // the slot's previous results have left the device
     if (nc <= 1) {
         if (host_audio) HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));
-        enqueue_chain(h, d_audio, 0, B, h->stream, h->profiling, slot, 0);
+        if (h->profiling) enqueue_chain(h, d_audio, 0, B, h->stream, true, slot, 0);      // per-stage events bracket whole-batch launches
+        else enqueue_chunk(h, d_audio, 0, B, h->stream, slot, 0);
     } else {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         if (host_audio && !pipelined) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_fork, 0));
@@ -633,7 +646,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
                 HIPCHK(h, hipEventRecord(h->ev_chunk[k], cs));
                 HIPCHK(h, hipStreamWaitEvent(s, h->ev_chunk[k], 0));
             }
-            enqueue_chain(h, d_audio, f0, n, s, false, slot, k);
+            enqueue_chunk(h, d_audio, f0, n, s, slot, k);
         }
         for (int i = 1; i < ns; i++) {
             HIPCHK(h, hipEventRecord(h->ev_join[i - 1], h->sub[i - 1]));
@@ -706,6 +719,7 @@ int ft8rx_enqueue_batch_host(ft8rx_handle* h, const int16_t* audio, int B) {
 }
 
 int ft8rx_set_streams(ft8rx_handle* h, int n) { if (!h || n < 1 || n > 8) return -1; h->n_streams = n; return 0; }
+int ft8rx_set_subbatch(ft8rx_handle* h, int frames) { if (!h || frames < 0) return -1; h->sub_frames = frames; return 0; }
 int ft8rx_set_ladder_mode(ft8rx_handle* h, int mode) { if (!h || mode < 0 || mode > 1) return -1; h->ladder_mode = mode; return 0; }
 
 int ft8rx_set_search_mask(ft8rx_handle* h, const uint8_t* mask, int n_frames) {

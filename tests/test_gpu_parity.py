@@ -1279,6 +1279,38 @@ def test_repeatable_across_runs_and_stream_counts(ocfg):
             assert rec[f][:cnt[f]].tobytes() == outs[0][0][f][:cnt[f]].tobytes()
 
 
+def test_subbatch_partition_invariance():
+    """ft8rx_set_subbatch: a stream's share of a batch runs as consecutive sub-batches through the whole chain (cache residency for
+    large batches).  Records and the (sorted) event log do not depend on the partition -- whole share, uneven tail, one frame per chain."""
+    import hashlib
+    from pyft8_amd import _lib
+    B = 80
+    h = _lib.Handle(max_frames=B)
+    ptr = h.staging_ptr()
+    h.synth_frames(ptr, 5200000, B, n_signals=40, snr_range=(-12.0, 8.0))
+
+    def digest(res):
+        rec, cnt, ev, evc = res
+        hsh = hashlib.sha256()
+        for f in range(B):
+            hsh.update(rec[f, :cnt[f]].tobytes())
+            hsh.update(np.sort(ev[f, :min(int(evc[f]), _lib.EVENT_CAP)], order=["cand", "ipass", "slot", "seq"]).tobytes())
+        return hsh.hexdigest(), int(cnt.sum())
+    outs = []
+    for ns, sub in ((1, 0), (2, 0), (2, 24), (2, 128), (4, 7), (1, 1), (2, 16)):
+        h.set_streams(ns)
+        h.set_subbatch(sub)
+        h.enqueue(ptr, B)
+        h.enqueue(ptr, B)                                                 # free-running: two batches back to back
+        h.fetch(B)
+        outs.append(digest(h.fetch(B)))
+    assert outs[0][1] > 100 * B // 2
+    assert all(o == outs[0] for o in outs), outs
+    with pytest.raises(_lib.Ft8rxError):
+        h.set_subbatch(-1)
+    h.close()
+
+
 def test_decode_messages_single_call(H):
     """ft8rx_decode_messages (audio -> messages in one native call) == ft8rx_decode_batch + ft8rx_package_batch."""
     from pyft8_amd import _lib
