@@ -313,6 +313,10 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the per-step gather of the packed results to rank 0 out (A/B of its cost)")
     ap.add_argument("--gather-repeat", type=int, default=1, help="measurement aid: gather every batch this many times (rank 0's receive + D2H load "
                     "of that many ranks in a one-rank group)")
+    ap.add_argument("--gather-depth", type=int, default=4, help="receive sets rank 0 keeps per peer (PackedGather depth): how many batches a rank may run "
+                    "ahead of the slowest one before its sends wait")
+    ap.add_argument("--delay-rank", type=int, default=None, help="test aid: this rank sleeps --delay-ms on the host in every step (a straggler)")
+    ap.add_argument("--delay-ms", type=float, default=20.0)
     ap.add_argument("--render-gathered", action="store_true", help="rank 0 also renders the messages of ALL gathered frames inside the timed steps "
                     "(by default every rank renders its own shard and rank 0 keeps the packed form of the others)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1 default command: skip the short runs of BASELINE configs 2-4")
@@ -467,7 +471,7 @@ def main():
         # in the line, instead of dying inside the timed loop
         err = None
         try:
-            gather = PackedGather(h, max(shard_counts), dst=0, force=args.force_gather, repeat=args.gather_repeat)
+            gather = PackedGather(h, max(shard_counts), dst=0, force=args.force_gather, repeat=args.gather_repeat, depth=args.gather_depth)
             h.enqueue(d_audio.data_ptr(), B)
             h.fetch_view(B)
             gather.submit()
@@ -488,6 +492,8 @@ def main():
     rendered = [0]
 
     def host_side(view):
+        if args.delay_rank is not None and rank == args.delay_rank:
+            time.sleep(args.delay_ms * 1e-3)
         if gather is not None:
             gather.submit()
             if args.render_gathered and rank == 0:
@@ -513,6 +519,7 @@ def main():
     t0 = time.perf_counter()
     msgs_, mc_ = run_steps(args.steps)
     h.sync()
+    dt_own = time.perf_counter() - t0          # this rank's own K steps (its gathers drained), before it meets the others
     barrier()
     dt = time.perf_counter() - t0
     # keep the GPU busy for --min-seconds in total (identical steps, not part of `value`): a 0.16-s timed region is invisible to
@@ -533,7 +540,7 @@ def main():
     kernel_only = B * args.steps / (time.perf_counter() - t1)
     cdev = "cuda" if args.backend == "nccl" else "cpu"
     t = torch.tensor([dt], device=cdev, dtype=torch.float64)
-    own = torch.tensor([dt, kernel_only], device=cdev, dtype=torch.float64)       # this rank's own clock, for the per-rank table
+    own = torch.tensor([dt_own, kernel_only], device=cdev, dtype=torch.float64)   # this rank's own clock (before the closing barrier), for the per-rank table
     per_rank_raw = [own]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -627,8 +634,13 @@ def main():
             sub = np.array(gather.seconds[args.warmup + 1:] or gather.seconds)
             gather_info = {"submit_ms_per_step": round(1e3 * float(sub.mean()), 4), "submit_ms_max": round(1e3 * float(sub.max()), 4),
                            "unoverlapped_ms": round(sync_ms, 3), "repeat": args.gather_repeat, "rendered_on_rank0": bool(args.render_gathered),
+                           "depth": gather.depth,
                            "submit_phases_ms": {k: round(1e3 * float(np.mean([p.get(k, 0.0) for p in gather.phases[args.warmup + 1:] or gather.phases])), 4)
                                                 for k in ("header", "wait_slot", "sizes", "issue")}}
+            if world > 1:                             # every rank's own host time in submit(), by phase: no rank waits for another's batch
+                allph = [None] * world
+                dist.all_gather_object(allph, gather_info["submit_phases_ms"])
+                gather_info["submit_phases_ms_by_rank"] = allph
             if rank == 0:
                 assert len(parts) == world * args.gather_repeat, f"{len(parts)} parts from {world} ranks"
                 total = sum(p.n_frames for p in parts[:world])

@@ -224,6 +224,7 @@ class Handle:
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.ft8rx_destroy(self._h)
             self._h = C.c_void_p()
+            self._packed_keep = None
 
     def __del__(self):
         try:
@@ -324,20 +325,27 @@ class Handle:
         self._chk(L.ft8rx_results_to_device(self._h, int(B), C.c_void_p(d_rec), C.c_void_p(d_cnt), C.c_void_p(d_ev), C.c_void_p(d_evc)),
                   "ft8rx_results_to_device")
 
-    def set_packed_output(self, buf0, buf1, cap_bytes):
+    def set_packed_output(self, buf0, buf1, cap_bytes, keep=None):
         """ft8rx_set_packed_output: raw pointers (device memory, or page-locked host memory from pinned_bytes()) of the two buffers the
-        following batches write their packed results into (one per result slot); None, None turns it off."""
+        following batches write their packed results into (one per result slot); None, None turns it off.
+        keep: the objects that own the two buffers (torch tensors, page-locked arrays).  The handle holds on to them -- and to the events
+        given to packed_fence -- until the packed output is reset or the handle is closed, so the pack kernels can never write into
+        memory whose Python owner has already been collected."""
         L = self._L
         L.ft8rx_set_packed_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         self._chk(L.ft8rx_set_packed_output(self._h, C.c_void_p(buf0 or None), C.c_void_p(buf1 or None), C.c_uint64(int(cap_bytes))),
                   "ft8rx_set_packed_output")
+        # (the call above has waited for every batch in flight: the previous owners may go now)
+        self._packed_keep = {"buffers": keep, "fence": [None, None]} if (buf0 or buf1) else None
 
-    def packed_fence(self, which, hip_event):
+    def packed_fence(self, which, hip_event, keep=None):
         """ft8rx_packed_output_fence: the next batch that packs into buffer `which` waits (on the device) for this HIP event, e.g.
-        torch.cuda.Event(...).cuda_event recorded behind an asynchronous send of the buffer."""
+        torch.cuda.Event(...).cuda_event recorded behind an asynchronous send of the buffer.  keep: the object that owns the event."""
         L = self._L
         L.ft8rx_packed_output_fence.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         self._chk(L.ft8rx_packed_output_fence(self._h, int(which), C.c_void_p(hip_event or None)), "ft8rx_packed_output_fence")
+        if getattr(self, "_packed_keep", None) is not None:
+            self._packed_keep["fence"][int(which)] = keep
 
     def packed_results(self):
         """ft8rx_packed_results: (which of the two packed buffers, its header as a dict) for the batch the last fetch returned."""

@@ -22,6 +22,8 @@ ranks in rank order = global frame order for shard()):
   gather_results_device(handle, n_frames) nccl only: the latest batch's results go device -> device into torch buffers
                                           (ft8rx_results_to_device), RCCL gathers them over xGMI, and rank `dst` makes the single
                                           D2H copy -- no host round trip on the sending ranks."""
+import weakref
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -130,8 +132,17 @@ def gather_results_device(handle, n_frames, dst=0, group=None, force=False):
     return tuple(res)
 
 
+def _store():
+    """The process group's rendezvous store (a TCPStore served by a background thread of global rank 0): PackedGather's mailbox for its
+    32-byte control messages.  A set() is one small TCP message to that server thread -- no rank's Python thread is involved in taking
+    it -- and check() polls without blocking, which torch.distributed's own point-to-point receives cannot do on gloo (a gloo Work
+    only learns that it is complete inside wait())."""
+    from torch.distributed import distributed_c10d as c10d
+    return c10d._get_default_store()
+
+
 class PackedGather:
-    """Gather of every batch's PACKED results to rank `dst`, overlapped with the next batch (module docstring).
+    """Gather of every batch's PACKED results to rank `dst`, overlapped with the following batches (module docstring).
 
         g = PackedGather(handle, B)                  # all ranks; sets the handle's packed output
         handle.enqueue(...); view = handle.fetch_view(B)
@@ -139,90 +150,233 @@ class PackedGather:
         ...                                          # (next enqueue / host message layer of this rank's own frames)
         parts = g.collect()                          # rank dst: [Packed of rank 0, rank 1, ...] of the oldest submitted batch; else None
 
-    At most two gathers are in flight (the handle has two result slots); submit() first completes the one that used the same slot.
+    No collective and no cross-rank rendezvous (round 5): a rank other than dst starts the point-to-point send of its buffer (RCCL
+    send on a side stream / gloo isend) and then drops one control message (batch number, byte count, overflow flag) into the process
+    group's store -- it never waits for another rank's batch, only (two batches later, before the same buffer is packed again) for its
+    OWN send to have been taken.  Rank dst looks into the mailbox whenever it is in submit() / collect() / drain() and posts the data
+    receive of every part that has been announced: parts land in arrival order, peer by peer, into a ring of `depth` receive sets
+    (set = batch number % depth, row = rank).  A peer may therefore run up to `depth` batches ahead of the slowest one before its
+    sends wait; rank dst itself waits only when it is `depth` batches ahead of the slowest peer, and in collect() / drain().
+    (Round 4 exchanged the byte counts with a blocking all_gather and used dist.gather: every step was a rendezvous of all ranks.)
+
     per_frame: bytes of records + events reserved per frame in each rank's two pack buffers (default None = the worst case, 48 max_cands
-    + 12 KB: a batch always fits; config-1 frames use ~6 KB, and a smaller figure makes an oversized batch raise instead of being
-    cut).  Rank dst's receive and page-locked buffers are sized from the byte counts actually seen (twice the first batch's, grown if
-    a later batch needs more), not from the capacity.  repeat > 1 (measurement aid) gathers every batch `repeat` times into distinct
-    buffers: rank dst's receive + D2H load of `repeat` ranks in a one-rank group."""
+    + 12 KB: a batch always fits; config-1 frames use ~6 KB, and a smaller figure makes an oversized batch raise -- on the rank it
+    happens on and, through the control message, on rank dst -- instead of being cut).  Rank dst's receive and page-locked buffers are
+    sized from the byte counts actually seen (twice the first batch's, grown if a later batch needs more), not from the capacity.
+    repeat > 1 (measurement aid) gathers every batch `repeat` times into distinct rows: rank dst's receive + D2H load of `repeat` times
+    as many ranks.  Every rank of `group` constructs the object, and all ranks construct their PackedGathers in the same order (the
+    n-th one of a process uses mailbox n)."""
 
     MIN_ROW = 1 << 20          # smallest receive row rank dst allocates (bytes); tests lower it to reach the growth path with small frames
+    TIMEOUT = 300.0           # seconds any wait may take before it raises instead of hanging (a peer died, a transport is stuck)
+    TAG_DATA = 12
+    _instances = 0             # PackedGathers constructed in this process: the mailbox prefix
 
-    def __init__(self, handle, n_frames, dst=0, group=None, force=False, per_frame=None, repeat=1):
+    def __init__(self, handle, n_frames, dst=0, group=None, force=False, per_frame=None, repeat=1, depth=4):
         from . import _lib
         self._lib, self.h, self.B, self.dst, self.group, self.repeat = _lib, handle, int(n_frames), dst, group, max(1, int(repeat))
+        self.depth = max(2, int(depth))
         self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.nccl = self.active and dist.get_backend(group) == "nccl"
         self.cap = (_lib.packed_capacity(self.B, handle.cfg.max_cands, per_frame) + 255) & ~255
-        self.pending = []                  # (slot, sizes, event-or-None, part stride) in submit order
-        self._fence = [None, None]         # keeps the event handed to ft8rx_packed_output_fence alive
-        self.ready, self._last = [], None  # completed gathers not collected yet (oldest first); the most recent result
-        self.seconds = []                  # host time spent inside submit() per call (the size exchange blocks; the rest is asynchronous)
-        self.phases = []                   # the same, split: header / wait_slot (the gather two batches ago) / sizes / issue
-        # the byte counts are exchanged on the host (a gloo group next to the RCCL one): a device-side exchange would make every
-        # submit() wait for the side stream, and a side stream shares one of the runtime's few hardware queues with a chunk stream
-        # of the decode -- measured: the 8-byte all_gather then waits for the whole batch in front of it (135 ms at config 3)
-        self.cpu_group = group
-        if self.nccl:
-            try:
-                self.cpu_group = dist.new_group(ranks=(dist.get_process_group_ranks(group) if group is not None else None), backend="gloo")
-            except Exception as e:                   # no gloo transport on this box: the counts go over RCCL (submit() then waits for the side stream)
-                import warnings
-                warnings.warn(f"PackedGather: no gloo group for the size exchange ({type(e).__name__}: {e}); using the device path", RuntimeWarning)
-                self.cpu_group = None
+        self.seq = 0                       # batches submitted by this rank
+        self.sends = []                    # completions of this rank's sends in flight, oldest first
+        self.batches = {}                  # rank dst: batch number -> {"parts": [...], "left": n, "err": str or None}
+        self.announced = {}                # rank dst: peer -> control messages received and not yet turned into data receives
+        self.ready, self._last = [], None  # rank dst: completed batches not collected yet (oldest first); the most recent result
+        self.collected = 0                 # batches handed out / dropped so far (all ranks count alike)
+        self.done_upto = 0                 # rank dst: batches [collected, done_upto) are complete and wait in `ready`
+        self.seconds = []                  # host time spent inside submit() per call
+        self.phases = []                   # the same, split: header / wait_slot (this rank's own send two batches ago) / sizes (control message; rank dst: polling) / issue
+        self.row = 0
+        self.row_history = []              # rank dst: every row size the receive sets have had (growth is visible to tests)
+        self.recv = self.host = None       # rank dst: allocated by _room() from the first byte counts seen
+        # control messages travel on the host, through the store: a device-side exchange would make the host wait for the side stream,
+        # which shares one of the runtime's few hardware queues with a chunk stream of the decode (135 ms per step at config 3, r04)
+        PackedGather._instances += 1
+        self.store = _store() if (self.active and self.world > 1) else None
+        self.prefix = f"ft8rx_pg{PackedGather._instances}"
         if self.nccl:
             dev = torch.device("cuda", torch.cuda.current_device())
             self.stream = torch.cuda.Stream(device=dev)
             self.src = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(2)]
             ptrs = [t.data_ptr() for t in self.src]
-            self.recv = self.host = None               # rank dst: allocated by _room() from the first batch's byte counts
-            self.row = 0
+            owners = list(self.src)
         else:
             # host path (gloo, or no process group at all): the pack kernels write page-locked host memory directly
             self.stream = None
             self._pin = [handle.pinned_bytes(self.cap) for _ in range(2)]
             self.src = [torch.from_numpy(a) for a in self._pin]
             ptrs = [a.ctypes.data for a in self._pin]
-            self.recv = self.host = None
-            self.row = 0
-        handle.set_packed_output(ptrs[0], ptrs[1], self.cap)
+            owners = list(self._pin)
+        self._set_output(ptrs[0], ptrs[1], self.cap, owners)
+        # if this object is dropped without close(), the packed output is switched off (which waits for the batches in flight) before
+        # the buffers go; the handle also holds references to them (Handle.set_packed_output keep=)
+        self._fin = weakref.finalize(self, PackedGather._shutoff, weakref.ref(handle))
+        self.next_ctrl = {}                # rank dst: peer -> batch number of the next control message expected from it
+        if self.active and self.rank == self.dst:
+            for r in range(self.world):
+                if r != self.dst:
+                    self.announced[r] = []
+                    self.next_ctrl[r] = 0
+
+    # ---- plumbing
+    def _set_output(self, p0, p1, cap, owners):
+        try:
+            self.h.set_packed_output(p0, p1, cap, keep=owners)
+        except TypeError:                  # a stand-in handle without the keep= argument (CPU tests)
+            self.h.set_packed_output(p0, p1, cap)
+
+    @staticmethod
+    def _shutoff(href):
+        h = href()
+        try:
+            if h is not None and getattr(h, "_h", None) is not None and (not hasattr(h._h, "value") or h._h.value):
+                h.set_packed_output(None, None, 0)
+        except Exception:
+            pass
+
+    def _g(self, r):
+        """global rank of group rank r"""
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _wait(self, cond, what):
+        """Poll until cond() -- progress is made by this thread only (_progress), so every wait goes through here."""
+        import time
+        t0 = time.perf_counter()
+        spins = 0
+        while True:
+            self._progress()
+            if cond():
+                return
+            spins += 1
+            if spins > 50:
+                time.sleep(50e-6)
+            if time.perf_counter() - t0 > self.TIMEOUT:
+                raise self._lib.Ft8rxError(f"PackedGather: timed out after {self.TIMEOUT:.0f} s waiting for {what} (rank {self.rank})")
+
+    @staticmethod
+    def _done(c):
+        """Has this transfer completed?  A CUDA event is polled.  A gloo work object cannot be (it learns of its completion only in
+        wait()), so it is waited for: that is only ever asked of a transfer whose other side is known to have been posted -- a receive
+        whose announcement has arrived, or this rank's own send when its buffer is needed again."""
+        if c is None:
+            return True
+        if hasattr(c, "query"):
+            return c.query()
+        c.wait()
+        return True
 
     def _room(self, m):
-        """Rank dst: receive (nccl) and host buffers with rows of at least m bytes for world x repeat parts, two sets (one per result
-        slot).  Sized to twice the first batch's largest part; a later batch that needs more first waits for the gathers in flight."""
+        """Rank dst: `depth` receive sets with rows of at least m bytes for world x repeat parts.  Sized to twice the first part seen; a
+        later part that needs more gets new, larger sets -- parts already received (or being received) keep their old memory alive."""
         if m <= self.row:
             return
-        while self.pending:
-            self._retire()
         self.row = min(self.cap, max(2 * m, self.MIN_ROW))
         self.row = (self.row + 255) & ~255
+        self.row_history.append(self.row)
         n = self.world * self.repeat
         if self.nccl:
             dev = self.src[0].device
-            self.recv = [torch.empty((n, self.row), dtype=torch.uint8, device=dev) for _ in range(2)]
-            self.host = [torch.empty((n, self.row), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self.recv = [torch.empty((n, self.row), dtype=torch.uint8, device=dev) for _ in range(self.depth)]
+            self.host = [torch.empty((n, self.row), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
         else:
-            self.host = [torch.empty((n, self.row), dtype=torch.uint8) for _ in range(2)]
+            self.host = [torch.empty((n, self.row), dtype=torch.uint8) for _ in range(self.depth)]
 
+    def _batch(self, k):
+        if k not in self.batches:
+            self.batches[k] = {"parts": [None] * (self.world * self.repeat), "left": self.world * self.repeat, "err": None, "open": []}
+        return self.batches[k]
+
+    def _set_free(self, k):
+        """May parts of batch k be received now?  (a) Its receive set last held batch k - depth, which must be complete -- an uncollected
+        one is dropped now, its memory is needed; (b) k <= own submits + depth - 3, so that what collect() handed out stays valid until
+        rank dst itself has submitted two more batches, however far the peers run ahead."""
+        old = k - self.depth
+        if old >= self.done_upto or k > self.seq + self.depth - 3:
+            return False
+        while self.ready and self.ready[0][0] <= old:
+            self.ready.pop(0)
+        self.collected = max(self.collected, min(old + 1, self.done_upto))
+        return True
+
+    def _receive(self, r, k, nbytes, flag, slot=None):
+        """Rank dst: post the data receive(s) of peer r's batch k (or take the local copy for r == dst)."""
+        b = self._batch(k)
+        if flag:
+            b["err"] = f"rank {r} reported a packed-buffer overflow for batch {k} ({nbytes} bytes needed; raise per_frame)"
+            b["left"] -= self.repeat               # no data follows; this rank's parts stay None
+            return
+        m = (nbytes + 255) & ~255
+        self._room(m)
+        s = k % self.depth
+        for rep in range(self.repeat):
+            i = rep * self.world + r
+            hrow = self.host[s][i]
+            if self.nccl:
+                with torch.cuda.stream(self.stream):
+                    drow = self.recv[s][i]
+                    if r == self.dst:
+                        drow[:m].copy_(self.src[slot][:m], non_blocking=True)
+                    else:
+                        dist.irecv(drow[:m], src=self._g(r), group=self.group).wait()      # (wait = the side stream waits; the host does not)
+                    hrow[:m].copy_(drow[:m], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                comp = ev
+            else:
+                if r == self.dst:
+                    hrow[:m].copy_(self.src[slot][:m])
+                    comp = None
+                else:
+                    comp = dist.irecv(hrow[:m], src=self._g(r), group=self.group, tag=self.TAG_DATA)
+            b["open"].append((i, comp, hrow, nbytes))
+        return
+
+    def _progress(self):
+        """Rank dst: take the control messages that have arrived, post the data receives they announce (in order per peer, while the ring
+        has room), note the parts that have landed, move completed batches to `ready` (in batch order).  Never blocks."""
+        if not (self.active and self.rank == self.dst):
+            return
+        for r, q in self.announced.items():
+            while True:
+                key = f"{self.prefix}/{r}/{self.next_ctrl[r]}"
+                if not self.store.check([key]):
+                    break
+                k, nbytes, flag = (int(x) for x in self.store.get(key).decode().split(","))
+                self.store.delete_key(key)
+                q.append((k, nbytes, flag))
+                self.next_ctrl[r] += 1
+            while q and self._set_free(q[0][0]):
+                k, nbytes, flag = q.pop(0)
+                self._receive(r, k, nbytes, flag)
+        for k in sorted(self.batches):
+            b = self.batches[k]
+            still = []
+            for i, comp, hrow, nbytes in b["open"]:
+                if self._done(comp):
+                    b["parts"][i] = self._lib.Packed(hrow.numpy()[:nbytes])
+                    b["left"] -= 1
+                else:
+                    still.append((i, comp, hrow, nbytes))
+            b["open"] = still
+        while self.done_upto in self.batches and self.batches[self.done_upto]["left"] == 0:
+            b = self.batches.pop(self.done_upto)
+            self.ready.append((self.done_upto, b["parts"], b["err"]))
+            self.done_upto += 1
+
+    # ---- the API
     def close(self):
+        """Drain, then switch the handle's packed output off."""
         self.drain()
         self.h.set_packed_output(None, None, 0)
-
-    def _finish(self, item):
-        slot, sizes, ev, m = item
-        if ev is not None:
-            ev.synchronize()
-        if not self.active:
-            return [self._lib.Packed(self._pin[slot][:sizes[0]])]
-        if self.rank != self.dst:
-            return None
-        flat = self.host[slot].view(-1).numpy()          # this batch's parts lie back to back, m bytes apart
-        return [self._lib.Packed(flat[i * m:i * m + sizes[i % self.world]]) for i in range(self.world * self.repeat)]
+        self._fin.detach()
 
     def submit(self):
-        """Start the gather of the batch the last fetch returned (every rank calls this once per fetched batch, in the same order)."""
+        """Start the gather of the batch the last fetch returned (every rank calls this once per fetched batch).  Asynchronous: returns
+        as soon as this rank's part is on its way (rank dst: as soon as its own part is copied and whatever has arrived is posted)."""
         import time
         t0 = time.perf_counter()
         ph = {}
@@ -232,84 +386,128 @@ class PackedGather:
             ph[name] = ph.get(name, 0.0) + now - _t[0]
             _t[0] = now
         slot, hdr = self.h.packed_results()
-        if hdr["overflow"]:
-            raise self._lib.Ft8rxError(f"PackedGather: a batch needs {hdr['bytes']} packed bytes, the buffers hold {self.cap} (raise per_frame)")
-        mark("header")
-        while any(p[0] == slot for p in self.pending):          # the gather that last used this slot's buffers
-            self._retire()
-        mark("wait_slot")
-        self.phases.append(ph)
+        overflow = bool(hdr["overflow"])
         nbytes = int(hdr["bytes"])
+        mark("header")
+        k = self.seq
+        self.seq += 1
+        self.phases.append(ph)
         if not self.active:
-            self.pending.append((slot, [nbytes], None, 0))
+            if overflow:
+                raise self._lib.Ft8rxError(f"PackedGather: a batch needs {nbytes} packed bytes, the buffers hold {self.cap} (raise per_frame)")
+            self.ready.append((k, [self._lib.Packed(self._pin[slot][:nbytes])], None))
+            del self.ready[:-2]
             self.seconds.append(time.perf_counter() - t0)
             return
-        if self.nccl and self.cpu_group is None:
-            with torch.cuda.stream(self.stream):
-                mine = torch.tensor([nbytes], dtype=torch.int64).to(self.src[slot].device)
-                allsz = torch.empty(self.world, dtype=torch.int64, device=mine.device)
-                dist.all_gather_into_tensor(allsz, mine, group=self.group)
-                sizes = [int(x) for x in allsz.tolist()]
-        else:
-            mine = torch.tensor([nbytes], dtype=torch.int64)
-            lst = [torch.zeros_like(mine) for _ in range(self.world)]
-            dist.all_gather(lst, mine, group=self.cpu_group)
-            sizes = [int(x.item()) for x in lst]
-        mark("sizes")
-        n = self.world * self.repeat
-        if self.rank == self.dst:
-            self._room((max(sizes) + 255) & ~255)
-        if self.nccl:
-            with torch.cuda.stream(self.stream):
-                m = (max(sizes) + 255) & ~255
-                # the parts of this batch are received back to back (m bytes apart) so that ONE D2H copy moves them all
-                flat = self.recv[slot].view(-1) if self.rank == self.dst else None
-                for rep in range(self.repeat):
-                    out = [flat[(rep * self.world + r) * m:(rep * self.world + r + 1) * m] for r in range(self.world)] if flat is not None else None
-                    dist.gather(self.src[slot][:m], out, dst=self.dst, group=self.group)
-                if flat is not None:
-                    self.host[slot].view(-1)[:n * m].copy_(flat[:n * m], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self.stream)
-                # the pack kernels that next write this slot's buffer (two enqueues from now) wait for the send on the device
-                self._fence[slot] = ev
-                self.h.packed_fence(slot, ev.cuda_event)
-                mark("issue")
-        else:
-            m = max(sizes)
-            flat = self.host[slot].view(-1) if self.rank == self.dst else None
-            for rep in range(self.repeat):
-                out = [flat[(rep * self.world + r) * m:(rep * self.world + r + 1) * m] for r in range(self.world)] if flat is not None else None
-                dist.gather(self.src[slot][:m], out, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            # Only this rank's OWN sends are ever waited for, and only when `depth` of them are in flight.  The buffer of this slot is
+            # safe without the host: on the device path the pack kernels of batch k + 2 wait for the send's event (packed_fence), on
+            # the host path the bytes leave from a private copy.
+            self.sends = [c for c in self.sends if not (hasattr(c, "query") and c.query())]
+            while len(self.sends) >= self.depth:
+                s0 = self.sends.pop(0)
+                self._wait(lambda: self._done(s0), f"an earlier send to be taken by rank {self.dst}")
+            mark("wait_slot")
+            comp = None
+            if not overflow:
+                m = (nbytes + 255) & ~255
+                if self.nccl:
+                    with torch.cuda.stream(self.stream):
+                        for rep in range(self.repeat):
+                            dist.isend(self.src[slot][:m], dst=self._g(self.dst), group=self.group).wait()      # (the side stream waits, not the host)
+                        comp = torch.cuda.Event()
+                        comp.record(self.stream)
+                        # the pack kernels that next write this slot's buffer (two enqueues from now) wait for the send on the device
+                        self.h.packed_fence(slot, comp.cuda_event, keep=comp)
+                else:
+                    # (host path: nothing on the device orders the pack kernels of batch k + 2 behind a gloo send, so the bytes leave
+                    # from a private copy -- the handle's buffer is free again when submit() returns)
+                    stage = self.src[slot][:m].clone()
+                    comp = _All([dist.isend(stage, dst=self._g(self.dst), group=self.group, tag=self.TAG_DATA) for rep in range(self.repeat)], keep=stage)
             mark("issue")
-            ev = None
-        self.pending.append((slot, sizes, ev, m))
+            # the announcement goes out AFTER the send has been started: when rank dst sees it, the matching receive cannot wait long
+            self.store.set(f"{self.prefix}/{self.rank}/{k}", f"{k},{nbytes},{1 if overflow else 0}")
+            mark("sizes")
+            self.sends.append(comp)
+            mark("issue")
+            self.seconds.append(time.perf_counter() - t0)
+            if overflow:
+                raise self._lib.Ft8rxError(f"PackedGather: batch {k} needs {nbytes} packed bytes, the buffers hold {self.cap} (raise per_frame); "
+                                           f"rank {self.dst} has been told")
+            return
+        # rank dst: its own part needs the receive set of batch k - depth back -- the only place it can wait for the slowest peer
+        self._wait(lambda: self._set_free(k), f"batch {k - self.depth} to complete (a peer is {self.depth} batches behind)")
+        mark("wait_slot")
+        self._progress()
+        mark("sizes")
+        self._receive(self.dst, k, nbytes, 1 if overflow else 0, slot)
+        if self.nccl and not overflow:
+            # the local copy reads src[slot] on the side stream: fence the next pack into it, like a send
+            ev = self.batches[k]["open"][-1][1]
+            self.h.packed_fence(slot, ev.cuda_event, keep=ev)
+        self._progress()
+        mark("issue")
         self.seconds.append(time.perf_counter() - t0)
-
-    def _retire(self):
-        """Complete the oldest gather in flight; its result waits in self.ready (the two most recent are kept) until collected."""
-        res = self._finish(self.pending.pop(0))
-        self.ready.append(res)
-        del self.ready[:-2]
-        self._last = res
-        return res
+        if overflow:
+            raise self._lib.Ft8rxError(f"PackedGather: batch {k} needs {nbytes} packed bytes, the buffers hold {self.cap} (raise per_frame)")
 
     def outstanding(self):
-        """Gathers submitted and not yet collected (in flight or completed)."""
-        return len(self.pending) + len(self.ready)
+        """Batches submitted by this rank and not yet collected (in flight or completed)."""
+        return self.seq - self.collected
+
+    def _take(self):
+        k, parts, err = self.ready.pop(0)
+        self.collected = k + 1
+        if err:
+            raise self._lib.Ft8rxError("PackedGather: " + err)
+        self._last = parts
+        return parts
 
     def collect(self):
-        """Rank dst: the per-rank Packed views of the OLDEST submitted batch not collected yet (valid until two more submits);
-        other ranks: None.  Waits for that gather if it is still in flight; with nothing outstanding: the last result again."""
-        if not self.ready and self.pending:
-            self._retire()
-        if self.ready:
-            return self.ready.pop(0)
-        return self._last
+        """Rank dst: the per-rank Packed views of the OLDEST submitted batch not collected yet (valid until `depth` - 1 more batches have
+        been submitted); waits until every rank's part of it has landed.  Other ranks: None, without waiting.  With nothing outstanding:
+        the last result again."""
+        if not self.active:
+            if self.ready:
+                return self._take()
+            return self._last
+        if self.rank != self.dst:
+            self.collected = self.seq
+            return None
+        if self.collected >= self.seq:
+            return self._last
+        want = self.collected
+        self._wait(lambda: self.done_upto > want or self.collected > want, f"batch {want} from every rank")
+        if self.collected > want or not self.ready:        # it was dropped meanwhile (its receive set was needed): the oldest one still there
+            return self._take() if self.ready else self._last
+        return self._take()
 
     def drain(self):
-        """Wait for every gather in flight; -> the last one's result (as collect)."""
-        while self.pending:
-            self._retire()
-        self.ready.clear()
+        """Wait for everything this rank has submitted: its sends taken (other ranks) / every rank's part of every batch up to this
+        rank's last submit landed (rank dst); -> the last batch's result (as collect)."""
+        if not self.active:
+            while self.ready:
+                self._take()
+            return self._last
+        if self.rank != self.dst:
+            while self.sends:
+                s0 = self.sends.pop(0)
+                self._wait(lambda: self._done(s0), f"the send of a batch to be taken by rank {self.dst}")
+            self.collected = self.seq
+            return None
+        self._wait(lambda: self.done_upto >= self.seq, f"batch {self.seq - 1} from every rank")
+        while self.ready:
+            self._take()
         return self._last
+
+
+class _All:
+    """several gloo sends as one"""
+    def __init__(self, items, keep=None):
+        self.items = [i for i in items if i is not None]
+        self.keep = keep
+
+    def wait(self):
+        for i in self.items:
+            i.wait()
+        self.items = []

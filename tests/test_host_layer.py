@@ -520,12 +520,10 @@ h = FakeHandle([batch(k) for k in range(nb)])
 if grow:
     PackedGather.MIN_ROW = 1024                                 # rank 0's receive rows start at twice the first batch's largest part
 g = PackedGather(h, shard(total, 0, world)[1], dst=0, repeat=2 if grow else 1)
-rows = []
 got = []
 for k in range(nb):                                             # the bench loop's order: fetch k, submit k, (collect k - 1)
     h.fetch()
     g.submit()
-    rows.append(g.row)
     if k > 0:
         parts = g.collect()
         if rank == 0:
@@ -538,7 +536,8 @@ parts = g.drain()
 if rank == 0:
     assert len(parts) == world * (2 if grow else 1)
     if grow:
-        assert rows[1] > rows[0] > 0, rows                      # the receive buffers were re-allocated while a gather was in flight
+        rows = g.row_history                                    # the receive sets were re-allocated while parts were in flight
+        assert len(rows) >= 2 and rows[-1] > rows[0] > 0, rows
         assert all(a.buf.tobytes() == b.buf.tobytes() for a, b in zip(parts[:world], parts[world:]))
     parts = parts[:world]
     got.append([[" ".join(x.decode() for x in m["f"]) for m in ms[:n]] for p in parts for ms, n in zip(*_lib.package_packed(p))])
@@ -551,7 +550,7 @@ dist.barrier(); dist.destroy_process_group()
 @pytest.mark.parametrize("world,total,mode", [(2, 5, ""), (8, 8 * 2 + 3, ""), (3, 7, "grow")])
 def test_packed_gather_gloo_uneven_shards(tmp_path, world, total, mode):
     """PackedGather over gloo at world sizes 2 and 8 (the rank-count-dependent paths: uneven shard() blocks, byte counts that differ
-    per rank, padded gather, two gathers in flight) on CPU with a stand-in handle that packs oracle records: rank 0 ends up with every
+    per rank, point-to-point sends announced through the store, several batches in flight) on CPU with a stand-in handle that packs oracle records: rank 0 ends up with every
     rank's frames in shard order, batch after batch, and renders the golden messages from the packed form.  "grow": the first batch is
     small, so rank 0's receive buffers (sized from the byte counts seen) are re-allocated while a gather is in flight; repeat = 2."""
     from pyft8_amd import _lib
