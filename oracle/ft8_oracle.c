@@ -973,6 +973,133 @@ int ft8o_ldpc(float* llr, int max_nc0, int max_iters, uint64_t* lo, uint64_t* hi
     return ldpc_core(llr, max_nc0, max_iters, accept_pure, NULL, lo, hi, n_its, has_out);
 }
 
+/* ------------------------------------------------------------------ np.argsort of a float32 vector (decoders.py:226)
+ * osd_012 orders the 174 columns with np.argsort(-np.abs(llr)).  numpy is a third-party dependency of the reference (not under
+ * /root/reference; pyproject.toml pins only >= 1.24) and its default argsort is UNSTABLE, so the order of equal keys -- the AP bits all
+ * sit at |llr| = 5 -- is whatever the algorithm of the installed build does.  The reference outputs this oracle is pinned to were
+ * produced by numpy 2.2.6 on an AVX-512 host, where np.argsort(float32) is x86-simd-sort's avx512_argsort (vendored under
+ * numpy/_core/src/npysort/x86-simd-sort; dispatched from x86_simd_argsort.dispatch.cpp with hasnan = true).  Restated here from that
+ * library's published algorithm:
+ *   - a vector containing a NaN: std_argsort_withnan (src/xss-common-argsort.h) = std::sort of the index array with the comparator
+ *     "both not NaN: a < b; a NaN: false; else true" -- libstdc++'s introsort (bits/stl_algo.h: __introsort_loop with depth limit
+ *     2 lg n, median-of-three to first, unguarded partition, threshold 16, heapsort fallback, final insertion sort);
+ *   - otherwise, n <= 256: argsort_n<..., 256> (xss-common-argsort.h), a DATA-OBLIVIOUS bitonic network over maxN = the smallest of
+ *     8, 16, ..., 256 with 2 n > maxN, 8 keys per register (32-bit keys travel in ymm registers next to 64-bit indices in zmm), padded
+ *     with +inf: each register sorted by sort_zmm_64bit (avx512-64bit-argsort.hpp), then bitonic_fullmerge_n_vec
+ *     (xss-network-keyvaluesort.hpp): for 2, 4, ... registers per group, COEX of register i with the REVERSED register n-1-i,
+ *     bitonic_clean_n_vec, bitonic_merge_zmm_64bit inside every register.  Every compare-exchange keeps a lane's (key, index) when
+ *     min/max returns its own key (cmp_merge / COEX: mask = eq(result, own key)), i.e. it swaps iff key[lower wire] > key[upper wire]
+ *     STRICTLY -- equal keys never move.  With wire = 8 * register + lane, every stage pairs wire w with w ^ m, the lower wire taking
+ *     the minimum; the masks m are listed by argsort_masks() below.
+ * (n > 256 partitions around a data-dependent pivot first; osd_012 never gets there.)
+ * Pinned: tests/test_oracle_golden.py::test_argsort_equals_numpy runs this against np.argsort of the installed numpy on tie-laden,
+ * NaN-laden and random vectors of every length up to 256 (where the installed numpy is the AVX-512 build); tools/argsort_check.py is
+ * the 10^6-vector version of it (profiles/r05_argsort_check.txt). */
+static int argsort_masks(int nvec, int* m) {
+    static const int first[6] = {1, 3, 1, 7, 2, 1};                    /* sort_zmm_64bit: lanes ^1, reverse of 4, ^1, reverse of 8, ^2, ^1 */
+    int n = 0;
+    for (int i = 0; i < 6; i++) m[n++] = first[i];
+    for (int per = 2; per <= nvec; per *= 2) {
+        m[n++] = 8 * per - 1;                                           /* register i against the reversed register per-1-i */
+        for (int num = per / 2; num >= 2; num /= 2) m[n++] = 8 * (num / 2);      /* bitonic_clean_n_vec: registers num/2 apart */
+        m[n++] = 4; m[n++] = 2; m[n++] = 1;                             /* bitonic_merge_zmm_64bit */
+    }
+    return n;
+}
+
+static int nan_less(const float* x, int32_t a, int32_t b) {             /* std_argsort_withnan's comparator */
+    if (!isnan(x[a]) && !isnan(x[b])) return x[a] < x[b];
+    return isnan(x[a]) ? 0 : 1;
+}
+/* libstdc++ std::sort(first, last, comp) on an index array (bits/stl_algo.h, bits/stl_heap.h), function for function */
+static void ss_unguarded_linear_insert(const float* x, int32_t* a, int last) {
+    int32_t val = a[last]; int next = last - 1;
+    while (nan_less(x, val, a[next])) { a[last] = a[next]; last = next; next--; }
+    a[last] = val;
+}
+static void ss_insertion_sort(const float* x, int32_t* a, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; i++) {
+        if (nan_less(x, a[i], a[first])) { int32_t val = a[i]; memmove(a + first + 1, a + first, sizeof(int32_t) * (size_t)(i - first)); a[first] = val; }
+        else ss_unguarded_linear_insert(x, a, i);
+    }
+}
+static void ss_push_heap(const float* x, int32_t* a, int first, int hole, int top, int32_t value) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && nan_less(x, a[first + parent], value)) { a[first + hole] = a[first + parent]; hole = parent; parent = (hole - 1) / 2; }
+    a[first + hole] = value;
+}
+static void ss_adjust_heap(const float* x, int32_t* a, int first, int hole, int len, int32_t value) {
+    const int top = hole; int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (nan_less(x, a[first + child], a[first + child - 1])) child--;
+        a[first + hole] = a[first + child]; hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a[first + hole] = a[first + child - 1]; hole = child - 1; }
+    ss_push_heap(x, a, first, hole, top, value);
+}
+static void ss_heapsort(const float* x, int32_t* a, int first, int last) {        /* __partial_sort(first, last, last) */
+    const int len = last - first;
+    if (len >= 2) for (int parent = (len - 2) / 2; ; parent--) { ss_adjust_heap(x, a, first, parent, len, a[first + parent]); if (parent == 0) break; }
+    while (last - first > 1) { last--; int32_t v = a[last]; a[last] = a[first]; ss_adjust_heap(x, a, first, 0, last - first, v); }
+}
+static void ss_median_to_first(const float* x, int32_t* a, int result, int p, int q, int r) {
+    int pick;
+    if (nan_less(x, a[p], a[q])) pick = nan_less(x, a[q], a[r]) ? q : (nan_less(x, a[p], a[r]) ? r : p);
+    else pick = nan_less(x, a[p], a[r]) ? p : (nan_less(x, a[q], a[r]) ? r : q);
+    int32_t t = a[result]; a[result] = a[pick]; a[pick] = t;
+}
+static void ss_introsort_loop(const float* x, int32_t* a, int first, int last, int depth) {
+    while (last - first > 16) {
+        if (depth == 0) { ss_heapsort(x, a, first, last); return; }
+        depth--;
+        ss_median_to_first(x, a, first, first + 1, first + (last - first) / 2, last - 1);
+        int lo = first + 1, hi = last;                                  /* __unguarded_partition(first + 1, last, pivot = first) */
+        for (;;) {
+            while (nan_less(x, a[lo], a[first])) lo++;
+            hi--;
+            while (nan_less(x, a[first], a[hi])) hi--;
+            if (!(lo < hi)) break;
+            int32_t t = a[lo]; a[lo] = a[hi]; a[hi] = t;
+            lo++;
+        }
+        ss_introsort_loop(x, a, lo, last, depth);
+        last = lo;
+    }
+}
+static void std_sort_withnan(const float* x, int32_t* a, int n) {
+    if (n < 2) return;
+    int lg = 0; while ((n >> (lg + 1)) != 0) lg++;
+    ss_introsort_loop(x, a, 0, n, 2 * lg);
+    if (n > 16) { ss_insertion_sort(x, a, 0, 16); for (int i = 16; i < n; i++) ss_unguarded_linear_insert(x, a, i); }
+    else ss_insertion_sort(x, a, 0, n);
+}
+
+int ft8o_argsort_f32(const float* x, int n, int32_t* out) {
+    if (n < 0 || n > 256) return -1;
+    for (int i = 0; i < n; i++) out[i] = i;
+    if (n < 2) return 0;
+    int has_nan = 0;
+    for (int i = 0; i < n; i++) if (isnan(x[i])) has_nan = 1;
+    if (has_nan) { std_sort_withnan(x, out, n); return 0; }
+    int maxn = 256;
+    while (maxn > 8 && 2 * n <= maxn) maxn /= 2;
+    float key[256]; int32_t idx[256];
+    for (int w = 0; w < maxn; w++) { key[w] = (w < n) ? x[w] : INFINITY; idx[w] = (w < n) ? w : 0; }
+    int masks[40];
+    const int nm = argsort_masks(maxn / 8, masks);
+    for (int s = 0; s < nm; s++) {
+        const int m = masks[s];
+        for (int w = 0; w < maxn; w++) {
+            const int u = w ^ m;
+            if (u > w && key[w] > key[u]) { float tk = key[w]; key[w] = key[u]; key[u] = tk; int32_t ti = idx[w]; idx[w] = idx[u]; idx[u] = ti; }
+        }
+    }
+    memcpy(out, idx, sizeof(int32_t) * (size_t)n);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ OSD (decoders.py:223-272) */
 static void cw91_to_bits(const uint64_t* w, uint8_t* b91) { for (int k = 0; k < 91; k++) b91[k] = (uint8_t)((w[k >> 6] >> (k & 63)) & 1ULL); }
 
@@ -992,18 +1119,12 @@ static int osd_trial(const uint64_t* w, const uint64_t* hard, int max_hd, accept
 
 static int osd_core(const float* llr, int singles, int doubles, int triples, int max_hd, accept_fn acc, void* ctx,
                     uint64_t* lo, uint64_t* hi, int32_t* trial_out, int32_t* info_cols, int32_t* hd_out) {
-    /* reliability order: |llr| descending, ties (and NaNs, last) by index -- the build's fixed tie rule
-     * for np.argsort(-abs(llr)) (decoders.py:226, unstable in the reference) */
-    int order[174];
-    for (int i = 0; i < 174; i++) order[i] = i;
+    /* reliability order: colperm = np.argsort(-np.abs(llr)) (decoders.py:226) exactly as the reference's numpy orders it, equal keys
+     * (the AP bits at |llr| = 5) and NaNs included: ft8o_argsort_f32 above */
+    int32_t order[174];
     float key[174];
-    for (int i = 0; i < 174; i++) key[i] = fabsf(llr[i]);
-    for (int i = 1; i < 174; i++) {
-        int t = order[i]; float kt = key[t]; int j = i - 1;
-        /* move t before order[j] iff key[t] strictly greater (NaN never moves, non-NaN passes NaN) */
-        while (j >= 0 && ((kt > key[order[j]]) || (kt == kt && key[order[j]] != key[order[j]]))) { order[j + 1] = order[j]; j--; }
-        order[j + 1] = t;
-    }
+    for (int i = 0; i < 174; i++) key[i] = -fabsf(llr[i]);
+    ft8o_argsort_f32(key, 174, order);
     uint64_t G[91][3];
     memcpy(G, FT8_G0, sizeof(G));
     uint8_t used[91]; memset(used, 0, sizeof(used));

@@ -98,6 +98,8 @@ int   ft8o_ldpc(float* llr /* in/out */, int max_nc0, int max_iters, uint64_t* l
                 int32_t* n_its, int32_t* has_out);
 int   ft8o_osd_ext(const float* llr, int singles, int doubles, int triples, int max_hd, uint64_t* lo, uint64_t* hi, int32_t* trial,
                    int32_t* info_cols, int32_t* hd_out);
+/* np.argsort(x) of n <= 256 float32 values as the reference's numpy (2.2.6, AVX-512: x86-simd-sort) orders them, ties and NaNs included */
+int   ft8o_argsort_f32(const float* x, int n, int32_t* out);
 int   ft8o_osd(const float* llr, int singles, int doubles, uint64_t* lo, uint64_t* hi, int32_t* trial,
                int32_t* info_cols /*[91] or NULL*/);
 /* hash table + rendering (reference decoders.py:16-115, databases.py:8-26) */

@@ -213,6 +213,15 @@ def osd(llr, singles=30, doubles=2, triples=0, max_hd=0, want_hd=False):
     return out + (hd.value,) if want_hd else out
 
 
+def argsort_f32(x):
+    """np.argsort(x) of <= 256 float32 values as the reference's numpy (2.2.6 on AVX-512) orders them (ft8o_argsort_f32)."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(len(x), np.int32)
+    if lib().ft8o_argsort_f32(_p(x), len(x), _p(out, C.c_int32)) != 0:
+        raise ValueError("ft8o_argsort_f32: 0 <= n <= 256")
+    return out
+
+
 def crc_valid91(llr91):
     llr91 = np.ascontiguousarray(llr91, np.float32)
     lo, hi = C.c_uint64(), C.c_uint64()

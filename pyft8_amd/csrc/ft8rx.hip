@@ -33,6 +33,7 @@
 #include "ft8_dev.h"
 
 #define MAXC FT8RX_MAX_CANDS
+#define WL_MULT(i) ((i) == WL_BP0 ? 5 : (i) == WL_OSDNAN ? 10 : 1)      /* entries per candidate slot of work list i */
 #define NF0MAX (FT8RX_MAX_F0 > 1024 ? 2048 : 1024)     /* per-frame stride of the per-f0 sync results; k_topk sorts this many keys */
 
 // The kernels live in one file per stage; this file is the C ABI, the handle and the launch chains.
@@ -315,7 +316,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     // stage entry points use one of the three at a time.  -1.16 MB of HBM per frame.
     static_assert((size_t)(96000 + FT8RX_SPEC_BINS) * sizeof(cpx) <= (size_t)FT8RX_GRID_ROWS * FT8RX_GRID_COLS * sizeof(float), "scratch A + cycle spectrum fit a frame's grid");
     if (!rc) { h->d_A = reinterpret_cast<cpx*>(h->d_grid); h->d_spec = h->d_A + B * 96000; }
-    for (int i = 0; i < WL_N; i++) rc |= dalloc(h, &h->d_work[i], B * MAXC * (i == WL_BP0 ? 5 : 1));      // WL_BP0 lists attempts
+    for (int i = 0; i < WL_N; i++) rc |= dalloc(h, &h->d_work[i], B * MAXC * WL_MULT(i));      // WL_BP0 / WL_OSDNAN list attempts
     rc |= dalloc(h, &h->d_wcount, (size_t)16 * WL_N);
     rc |= dalloc(h, &h->d_ev, B * FT8RX_EVENT_CAP);
     rc |= dalloc(h, &h->d_evcount, B);
@@ -472,7 +473,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
 #define STAGE(name) do { if (prof) { hipEventRecord(h->pev[h->pnames.size()], s); h->pnames.push_back(name); } } while (0)
     int32_t* wc = h->d_wcount + WL_N * chunk;                      // (evc and wc are zeroed by k_topk)
     WorkList wl[WL_N];
-    for (int i = 0; i < WL_N; i++) { wl[i].items = h->d_work[i] + F * MAXC * (i == WL_BP0 ? 5 : 1); wl[i].count = wc + i; }
+    for (int i = 0; i < WL_N; i++) { wl[i].items = h->d_work[i] + F * MAXC * WL_MULT(i); wl[i].count = wc + i; }
     STAGE("spectrogram");
     ft8rx_ilp_spectrogram(B, s, audio, grid, h->T);
     STAGE("sync");
@@ -511,8 +512,12 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
         k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(3, rec, ncand, attG, attB, B, c, wl[WL_OSD]);
     }
     STAGE("osd");
-    (osd_nflip(c.osd_single, c.osd_triple) > OSD_FLIPS_A ? k_osd_wide : k_osd)<<<ladder_grid(B * MAXC * 10), 64, 0, s>>>(
-        0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials, osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd, wl[WL_OSD]);
+    const bool osd_wide = osd_nflip(c.osd_single, c.osd_triple) > OSD_FLIPS_A;
+    (osd_wide ? k_osd_wide : k_osd)<<<ladder_grid(B * MAXC * 10), 64, 0, s>>>(
+        0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials, osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd, wl[WL_OSD], wl[WL_OSDNAN]);
+    // attempts on vectors with a NaN (a NaN-poisoned BP output): the reference's numpy orders those with std::sort -- a kernel of their own
+    (osd_wide ? k_osd_nan_wide : k_osd_nan)<<<OSD_NAN_GRID, 64, 0, s>>>(
+        0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials, osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd, wl[WL_OSDNAN]);
     STAGE("select2");
     k_select2<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, attO, B);
     if (prof) hipEventRecord(h->pev[h->pnames.size()], s);
@@ -1029,9 +1034,15 @@ int ft8rx_osd_ext(ft8rx_handle* h, const float* llr, int n, int singleflips, int
     float* d_in = S.put(llr, (size_t)n * 174); NEED(d_in);
     uint32_t* d_tr = S.put(tr.data(), tr.size()); NEED(d_tr);
     Att* d_att = S.get<Att>(n); NEED(d_att);
-    (osd_nflip(singleflips, tripleflips) > OSD_FLIPS_A ? k_osd_wide : k_osd)<<<n, 64, 0, h->stream>>>(
+    int32_t* d_nan = S.get<int32_t>((size_t)n + 1); NEED(d_nan);            // [0] = length of the list of NaN vectors, then the list
+    HIPCHK(h, hipMemsetAsync(d_nan, 0, sizeof(int32_t), h->stream));
+    const WorkList nanl{d_nan + 1, d_nan};
+    const bool osd_wide = osd_nflip(singleflips, tripleflips) > OSD_FLIPS_A;
+    (osd_wide ? k_osd_wide : k_osd)<<<n, 64, 0, h->stream>>>(
         2, d_in, nullptr, nullptr, nullptr, nullptr, d_att, nullptr, nullptr, d_tr, (int)tr.size(), osd_nflip(singleflips, tripleflips), max_hd,
-        WorkList{nullptr, nullptr});
+        WorkList{nullptr, nullptr}, nanl);
+    (osd_wide ? k_osd_nan_wide : k_osd_nan)<<<OSD_NAN_GRID, 64, 0, h->stream>>>(
+        2, d_in, nullptr, nullptr, nullptr, nullptr, d_att, nullptr, nullptr, d_tr, (int)tr.size(), osd_nflip(singleflips, tripleflips), max_hd, nanl);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<Att> a(n);
     HIPCHK(h, hipMemcpy(a.data(), d_att, sizeof(Att) * n, hipMemcpyDeviceToHost));

@@ -34,7 +34,7 @@ __device__ __constant__ uint8_t d_PAYSYM[58] = {7,8,9,10,11,12,13,14,15,16,17,18
 // order is whatever the atomics give -- every attempt writes its own result slot and the host sorts the event log, so results do
 // not depend on it.
 struct WorkList { int32_t* items; int32_t* count; };
-enum { WL_BP0 = 0, WL_FINE = 1, WL_BP1 = 2, WL_BP1B = 3, WL_BP1C = 4, WL_OSD = 5, WL_N = 6 };
+enum { WL_BP0 = 0, WL_FINE = 1, WL_BP1 = 2, WL_BP1B = 3, WL_BP1C = 4, WL_OSD = 5, WL_OSDNAN = 6, WL_N = 7 };      // WL_BP0 lists attempts (x 5), WL_OSDNAN OSD attempts (x 10)
 
 #define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */
 

@@ -5,8 +5,9 @@
 
 // ------------------------------------------------------------------------------------ OSD (decoders.py:223-272)
 // One wavefront per attempt, three phases:
-//   1. reliability order: bitonic network over 256 composite keys held in registers, exchanged by DPP / ds_swizzle / ds_bpermute (fixed tie
-//      rule for the reference's unstable argsort);
+//   1. reliability order = np.argsort(-abs(llr)) as the reference's numpy (2.2.6 on AVX-512: x86-simd-sort) orders it, equal keys
+//      included: that library's 256-wire compare-exchange network run on (key, index) pairs held in registers, exchanged by DPP /
+//      ds_swizzle / ds_bpermute; a vector with a NaN takes the library's other path, std::sort, on one lane (rare);
 //   2. most-reliable-basis Gauss-Jordan over GF(2) with the generator held COLUMN-wise: lane l owns columns l, 64+l, 128+l
 //      of G0 (91 row bits each, 3 x u32).  A visited column is broadcast to scalar registers; "independent of the accepted
 //      columns" is then a scalar test (any 1 in an unlocked row), the pivot row a scalar find-first-set, and the elimination
@@ -28,29 +29,115 @@ __device__ unsigned long long g_osd_t[32768][10];       // per block: plain adds
 #define OT(i) do { } while (0)
 #define OT_FLUSH do { } while (0)
 #endif
-FT8_DEV uint64_t shfl64(uint64_t v, int src) {
-    uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
-    return ((uint64_t)hi << 32) | lo;
+// ---- np.argsort's compare-exchange network (oracle/ft8_oracle.c: ft8o_argsort_f32 has the derivation and the library references).
+// 256 wires = 32 registers of 8 lanes in the library; here wire w = 64 q + lane sits in register q of the lane.  Every stage pairs wire w
+// with w ^ M, the LOWER wire keeps the smaller key, and equal keys never move (the library moves an index only when min / max did not
+// return the lane's own key).  Stage masks: 1 3 1 7 2 1 | 15 4 2 1 | 31 8 4 2 1 | 63 16 8 4 2 1 | 127 32 16 8 4 2 1 | 255 64 32 16 8 4 2 1.
+// osd_px<M>: the value of lane ^ M, M < 64: quad permutes / row mirrors (DPP) for 1, 2, 3, 7, 15, a row rotate for 8, ds_swizzle (crossbar only,
+// no address register) for 4, 16, 31, ds_bpermute for 32 and 63.
+template <int M> FT8_DEV uint32_t osd_px(uint32_t v, int lane) {
+    if (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);          // quad_perm:[1,0,3,2]
+    if (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);          // quad_perm:[2,3,0,1]
+    if (M == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xf, 0xf, false);          // quad_perm:[3,2,1,0]
+    if (M == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);         // row_half_mirror
+    if (M == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);        // row_mirror
+    if (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);         // row_ror:8
+    if (M == 4 || M == 16 || M == 31) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (M << 10));   // bit mode: lane ^ M within 32
+    return __shfl(v, lane ^ M);
+}
+// one stage between lanes M apart on NQ registers of (key, index) pairs
+template <int M, int NQ> FT8_DEV void osd_stage(uint32_t* hk, uint32_t* ix, int lane) {
+    constexpr int top = M >= 32 ? 32 : M >= 16 ? 16 : M >= 8 ? 8 : M >= 4 ? 4 : M >= 2 ? 2 : 1;      // highest bit of M: clear on the lower wire
+    const bool lower = (lane & top) == 0;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const uint32_t pk = osd_px<M>(hk[q], lane), pi = osd_px<M>(ix[q], lane);
+        const bool take = lower ? (hk[q] > pk) : (hk[q] < pk);
+        hk[q] = take ? pk : hk[q]; ix[q] = take ? pi : ix[q];
+    }
+}
+template <int NQ> FT8_DEV void osd_stages_421(uint32_t* hk, uint32_t* ix, int lane) {
+    osd_stage<4, NQ>(hk, ix, lane); osd_stage<2, NQ>(hk, ix, lane); osd_stage<1, NQ>(hk, ix, lane);
+}
+// register a (lower wires) against register b, same lane (reversed = false) or lane 63 - l (reversed = true: the first stage of a merge)
+template <bool REV> FT8_DEV void osd_stage_regs(uint32_t& ka, uint32_t& ia, uint32_t& kb, uint32_t& ib, int lane) {
+    const uint32_t pkb = REV ? __shfl(kb, 63 - lane) : kb, pib = REV ? __shfl(ib, 63 - lane) : ib;      // what a's lane faces
+    const uint32_t pka = REV ? __shfl(ka, 63 - lane) : ka, pia = REV ? __shfl(ia, 63 - lane) : ia;      // what b's lane faces
+    const bool ta = ka > pkb, tb = kb < pka;
+    ka = ta ? pkb : ka; ia = ta ? pib : ia;
+    kb = tb ? pka : kb; ib = tb ? pia : ib;
 }
 
-// the value of lane ^ S: quad permutes (DPP) for S = 1, 2, ds_swizzle (crossbar only, no address register) for 4, 8, 16, ds_bpermute for 32
-template <int S> FT8_DEV uint32_t osd_xlane(uint32_t v, int lane) {
-    if (S == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);          // quad_perm:[1,0,3,2]
-    if (S == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);          // quad_perm:[2,3,0,1]
-    if (S == 4 || S == 8 || S == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (S << 10));   // bit mode: lane ^ S within 32
-    return __shfl(v, lane ^ S);
+// ---- the library's path for a vector that contains a NaN (std_argsort_withnan): libstdc++'s std::sort of the index array with the
+// comparator "both not NaN: a < b; a NaN: false; else true" on the keys -|llr|.  One lane, in LDS; rare (a NaN-poisoned BP output,
+// decoders.py:143-147).  Function for function as in oracle/ft8_oracle.c (std_sort_withnan), with the recursion on the right part
+// turned into an explicit stack (the parts are disjoint, their order does not matter).
+FT8_DEV bool osd_nl(const float* x, int a, int b) {
+    const float xa = x[a], xb = x[b];
+    if (xa == xa && xb == xb) return fabsf(xa) > fabsf(xb);             // -|xa| < -|xb|
+    return xa == xa;                                                    // a NaN: false; a number against a NaN: true
 }
-// one compare-exchange step of the bitonic network between lanes S apart: this lane keeps the smaller key iff keep_min
-template <int S> FT8_DEV uint64_t osd_cx(uint64_t k, int lane, bool keep_min) {
-    const uint64_t o = ((uint64_t)osd_xlane<S>((uint32_t)(k >> 32), lane) << 32) | osd_xlane<S>((uint32_t)k, lane);
-    return ((k < o) == keep_min) ? k : o;
+FT8_DEV void osd_ss_linear_insert(const float* x, int* a, int last) {
+    const int val = a[last]; int next = last - 1;
+    while (osd_nl(x, val, a[next])) { a[last] = a[next]; last = next; next--; }
+    a[last] = val;
 }
-// the lane strides S, S/2, ..., 1 of one merge on NQ registers; up(q) = direction of block q
-template <int S, int NQ, typename UP> FT8_DEV void osd_merge_lanes(uint64_t* kq, int lane, UP up) {
-    const bool lower = (lane & S) == 0;
-#pragma unroll
-    for (int q = 0; q < NQ; q++) kq[q] = osd_cx<S>(kq[q], lane, lower == up(q));
-    if constexpr (S > 1) osd_merge_lanes<S / 2, NQ>(kq, lane, up);
+FT8_DEV void osd_ss_insertion(const float* x, int* a, int first, int last) {
+    for (int i = first + 1; i < last; i++) {
+        if (osd_nl(x, a[i], a[first])) { const int val = a[i]; for (int j = i; j > first; j--) a[j] = a[j - 1]; a[first] = val; }
+        else osd_ss_linear_insert(x, a, i);
+    }
+}
+FT8_DEV void osd_ss_adjust_heap(const float* x, int* a, int first, int hole, int len, int value) {
+    const int top = hole; int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (osd_nl(x, a[first + child], a[first + child - 1])) child--;
+        a[first + hole] = a[first + child]; hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a[first + hole] = a[first + child - 1]; hole = child - 1; }
+    int parent = (hole - 1) / 2;                                        // __push_heap
+    while (hole > top && osd_nl(x, a[first + parent], value)) { a[first + hole] = a[first + parent]; hole = parent; parent = (hole - 1) / 2; }
+    a[first + hole] = value;
+}
+FT8_DEV void osd_std_sort_withnan(const float* x, int* a, int* stack /* [3 * 20] */) {
+    const int n = 174;
+    for (int i = 0; i < n; i++) a[i] = i;
+    int sp = 0;
+    stack[0] = 0; stack[1] = n; stack[2] = 2 * 7; sp = 1;              // depth limit 2 * floor(lg 174)
+    while (sp > 0) {
+        sp--;
+        int first = stack[3 * sp], last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
+        while (last - first > 16) {
+            if (depth == 0) {                                           // heapsort (__partial_sort(first, last, last))
+                const int len = last - first;
+                for (int parent = (len - 2) / 2; parent >= 0; parent--) osd_ss_adjust_heap(x, a, first, parent, len, a[first + parent]);
+                while (last - first > 1) { last--; const int v = a[last]; a[last] = a[first]; osd_ss_adjust_heap(x, a, first, 0, last - first, v); }
+                break;
+            }
+            depth--;
+            {   // __move_median_to_first(first, first + 1, mid, last - 1)
+                const int p = first + 1, q = first + (last - first) / 2, r = last - 1;
+                int pick;
+                if (osd_nl(x, a[p], a[q])) pick = osd_nl(x, a[q], a[r]) ? q : (osd_nl(x, a[p], a[r]) ? r : p);
+                else pick = osd_nl(x, a[p], a[r]) ? p : (osd_nl(x, a[q], a[r]) ? r : q);
+                const int t = a[first]; a[first] = a[pick]; a[pick] = t;
+            }
+            int lo = first + 1, hi = last;                              // __unguarded_partition(first + 1, last, pivot = *first)
+            for (;;) {
+                while (osd_nl(x, a[lo], a[first])) lo++;
+                hi--;
+                while (osd_nl(x, a[first], a[hi])) hi--;
+                if (!(lo < hi)) break;
+                const int t = a[lo]; a[lo] = a[hi]; a[hi] = t;
+                lo++;
+            }
+            stack[3 * sp] = lo; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; sp++;      // the right part, later
+            last = lo;
+        }
+    }
+    osd_ss_insertion(x, a, 0, 16);                                      // __final_insertion_sort, n > 16
+    for (int i = 16; i < n; i++) osd_ss_linear_insert(x, a, i);
 }
 
 #define OSD_MAXFLIP 91            /* flip rows kept per attempt = all 91 basis positions (decoders.py:244-246 takes any count up to the basis size) */
@@ -69,12 +156,15 @@ FT8_DEV unsigned osd_syndrome(uint64_t w0, uint64_t w1) { return ft8_crc_syndrom
 // mode 0: pipeline (work = (candidate, slot 0..9)); mode 2: raw vectors.  WIDE: more than 62 flip rows (k_osd_wide) -- a kernel of its
 // own, because the second flip word costs 13 VGPRs = two of the seven waves per SIMD that hide this kernel's scalar-pipe latency
 // (one kernel with a run-time switch: 0.737 -> 0.791 ms per 256 frames at the reference's 30 / 2)
-template <bool WIDE>
+// NANV: the kernel of the attempts whose vector holds a NaN (k_osd_nan / k_osd_nan_wide).  The library sorts such a vector with std::sort
+// -- a serial algorithm, run by one lane, whose code costs the main kernel 8 VGPRs and a scratch frame if it lives there: the main kernels
+// (NANV = false) only append such an attempt to `nanlist` and leave; the NaN kernels stride over that list (almost always empty).
+template <bool WIDE, bool NANV>
 FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ llr_in, const float* __restrict__ saved,
                          const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,
                          const int32_t* __restrict__ ncand, Att* __restrict__ attO,
                          ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,
-                         int nflip, int max_hd) {
+                         int nflip, int max_hd, const WorkList& nanlist) {
     __shared__ float llr[176];
     __shared__ uint64_t skey[256];
     __shared__ uint64_t ftab[192];                         // per column (natural order): bit i = flip i covers it (i < 62), bit 63 = order-0 codeword bit
@@ -104,43 +194,47 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
         for (int i = lane; i < 174; i += 64) llr[i] = llr_in[vec * 174 + i];
     }
     __syncthreads();
-    // ---- reliability order: |llr| descending, ties and NaNs (last) by index (fixed rule for np.argsort, decoders.py:226).
-    // Bitonic network over 256 composite keys ((~magnitude bits) << 32 | index), element 64 q + lane in register q of the lane: the steps
-    // between lanes are cross-lane exchanges, the strides 64 / 128 are register pairs of one lane -- no LDS image, no barriers (the LDS form
-    // spent 21 % of the kernel here, 36 barriers per attempt: profiles/r04_osd_timing.txt).  Register 3 would hold the 64 padding keys
-    // (~0): every step that involves it is resolved by hand below.
-    uint64_t kq[3];
+    // ---- reliability order: np.argsort(-abs(llr)) as the reference's numpy orders it (decoders.py:226; the network above).  Keys: the
+    // magnitude bits, inverted so that an ascending unsigned sort is |llr| descending; padding wires (174 .. 255) hold the largest key.
+    // Register 3 would be all padding and stays all padding up to the last merge: every stage that involves it is resolved by hand.
+    uint32_t hk[3], ix[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) {
         const int i = lane + 64 * q;
-        uint64_t key = ~0ull;
-        if (i < 174) {
-            const float x = llr[i];
-            const uint32_t k32 = (x != x) ? 0u : ((__float_as_uint(x) & 0x7fffffffu) + 1u);
-            key = ((uint64_t)(0xFFFFFFFFu - k32) << 32) | (uint32_t)i;
-        }
-        kq[q] = key;
+        const uint32_t mag = __float_as_uint(llr[i < 174 ? i : 0]) & 0x7fffffffu;
+        hk[q] = (i < 174) ? 0xFFFFFFFEu - mag : 0xFFFFFFFFu;
+        ix[q] = (i < 174) ? (uint32_t)i : 0u;
     }
+    const bool any_nan = __ballot((hk[0] < 0x807FFFFEu) || (hk[1] < 0x807FFFFEu) || (lane < 46 && hk[2] < 0x807FFFFEu)) != 0;      // magnitude bits above infinity's
     OT(0);
 #ifndef OSD_TIMING_SKIP_SORT            /* timing-only builds (tools/ab_variants.sh): never defined in the product */
-    // sizes 2 .. 64: the three real blocks, each in its own register; block q ends ascending for even q, descending for odd q
-    osd_merge_lanes<1, 3>(kq, lane, [&](int) { return (lane & 2) == 0; });
-    osd_merge_lanes<2, 3>(kq, lane, [&](int) { return (lane & 4) == 0; });
-    osd_merge_lanes<4, 3>(kq, lane, [&](int) { return (lane & 8) == 0; });
-    osd_merge_lanes<8, 3>(kq, lane, [&](int) { return (lane & 16) == 0; });
-    osd_merge_lanes<16, 3>(kq, lane, [&](int) { return (lane & 32) == 0; });
-    osd_merge_lanes<32, 3>(kq, lane, [&](int q) { return (q & 1) == 0; });
-    // size 128.  Blocks 0 (ascending) and 1 (descending) merge upwards: stride 64 is the register pair, then the lane strides.
-    { const uint64_t a = kq[0], b = kq[1]; const bool lt = a < b; kq[0] = lt ? a : b; kq[1] = lt ? b : a; }
-    osd_merge_lanes<32, 2>(kq, lane, [&](int) { return true; });
-    // Blocks 2 (ascending) and 3 (all padding) merge DOWNWARDS: the padding moves to block 2, block 3 becomes block 2 reversed.
-    uint64_t k3 = shfl64(kq[2], 63 - lane);
-    // size 256, upwards.  Stride 128: (block 0, padding) stays; (block 1, block 3) exchange.  Stride 64: (block 0, block 1) exchange;
-    // (padding, block 3) swap, i.e. block 2 := block 3.  Then the lane strides on blocks 0 .. 2.
-    { const uint64_t a = kq[1], b = k3; const bool lt = a < b; kq[1] = lt ? a : b; k3 = lt ? b : a; }
-    { const uint64_t a = kq[0], b = kq[1]; const bool lt = a < b; kq[0] = lt ? a : b; kq[1] = lt ? b : a; }
-    kq[2] = k3;
-    osd_merge_lanes<32, 3>(kq, lane, [&](int) { return true; });
+    if (NANV) {                                               // the library's std::sort path, one lane (k_osd_nan)
+        if (!any_nan) return;                                 // (never: the list only holds such attempts)
+        int* ordl = reinterpret_cast<int*>(skey);             // [174] the order, then [60] the range stack (skey is not in use yet)
+        if (lane == 0) osd_std_sort_withnan(llr, ordl, ordl + 176);
+        __syncthreads();
+        ix[0] = (uint32_t)ordl[lane]; ix[1] = (uint32_t)ordl[64 + lane]; ix[2] = (uint32_t)ordl[128 + (lane < 46 ? lane : 0)];
+        __syncthreads();
+    } else if (any_nan) {                                     // wave-uniform, rare: left to the NaN kernel
+        if (lane == 0) work_push(nanlist, bid);
+        return;
+    } else {
+        // inside the registers: each register's 64 wires sorted (8 library registers), three at a time
+        osd_stage<1, 3>(hk, ix, lane); osd_stage<3, 3>(hk, ix, lane); osd_stage<1, 3>(hk, ix, lane);
+        osd_stage<7, 3>(hk, ix, lane); osd_stage<2, 3>(hk, ix, lane); osd_stage<1, 3>(hk, ix, lane);
+        osd_stage<15, 3>(hk, ix, lane); osd_stages_421<3>(hk, ix, lane);
+        osd_stage<31, 3>(hk, ix, lane); osd_stage<8, 3>(hk, ix, lane); osd_stages_421<3>(hk, ix, lane);
+        osd_stage<63, 3>(hk, ix, lane); osd_stage<16, 3>(hk, ix, lane); osd_stage<8, 3>(hk, ix, lane); osd_stages_421<3>(hk, ix, lane);
+        // merge of 16 library registers: wires 0..63 against 127..64 reversed (registers 0 / 1); registers 2 / 3: 3 is padding, 2 is
+        // sorted and stays as it is through this whole merge
+        osd_stage_regs<true>(hk[0], ix[0], hk[1], ix[1], lane);
+        osd_stage<32, 2>(hk, ix, lane); osd_stage<16, 2>(hk, ix, lane); osd_stage<8, 2>(hk, ix, lane); osd_stages_421<2>(hk, ix, lane);
+        // merge of 32: w against 255 - w (register 1 against register 2 reversed; register 0 faces padding), then registers 0 / 1 lane
+        // by lane (2 faces padding), then the lane strides on all three
+        osd_stage_regs<true>(hk[1], ix[1], hk[2], ix[2], lane);
+        osd_stage_regs<false>(hk[0], ix[0], hk[1], ix[1], lane);
+        osd_stage<32, 3>(hk, ix, lane); osd_stage<16, 3>(hk, ix, lane); osd_stage<8, 3>(hk, ix, lane); osd_stages_421<3>(hk, ix, lane);
+    }
 #endif
     // ---- Gauss-Jordan over GF(2), generator held column-wise in SORTED order: lane l of register set s owns the column at
     // reliability position 64 s + l (91 row bits: rows 0..63 as two u32, rows 64..90 in a third).  A row is "locked" once it has
@@ -154,7 +248,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     // is this kernel's bottleneck (profiles/r02_notes.md), so the bookkeeping is kept to lock words and one accepted-position bit
     // per step; everything that can wait (hard-decision mask, flip rows, syndromes) is done afterwards on the vector side.
     OT(1);
-    const int ord0 = (int)(uint32_t)kq[0], ord1 = (int)(uint32_t)kq[1], ord2 = (lane < 46) ? (int)(uint32_t)kq[2] : 0;
+    const int ord0 = (int)ix[0], ord1 = (int)ix[1], ord2 = (lane < 46) ? (int)ix[2] : 0;
     const bool has2 = lane < 46;
     uint32_t x00 = d_G0T[ord0][0], x01 = d_G0T[ord0][1], x02 = d_G0T[ord0][2];
     uint32_t x10 = d_G0T[ord1][0], x11 = d_G0T[ord1][1], x12 = d_G0T[ord1][2];
@@ -367,19 +461,37 @@ __global__ __launch_bounds__(64) OSD_ATTR void NAME(int mode, const float* __res
                                            const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,                            \
                                            const int32_t* __restrict__ ncand, Att* __restrict__ attO,                               \
                                            ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,        \
-                                           int nflip, int max_hd, WorkList work) {                                                  \
-    if (mode == 2) { osd_attempt<WIDE>(threadIdx.x, 2, blockIdx.x, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd); return; } \
+                                           int nflip, int max_hd, WorkList work, WorkList nanlist) {                                \
+    if (mode == 2) { osd_attempt<WIDE, false>(threadIdx.x, 2, blockIdx.x, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd, nanlist); return; } \
     const int n = *work.count * 10;                                                                                                 \
     _Pragma("unroll 1")                                                                                                             \
     for (int item = blockIdx.x; item < n; item += gridDim.x) {                                                                      \
         int lane = threadIdx.x;                                                                                                     \
         asm volatile("" : "+v"(lane));       /* opaque per item: nothing lane-specific is hoisted across attempts (register pressure) */ \
-        osd_attempt<WIDE>(lane, 0, work.items[item / 10] * 10 + item % 10, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd); \
+        osd_attempt<WIDE, false>(lane, 0, work.items[item / 10] * 10 + item % 10, llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd, nanlist); \
         __syncthreads();                     /* the LDS arrays are reused by the next attempt */                                   \
     }                                                                                                                               \
 }
 OSD_KERNEL(k_osd, false)
 OSD_KERNEL(k_osd_wide, true)        /* more than OSD_FLIPS_A flip rows */
 #undef OSD_KERNEL
+// the attempts the main kernels left on `nanlist` (attempt ids as they got them: candidate * 10 + slot, or the vector index in mode 2)
+#define OSD_NAN_KERNEL(NAME, WIDE)                                                                                                   \
+__global__ __launch_bounds__(64) void NAME(int mode, const float* __restrict__ llr_in, const float* __restrict__ saved,             \
+                                           const Att* __restrict__ attB, ft8rx_record* __restrict__ rec,                            \
+                                           const int32_t* __restrict__ ncand, Att* __restrict__ attO,                               \
+                                           ft8rx_event* ev, int32_t* evcount, const uint32_t* __restrict__ trials, int ntr,        \
+                                           int nflip, int max_hd, WorkList nanlist) {                                               \
+    const int n = *nanlist.count;                                                                                                   \
+    _Pragma("unroll 1")                                                                                                             \
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {                                                                      \
+        osd_attempt<WIDE, true>(threadIdx.x, mode, nanlist.items[item], llr_in, saved, attB, rec, ncand, attO, ev, evcount, trials, ntr, nflip, max_hd, nanlist); \
+        __syncthreads();                                                                                                            \
+    }                                                                                                                               \
+}
+OSD_NAN_KERNEL(k_osd_nan, false)
+OSD_NAN_KERNEL(k_osd_nan_wide, true)
+#undef OSD_NAN_KERNEL
+#define OSD_NAN_GRID 512             /* blocks of the NaN kernels: they stride over a list that is almost always empty */
 
 #endif
