@@ -412,6 +412,14 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
         static uint16_t ct[12][256];
         for (int b = 0; b < 12; b++) for (int x = 0; x < 256; x++) { uint16_t a = 0; for (int t = 0; t < 8; t++) if ((x >> t) & 1) a ^= syn91[8 * b + t]; ct[b][x] = a; }
         ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CRC_T), ct, sizeof(ct)) == hipSuccess;
+        {   // np.argsort of an all-NaN vector (kernels/osd.hpp: d_NANPERM)
+            float xn[174]; int perm[176], stk[64]; uint8_t p8[192];
+            for (int i = 0; i < 174; i++) xn[i] = NAN;
+            osd_std_sort_withnan(xn, perm, stk);
+            memset(p8, 0, sizeof(p8));
+            for (int i = 0; i < 174; i++) p8[i] = (uint8_t)perm[i];
+            ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_NANPERM), p8, sizeof(p8)) == hipSuccess;
+        }
         const std::vector<uint32_t> tr = osd_trial_table(cfg->osd_single, cfg->osd_double, cfg->osd_triple);
         h->n_trials = (int)tr.size();
         if (upload(h, &h->d_trials, tr)) ok = false;

@@ -72,23 +72,24 @@ template <bool REV> FT8_DEV void osd_stage_regs(uint32_t& ka, uint32_t& ia, uint
 // comparator "both not NaN: a < b; a NaN: false; else true" on the keys -|llr|.  One lane, in LDS; rare (a NaN-poisoned BP output,
 // decoders.py:143-147).  Function for function as in oracle/ft8_oracle.c (std_sort_withnan), with the recursion on the right part
 // turned into an explicit stack (the parts are disjoint, their order does not matter).
-FT8_DEV bool osd_nl(const float* x, int a, int b) {
+#define FT8_HD __host__ __device__ inline
+FT8_HD bool osd_nl(const float* x, int a, int b) {
     const float xa = x[a], xb = x[b];
     if (xa == xa && xb == xb) return fabsf(xa) > fabsf(xb);             // -|xa| < -|xb|
     return xa == xa;                                                    // a NaN: false; a number against a NaN: true
 }
-FT8_DEV void osd_ss_linear_insert(const float* x, int* a, int last) {
+FT8_HD void osd_ss_linear_insert(const float* x, int* a, int last) {
     const int val = a[last]; int next = last - 1;
     while (osd_nl(x, val, a[next])) { a[last] = a[next]; last = next; next--; }
     a[last] = val;
 }
-FT8_DEV void osd_ss_insertion(const float* x, int* a, int first, int last) {
+FT8_HD void osd_ss_insertion(const float* x, int* a, int first, int last) {
     for (int i = first + 1; i < last; i++) {
         if (osd_nl(x, a[i], a[first])) { const int val = a[i]; for (int j = i; j > first; j--) a[j] = a[j - 1]; a[first] = val; }
         else osd_ss_linear_insert(x, a, i);
     }
 }
-FT8_DEV void osd_ss_adjust_heap(const float* x, int* a, int first, int hole, int len, int value) {
+FT8_HD void osd_ss_adjust_heap(const float* x, int* a, int first, int hole, int len, int value) {
     const int top = hole; int child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
@@ -100,7 +101,7 @@ FT8_DEV void osd_ss_adjust_heap(const float* x, int* a, int first, int hole, int
     while (hole > top && osd_nl(x, a[first + parent], value)) { a[first + hole] = a[first + parent]; hole = parent; parent = (hole - 1) / 2; }
     a[first + hole] = value;
 }
-FT8_DEV void osd_std_sort_withnan(const float* x, int* a, int* stack /* [3 * 20] */) {
+FT8_HD void osd_std_sort_withnan(const float* x, int* a, int* stack /* [3 * 20] */) {
     const int n = 174;
     for (int i = 0; i < n; i++) a[i] = i;
     int sp = 0;
@@ -139,6 +140,11 @@ FT8_DEV void osd_std_sort_withnan(const float* x, int* a, int* stack /* [3 * 20]
     osd_ss_insertion(x, a, 0, 16);                                      // __final_insertion_sort, n > 16
     for (int i = 16; i < n; i++) osd_ss_linear_insert(x, a, i);
 }
+
+#undef FT8_HD
+// the order std::sort leaves an ALL-NaN vector in (the comparator is then always false: a fixed permutation; ft8rx_create fills it by
+// running the routine above on the host): the common NaN case -- a NaN-poisoned BP output is NaN everywhere -- stays in the main kernel
+__device__ uint8_t d_NANPERM[192];
 
 #define OSD_MAXFLIP 91            /* flip rows kept per attempt = all 91 basis positions (decoders.py:244-246 takes any count up to the basis size) */
 #define OSD_FLIPS_A 62            /* flips 0..61: one bit each in the column's 64-bit word (bit 63 = order-0 codeword bit); flips 62..90: a second, 32-bit word
@@ -205,16 +211,19 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
         hk[q] = (i < 174) ? 0xFFFFFFFEu - mag : 0xFFFFFFFFu;
         ix[q] = (i < 174) ? (uint32_t)i : 0u;
     }
-    const bool any_nan = __ballot((hk[0] < 0x807FFFFEu) || (hk[1] < 0x807FFFFEu) || (lane < 46 && hk[2] < 0x807FFFFEu)) != 0;      // magnitude bits above infinity's
+    const uint64_t nan0 = __ballot(hk[0] < 0x807FFFFEu), nan1 = __ballot(hk[1] < 0x807FFFFEu), nan2 = __ballot(lane < 46 && hk[2] < 0x807FFFFEu);      // magnitude bits above infinity's
+    const bool any_nan = (nan0 | nan1 | nan2) != 0, all_nan = (nan0 & nan1) == ~0ull && nan2 == (1ull << 46) - 1;
     OT(0);
 #ifndef OSD_TIMING_SKIP_SORT            /* timing-only builds (tools/ab_variants.sh): never defined in the product */
     if (NANV) {                                               // the library's std::sort path, one lane (k_osd_nan)
-        if (!any_nan) return;                                 // (never: the list only holds such attempts)
+        if (!any_nan || all_nan) return;                      // (never: the list only holds vectors with some, not only, NaNs)
         int* ordl = reinterpret_cast<int*>(skey);             // [174] the order, then [60] the range stack (skey is not in use yet)
         if (lane == 0) osd_std_sort_withnan(llr, ordl, ordl + 176);
         __syncthreads();
         ix[0] = (uint32_t)ordl[lane]; ix[1] = (uint32_t)ordl[64 + lane]; ix[2] = (uint32_t)ordl[128 + (lane < 46 ? lane : 0)];
         __syncthreads();
+    } else if (all_nan) {                                     // std::sort of 174 NaNs: a fixed permutation
+        ix[0] = d_NANPERM[lane]; ix[1] = d_NANPERM[64 + lane]; ix[2] = d_NANPERM[128 + lane];
     } else if (any_nan) {                                     // wave-uniform, rare: left to the NaN kernel
         if (lane == 0) work_push(nanlist, bid);
         return;
