@@ -5,8 +5,11 @@ repository: it decodes N never-seen synthetic frames (varied signal counts, SNR 
 reference (oracle/ref_harness.py, ~3 s per frame) and with the oracle and requires identical candidate lists, message
 lists in emit order, SNR/dt/frequency strings, decode notes and the complete unpack() call sequence.
 
-It needs /root/reference and costs minutes, so it only runs on request:
-    PYFT8_REF_CROSSCHECK=24 python -m pytest tests/test_reference_crosscheck.py -q -m ref
+It needs /root/reference (~3 s per frame).  A fixed subset of eight frames -- four recipes at Receiver defaults / non-default kwargs
+and four with time windows far beyond the default, where symbols are read clamped -- runs whenever the reference is present
+(test_default_subset: part of the plain CPU suite in the build container, skipped on a box without /root/reference); the large runs
+are on request:
+    PYFT8_REF_CROSSCHECK=1000 PYFT8_REF_LOG=lines.txt python -m pytest tests/test_reference_crosscheck.py -q -m ref -n 7
 """
 import os
 import sys
@@ -28,7 +31,7 @@ def say(msg):
             f.write(msg + "\n")
 
 
-pytestmark = [pytest.mark.ref, pytest.mark.skipif(not (N and HAVE_REF), reason="set PYFT8_REF_CROSSCHECK=<n frames>; needs /root/reference")]
+needs_ref = pytest.mark.skipif(not HAVE_REF, reason="needs /root/reference (build container only)")
 
 RECIPES = [dict(n_signals=50, snr_range=(-10.0, 10.0)), dict(n_signals=30, snr_range=(-20.0, 0.0)), dict(n_signals=8, snr_range=(-24.0, -12.0)),
            dict(n_signals=70, snr_range=(-5.0, 15.0)), dict(n_signals=1, snr_range=(0.0, 5.0)), dict(n_signals=0)]
@@ -44,15 +47,33 @@ if os.environ.get("PYFT8_REF_CROSSCHECK_TIME"):          # wide time windows: ca
     KWARGS = [dict(search_time_range=[-6.0, 3.0], sync_score_min=70), dict(search_time_range=[-1.0, 8.2], sync_score_min=70),
               dict(search_time_range=[-5.0, 1.0]), dict(search_time_range=[2.0, 8.0], sync_score_min=60, max_cands=256)]
     BASE = 7600000
+TIME_KWARGS = [dict(search_time_range=[-6.0, 3.0], sync_score_min=70), dict(search_time_range=[-1.0, 8.2], sync_score_min=70),
+               dict(search_time_range=[-5.0, 1.0]), dict(search_time_range=[2.0, 8.0], sync_score_min=60, max_cands=256)]
 
 
+@pytest.mark.ref
 @pytest.mark.parametrize("k", range(N))
+@pytest.mark.skipif(not (N and HAVE_REF), reason="set PYFT8_REF_CROSSCHECK=<n frames>; needs /root/reference")
 def test_oracle_equals_reference_on_fresh_frame(k):
+    crosscheck_frame(k, RECIPES[k % len(RECIPES)], KWARGS[k % len(KWARGS)], BASE)
+
+
+@needs_ref
+@pytest.mark.parametrize("which,k", [("std", 0), ("std", 1), ("std", 3), ("std", 9), ("time", 0), ("time", 1), ("time", 2), ("time", 3)])
+def test_default_subset(which, k):
+    """Not env-gated: a future edit of the arithmetic contract cannot drift from receiver.py:140-206 / decoders.py:223-272
+    unnoticed -- every run of the CPU suite in the build container decodes these eight frames with the real reference."""
+    if which == "std":
+        crosscheck_frame(k, RECIPES[k % 6], [dict(), dict(), dict(), dict(sync_score_min=100, max_cands=150), dict(search_freq_range=[300, 2500], search_time_range=[-1.0, 2.0])][k % 5], 7000000)
+    else:
+        crosscheck_frame(k, RECIPES[k % 6] if "freq_range" not in RECIPES[0] else dict(n_signals=50, snr_range=(-10.0, 10.0)), TIME_KWARGS[k % 4], 7600000)
+
+
+def crosscheck_frame(k, recipe, kw, BASE):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     from ref_harness import run_frame
     from pyft8_amd import synth
     from pyft8_amd.receiver import config_from_kwargs
-    recipe, kw = RECIPES[k % len(RECIPES)], KWARGS[k % len(KWARGS)]
     audio = synth.make_frame(BASE + k, **recipe)
     cands, tr, rx = run_frame(audio, **kw)
     cfg = config_from_kwargs(**kw)
@@ -144,6 +165,8 @@ def test_oracle_equals_reference_on_fresh_frame(k):
     assert len(diff) <= 4
 
 
+@pytest.mark.ref
+@pytest.mark.skipif(not (N and HAVE_REF), reason="set PYFT8_REF_CROSSCHECK=<n frames>; needs /root/reference")
 @pytest.mark.parametrize("name", ["silence", "tone", "nyquist", "dc", "impulse", "burst", "half"])
 def test_oracle_equals_reference_on_degenerate_input(name):
     """Digital silence, a pure tone on a bin centre, full-scale Nyquist, DC, a single impulse, one clipped hop in noise, audio that
@@ -170,6 +193,8 @@ def test_oracle_equals_reference_on_degenerate_input(name):
     assert r["n_events"] == len(tr.unpack_calls)
 
 
+@pytest.mark.ref
+@pytest.mark.skipif(not (N and HAVE_REF), reason="set PYFT8_REF_CROSSCHECK=<n frames>; needs /root/reference")
 @pytest.mark.parametrize("k", [0, 1])
 def test_oracle_equals_reference_on_special_message_types(k):
     """The frames of test_gpu_parity.test_special_message_types_through_the_pipeline decoded by the real reference: same messages in
