@@ -411,8 +411,9 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
                             float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
     __shared__ cpx z[3200];
     __shared__ cpx slice[FINE_SLICE];  // the candidate's 1064 spectrum bins, read by the first stage of all ten IFFTs
-    __shared__ __attribute__((aligned(8))) float mg[640];   // scoring (on, off) sums as fp64, later the [79][8] grid
-    __shared__ cpx w400[400];          // W3200[8 t]: every twiddle of the [4,4] stage
+    __shared__ cpx w400[400];          // W3200[8 t]: every twiddle of the [4,4] stage of the ONE transform (the time scan's); dead after it, then
+    float* mg = reinterpret_cast<float*>(w400);      // [640] scoring (on, off) sums as fp64, later the [79][8] grid -- first written after that transform
+    static_assert(sizeof(cpx) * 400 >= sizeof(float) * 640, "mg overlays w400");
     float* p = reinterpret_cast<float*>(slice);      // [464] the slice is dead once the last IFFT has run: reuse it
     float* llr = p + 464;                            // [176]
     float* sq = llr + 176;                           // [176]

@@ -24,10 +24,16 @@ __device__ unsigned long long g_osd_t[32768][10];       // per block: plain adds
 #define OT_DECL unsigned long long ot_prev = __builtin_readcyclecounter();
 #define OT(i) do { const unsigned long long ot_now = __builtin_readcyclecounter(); if (lane == 0) g_osd_t[blockIdx.x & 32767][i] += ot_now - ot_prev; ot_prev = __builtin_readcyclecounter(); } while (0)
 #define OT_FLUSH do { if (lane == 0) g_osd_t[blockIdx.x & 32767][9] += 1ull; } while (0)
+#ifdef OSD_COUNT_VISITS
+#define OT_VISIT do { if (lane == 0) g_osd_t[blockIdx.x & 32767][8] += 1ull; } while (0)      /* one visited column (its own build: the store costs every visit) */
+#else
+#define OT_VISIT do { } while (0)
+#endif
 #else
 #define OT_DECL
 #define OT(i) do { } while (0)
 #define OT_FLUSH do { } while (0)
+#define OT_VISIT do { } while (0)
 #endif
 // ---- np.argsort's compare-exchange network (oracle/ft8_oracle.c: ft8o_argsort_f32 has the derivation and the library references).
 // 256 wires = 32 registers of 8 lanes in the library; here wire w = 64 q + lane sits in register q of the lane.  Every stage pairs wire w
@@ -272,8 +278,102 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
 #ifdef OSD_TIMING_SKIP_ELIM
     k = 91;
 #endif
+#ifndef OSD_VISIT_ALL                /* -DOSD_VISIT_ALL: the round-4 loop (every position visited), for the A/B of tools/ab_variants.sh */
+    // SYSTEMATIC COLUMNS ARE NOT VISITED (round 5).  Column v < 91 of G0 = [I | A^T] is the unit vector e_v, and it stays e_v until some
+    // pivot takes row v (an elimination only touches columns with a 1 in the pivot row).  Reached with row v free it is accepted with
+    // pivot v and changes nothing -- about half of the ~105 visited positions, each costing the full broadcast / test / lock round on
+    // the scalar pipe, the kernel's bottleneck.  So: the systematic columns at positions < OSD_TRIV ("trivial") are accepted without a
+    // visit, the loop walks the other positions only (a bit mask per register set, find-first-set), and the free choice of the pivot
+    // row keeps them trivial: a visited column takes its pivot among the rows that do NOT belong to a trivial column (lockU = locked or
+    // reserved) -- there are as many such rows as pivots needed, up to the few positions the basis ends before or after OSD_TRIV.
+    // Only a column with no 1 left there STEALS: among its 1s in rows of trivial columns positioned AFTER it (a trivial column before
+    // it has been accepted: its row is locked) it takes the lowest, and the robbed column -- no longer a unit vector -- goes back
+    // onto the visit list.  The basis is complete when visited accepts + trivial positions passed reach 91 (tcN: the number of
+    // trivial positions before a lane).  Same information set as the plain loop, position for position (tests: info set == oracle's).
+#define OSD_TRIV 96
+    int* posrow = reinterpret_cast<int*>(skey);               // [96] position of systematic column v (skey is idle until the flip rows)
+    if (ord0 < 91) posrow[ord0] = lane;
+    if (ord1 < 91) posrow[ord1] = 64 + lane;
+    if (has2 && ord2 < 91) posrow[ord2] = 128 + lane;
+    uint64_t triv0 = __ballot(ord0 < 91), triv1 = __ballot(ord1 < 91 && lane < OSD_TRIV - 64);
+    int tc0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(triv0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)triv0, 0));
+    int tc1 = __popcll(triv0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(triv1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)triv1, 0));
+    int ntriv = __popcll(triv0) + __popcll(triv1);
+    __syncthreads();
+    // rows reserved for trivial columns: bit r = systematic column r sits at a position < OSD_TRIV
+    const uint64_t u01 = __ballot(posrow[lane] < OSD_TRIV);
+    const uint32_t u2 = (uint32_t)__ballot(lane < 27 && posrow[64 + (lane < 27 ? lane : 0)] < OSD_TRIV);
+    uint64_t lockU01 = u01; uint32_t lockU2 = lock2 | u2;      // locked by a pivot, or reserved for a trivial column
+    uint64_t vis0 = ~triv0, vis1 = ~triv1, vis2 = (1ull << 46) - 1;
+    // One visit = one straight path, integers only on the scalar side (a boolean that lives across a branch becomes a lane mask and
+    // drags selects onto the vector pipe).  Both pipes are close to their ceilings in this loop -- eight waves x (SALU + VALU per visit)
+    // x 4 cycles is what a round of visits takes (profiles/r05_notes.md) -- so the visit is counted in instructions:
+    //   * every visit marks its position accepted and counts it (ACC, k) without a test; the rare paths take that back: the steal
+    //     branch only replaces the eligible rows (a01, a2), and a dependent column (no eligible row at all) clears its mark, uncounts
+    //     itself and runs the rest with an empty pivot b = 0 -- no column "has a 1 in row b", the update mask is zero everywhere;
+    //   * the locked rows exist once (lockU = pivots taken + rows reserved for trivial columns); the steal branch works out which
+    //     reserved rows are up for grabs from posrow and the trivial masks;
+    //   * the update: "a 1 in the pivot row" as an all-ones / zero mask (an AND, two v_and_or, a compare, a select), then (mask & m) ^ x
+    //     per word -- one v_bitop3 each on gfx950;
+    //   * columns at positions already passed never change again (an accepted one is a unit vector at a locked row, a rejected one has
+    //     all its 1s in rows that were locked when it was visited, and a pivot row is an unlocked row): while register set 1 is
+    //     walked, set 0 is left alone; while set 2 is walked, sets 0 and 1.
+    // TCV: trivial positions before a lane of this register set; BASE: its first position; VIS: its visit mask.  When the basis is
+    // complete every visit mask is emptied, which ends this loop and skips the ones that follow.
+#define OSD_UPD(X0, X1, X2) { uint32_t mk = (((X0 & blo) | (X1 & bhi) | (X2 & b2)) != 0u) ? ~0u : 0u; asm volatile("" : "+v"(mk)); \
+                              X0 ^= mk & m0; X1 ^= mk & m1; X2 ^= mk & m2; }
+#define OSD_STEP(XA, XB, XC, ACC, VIS, TCV, BASE, UPDATES)                                                                         \
+    while (VIS != 0) {                                                                                                             \
+        const int il = __builtin_ctzll(VIS);                                                                                       \
+        OT_VISIT;                                                                                                                  \
+        if (k + __builtin_amdgcn_readlane(TCV, il) >= 91) { vis0 = 0; vis1 = 0; vis2 = 0; continue; }      /* completed by a trivial column before this one */ \
+        const uint64_t bit = 1ull << il;                                                                                           \
+        VIS &= ~bit; ACC |= bit; k++;                                                                                              \
+        const uint32_t c0 = __builtin_amdgcn_readlane(XA, il), c1 = __builtin_amdgcn_readlane(XB, il), c2 = __builtin_amdgcn_readlane(XC, il); \
+        const uint64_t c01 = ((uint64_t)c1 << 32) | c0;                                                                            \
+        uint64_t a01 = c01 & ~lockU01; uint32_t a2 = c2 & ~lockU2;                                                                 \
+        if (__builtin_expect(!(a01 | a2), 0)) {                /* rare: nothing outside the locked and reserved rows -- steal, or dependent */ \
+            const int p = (BASE) + il;                                                                                             \
+            /* rows of columns that are still trivial and come after this position (lane = row; a robbed column's row is a pivot's) */ \
+            const int pa = posrow[lane], pb = posrow[64 + (lane < 27 ? lane : 0)];                                                 \
+            const bool ta = pa > p && pa < OSD_TRIV && (((pa < 64 ? triv0 >> pa : triv1 >> (pa - 64)) & 1ull) != 0);               \
+            const bool tb = lane < 27 && pb > p && pb < OSD_TRIV && (((pb < 64 ? triv0 >> pb : triv1 >> (pb - 64)) & 1ull) != 0);  \
+            a01 = c01 & __ballot(ta); a2 = c2 & (uint32_t)__ballot(tb);                                                            \
+            if (a01 | a2) {                                                                                                        \
+                const int r = a01 ? __builtin_ctzll(a01) : 64 + __builtin_ctz(a2);                                                 \
+                const int q = __builtin_amdgcn_readfirstlane(posrow[r]);   /* the robbed trivial column: visited like any other from now on */ \
+                if (q < 64) { triv0 &= ~(1ull << q); vis0 |= 1ull << q; tc0 -= (lane > q) ? 1 : 0; tc1 -= 1; }                    \
+                else { triv1 &= ~(1ull << (q - 64)); vis1 |= 1ull << (q - 64); tc1 -= (lane > q - 64) ? 1 : 0; }                   \
+                ntriv--;                                                                                                           \
+            } else { ACC &= ~bit; k--; }                       /* dependent on the accepted columns */                             \
+        }                                                                                                                          \
+        {   /* the accept step: pivot = the lowest eligible row, clear the column's other 1s everywhere, lock the row */            \
+            asm volatile("" : "+s"(a2));                       /* opaque: nothing about the branch above is threaded into the code below */ \
+            const uint64_t b01 = a01 & (0 - a01);                                                                                  \
+            const uint32_t b2 = a01 ? 0u : (a2 & (0u - a2));                                                                       \
+            const uint32_t blo = (uint32_t)b01, bhi = (uint32_t)(b01 >> 32);                                                       \
+            const uint32_t m0 = c0 & ~blo, m1 = c1 & ~bhi, m2 = c2 & ~b2;                                                          \
+            UPDATES                                                                                                                \
+            lockU01 |= b01; lockU2 |= b2;                                                                                          \
+        }                                                                                                                          \
+    }
+    OT(2);
+    OSD_STEP(x00, x01, x02, acc0, vis0, tc0, 0, OSD_UPD(x00, x01, x02) OSD_UPD(x10, x11, x12) OSD_UPD(x20, x21, x22))
+    OSD_STEP(x10, x11, x12, acc1, vis1, tc1, 64, OSD_UPD(x10, x11, x12) OSD_UPD(x20, x21, x22))
+    {
+        int tc2 = ntriv;                                      // every trivial position lies before register set 2
+        OSD_STEP(x20, x21, x22, acc2, vis2, tc2, 128, OSD_UPD(x20, x21, x22))
+    }
+#undef OSD_STEP
+#undef OSD_UPD
+    // the trivial columns of the basis: the first 91 - k of them
+    acc0 |= __ballot(((triv0 >> lane) & 1ull) && tc0 < 91 - k);
+    acc1 |= __ballot(((triv1 >> lane) & 1ull) && tc1 < 91 - k);
+    __syncthreads();                                          // posrow (in skey) is done with: the flip rows overlay it below
+#else
 #define OSD_STEP(XA, XB, XC, ACC, IL)                                                                                              \
     {                                                                                                                              \
+        OT_VISIT;                                                                                                                  \
         const uint32_t c0 = __builtin_amdgcn_readlane(XA, IL), c1 = __builtin_amdgcn_readlane(XB, IL), c2 = __builtin_amdgcn_readlane(XC, IL); \
         const uint64_t c01 = ((uint64_t)c1 << 32) | c0;                                                                            \
         const uint64_t a01 = c01 & ~lock01; const uint32_t a2 = c2 & ~lock2;                                                       \
@@ -302,6 +402,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     OSD_RUN(x20, x21, x22, acc2, 46)
 #undef OSD_RUN
 #undef OSD_STEP
+#endif
     OT(3);
     // Every accepted column is now a unit vector (its pivot row).  Acceptance order = position order, so the accepted column at
     // position p is the kk-th accepted one with kk = number of accepted positions before p.

@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyft8_amd import _lib  # noqa: E402
 
-NAMES = ["LLR loads, AP override, sort keys", "bitonic sort (36 steps, keys in registers)", "generator columns in sorted order (d_G0T loads), hard decisions",
+NAMES = ["LLR loads, AP override, sort keys", "np.argsort network (36 stages, keys in registers)", "generator columns in sorted order (d_G0T loads), hard decisions",
          "Gauss-Jordan: visited columns until 91 are accepted", "flip rows published, hard-decision mask", "per-column flip words (nflip broadcast reads), un-permutation",
          "CRC syndromes of the order-0 codeword and the flips", "trials (+ slow path of zero-syndrome trials), result"]
 
@@ -35,6 +35,7 @@ def main():
     print(f"k_osd, {B} frames: {n} attempts that ran; shader cycles of lane 0 summed over all attempts (share; cycles per attempt)")
     for i, nm in enumerate(NAMES):
         print(f"  {i} {nm:<90s} {int(out[i]):>16,d}  {100 * out[i] / tot:5.1f} %  {out[i] / max(n, 1):9.0f}")
+    print(f"  visited columns per attempt: {out[8] / max(n, 1):.1f}")
     h.close()
 
 
