@@ -51,17 +51,45 @@ template <int M> FT8_DEV uint32_t osd_px(uint32_t v, int lane) {
     if (M == 4 || M == 16 || M == 31) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (M << 10));   // bit mode: lane ^ M within 32
     return __shfl(v, lane ^ M);
 }
-// one stage between lanes M apart on NQ registers of (key, index) pairs
+// One stage between lanes M apart on NQ registers of (key, index) pairs.  The sort is a fifth of the attempt's vector instructions and the
+// kernel is bound by their number, so a register-stage is written out: both orders of the pair (min, max), the lane's side picked with a
+// constant lane mask (a scalar operand), "the key changed" = "take the partner's index" -- 5 vector instructions where the compare-and-
+// select form compiled to ~14.  For the strides a DPP control reaches (1, 2, 3, 7, 15, 8) the partner is read as a DPP operand of v_min /
+// v_max / v_cndmask themselves (inline assembly: the compiler only fuses a DPP move into a single user).  Hazards the assembler does not
+// see inside an asm block: VALU writes VCC -> VALU reads VCC needs two wait states on gfx950 (the s_nop below); a DPP read of a VGPR needs
+// two wait states after the VALU write -- the blocks of the other register sets (or of the previous stage) lie in between.
+#define OSD_LOWMASK(top) ((top) == 1 ? 0x5555555555555555ull : (top) == 2 ? 0x3333333333333333ull : (top) == 4 ? 0x0F0F0F0F0F0F0F0Full : \
+                          (top) == 8 ? 0x00FF00FF00FF00FFull : (top) == 16 ? 0x0000FFFF0000FFFFull : 0x00000000FFFFFFFFull)
+#define OSD_DPP_STAGE(CTRL)                                                                                                          \
+    asm volatile("v_min_u32_dpp %[mn], %[hk], %[hk] " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                         \
+                 "v_max_u32_dpp %[mx], %[hk], %[hk] " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                         \
+                 "v_cndmask_b32 %[mn], %[mx], %[mn], %[low]\n\t"                                                                    \
+                 "v_cmp_eq_u32 vcc, %[mn], %[hk]\n\t"                                                                                \
+                 "s_nop 1\n\t"                                                                                                       \
+                 "v_cndmask_b32_dpp %[ix], %[ix], %[ix], vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 : [mn] "=&v"(mn), [mx] "=&v"(mx), [ix] "+v"(ix[q]) : [hk] "v"(hk[q]), [low] "s"(low) : "vcc");
 template <int M, int NQ> FT8_DEV void osd_stage(uint32_t* hk, uint32_t* ix, int lane) {
     constexpr int top = M >= 32 ? 32 : M >= 16 ? 16 : M >= 8 ? 8 : M >= 4 ? 4 : M >= 2 ? 2 : 1;      // highest bit of M: clear on the lower wire
-    const bool lower = (lane & top) == 0;
+    const uint64_t low = OSD_LOWMASK(top);                     // lanes that hold the lower wire of their pair
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const uint32_t pk = osd_px<M>(hk[q], lane), pi = osd_px<M>(ix[q], lane);
-        const bool take = lower ? (hk[q] > pk) : (hk[q] < pk);
-        hk[q] = take ? pk : hk[q]; ix[q] = take ? pi : ix[q];
+        uint32_t mn, mx;
+        if constexpr (M == 1) { OSD_DPP_STAGE("quad_perm:[1,0,3,2]") }
+        else if constexpr (M == 2) { OSD_DPP_STAGE("quad_perm:[2,3,0,1]") }
+        else if constexpr (M == 3) { OSD_DPP_STAGE("quad_perm:[3,2,1,0]") }
+        else if constexpr (M == 7) { OSD_DPP_STAGE("row_half_mirror") }
+        else if constexpr (M == 15) { OSD_DPP_STAGE("row_mirror") }
+        else if constexpr (M == 8) { OSD_DPP_STAGE("row_ror:8") }
+        else {
+            const uint32_t pk = osd_px<M>(hk[q], lane), pi = osd_px<M>(ix[q], lane);
+            mn = pk < hk[q] ? pk : hk[q]; mx = pk < hk[q] ? hk[q] : pk;
+            asm("v_cndmask_b32 %0, %1, %0, %2" : "+v"(mn) : "v"(mx), "s"(low));      // lower wire: the minimum
+            ix[q] = (mn == hk[q]) ? ix[q] : pi;
+        }
+        hk[q] = mn;
     }
 }
+#undef OSD_DPP_STAGE
 template <int NQ> FT8_DEV void osd_stages_421(uint32_t* hk, uint32_t* ix, int lane) {
     osd_stage<4, NQ>(hk, ix, lane); osd_stage<2, NQ>(hk, ix, lane); osd_stage<1, NQ>(hk, ix, lane);
 }
@@ -69,11 +97,10 @@ template <int NQ> FT8_DEV void osd_stages_421(uint32_t* hk, uint32_t* ix, int la
 template <bool REV> FT8_DEV void osd_stage_regs(uint32_t& ka, uint32_t& ia, uint32_t& kb, uint32_t& ib, int lane) {
     const uint32_t pkb = REV ? __shfl(kb, 63 - lane) : kb, pib = REV ? __shfl(ib, 63 - lane) : ib;      // what a's lane faces
     const uint32_t pka = REV ? __shfl(ka, 63 - lane) : ka, pia = REV ? __shfl(ia, 63 - lane) : ia;      // what b's lane faces
-    const bool ta = ka > pkb, tb = kb < pka;
-    ka = ta ? pkb : ka; ia = ta ? pib : ia;
-    kb = tb ? pka : kb; ib = tb ? pia : ib;
+    const uint32_t na = pkb < ka ? pkb : ka, nb = pka > kb ? pka : kb;                                   // a keeps the minimum, b the maximum
+    ia = (na == ka) ? ia : pib; ib = (nb == kb) ? ib : pia;
+    ka = na; kb = nb;
 }
-
 // ---- the library's path for a vector that contains a NaN (std_argsort_withnan): libstdc++'s std::sort of the index array with the
 // comparator "both not NaN: a < b; a NaN: false; else true" on the keys -|llr|.  One lane, in LDS; rare (a NaN-poisoned BP output,
 // decoders.py:143-147).  Function for function as in oracle/ft8_oracle.c (std_sort_withnan), with the recursion on the right part
@@ -182,7 +209,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     __shared__ uint64_t ftab[192];                         // per column (natural order): bit i = flip i covers it (i < 62), bit 63 = order-0 codeword bit
     // the sort keys are dead once the reliability order has been read into registers; their 2 KB then hold
     uint32_t* ftabB = reinterpret_cast<uint32_t*>(skey);  // [192] bit i - 62 = flip i covers it (62 <= i < 91), and
-    uint32_t* frow = ftabB + 192;                          // [3 (OSD_MAXFLIP + 1)] unit vectors of the flip columns (their pivot rows)
+    uint32_t* frow = ftabB + 192;                          // [OSD_MAXFLIP] pivot rows of the flip columns (row indices)
     static_assert((192 + 3 * (OSD_MAXFLIP + 1)) * sizeof(uint32_t) <= 256 * sizeof(uint64_t), "ftabB + frow overlay the sort keys");
     constexpr bool wide = WIDE;                            // nflip > OSD_FLIPS_A (the launcher picks the kernel)
     const int nflipA = wide ? OSD_FLIPS_A : nflip;
@@ -411,16 +438,14 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     const int kk0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(acc0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acc0, 0));
     const int kk1 = n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(acc1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acc1, 0));
     const int kk2 = n0 + n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(acc2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acc2, 0));
-    // flip i = the row locked by accepted column 90 - i (least reliable basis members first): that column's lane publishes its unit vector
-    if (lane < 3 * (OSD_MAXFLIP + 1)) frow[lane] = 0u;
-    if (64 + lane < 3 * (OSD_MAXFLIP + 1)) frow[64 + lane] = 0u;
-    if (128 + lane < 3 * (OSD_MAXFLIP + 1)) frow[128 + lane] = 0u;
-    if (192 + lane < 3 * (OSD_MAXFLIP + 1)) frow[192 + lane] = 0u;
-    if (256 + lane < 3 * (OSD_MAXFLIP + 1)) frow[256 + lane] = 0u;
-    __syncthreads();
-    { const int i = 90 - kk0; if (in0 && i >= 0 && i < nflip) { frow[3 * i] = x00; frow[3 * i + 1] = x01; frow[3 * i + 2] = x02; } }
-    { const int i = 90 - kk1; if (in1 && i >= 0 && i < nflip) { frow[3 * i] = x10; frow[3 * i + 1] = x11; frow[3 * i + 2] = x12; } }
-    { const int i = 90 - kk2; if (in2 && i >= 0 && i < nflip) { frow[3 * i] = x20; frow[3 * i + 1] = x21; frow[3 * i + 2] = x22; } }
+    // flip i = the row locked by accepted column 90 - i (least reliable basis members first): that column's lane publishes the INDEX of its
+    // pivot row (its column is the unit vector of that row); all 91 basis members exist, so every flip i < nflip <= 91 gets its entry
+    int* fri = reinterpret_cast<int*>(frow);                   // [OSD_MAXFLIP] pivot row of flip i
+#define OSD_ROWIDX(X0, X1, X2) ((X0) ? __builtin_ctz(X0) : (X1) ? 32 + __builtin_ctz(X1) : 64 + __builtin_ctz((X2) | 0x80000000u))
+    { const int i = 90 - kk0; if (in0 && i >= 0 && i < nflip) fri[i] = OSD_ROWIDX(x00, x01, x02); }
+    { const int i = 90 - kk1; if (in1 && i >= 0 && i < nflip) fri[i] = OSD_ROWIDX(x10, x11, x12); }
+    { const int i = 90 - kk2; if (in2 && i >= 0 && i < nflip) fri[i] = OSD_ROWIDX(x20, x21, x22); }
+#undef OSD_ROWIDX
     // hm = rows whose accepted column has hard decision 1 (OR of those unit vectors): order-0 codeword bit of a column = parity(column & hm)
     if (lane < 3) hmw[lane] = 0u;
     __syncthreads();
@@ -436,27 +461,35 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     const uint32_t hm0 = hmw[0], hm1 = hmw[1], hm2 = hmw[2];
     OT(4);
     // per column: bit i = flip i has a 1 in this column (i < 62), bit 63 = the order-0 codeword bit
-    uint64_t f0 = (uint64_t)((__popc(x00 & hm0) + __popc(x01 & hm1) + __popc(x02 & hm2)) & 1) << 63,
-             f1 = (uint64_t)((__popc(x10 & hm0) + __popc(x11 & hm1) + __popc(x12 & hm2)) & 1) << 63,
-             f2 = (uint64_t)((__popc(x20 & hm0) + __popc(x21 & hm1) + __popc(x22 & hm2)) & 1) << 63;
-    for (int i = 0; i < nflipA; i++) {
-        const uint32_t r0 = frow[3 * i], r1 = frow[3 * i + 1], r2 = frow[3 * i + 2];      // broadcast reads (a unit vector, or 0 if absent)
-        f0 |= (uint64_t)(((x00 & r0) | (x01 & r1) | (x02 & r2)) != 0) << i;
-        f1 |= (uint64_t)(((x10 & r0) | (x11 & r1) | (x12 & r2)) != 0) << i;
-        f2 |= (uint64_t)(((x20 & r0) | (x21 & r1) | (x22 & r2)) != 0) << i;
+    // Flip i's row is one bit position of the 91-bit column: its index is read as a SCALAR (a broadcast LDS read), the word it lies in
+    // is a uniform three-way branch, and a column's flip bit costs a v_bfe_u32 and a v_lshl_or_b32 -- 6 vector instructions per flip
+    // for the three register sets (the generic "column AND unit vector != 0" form: ~30; this loop was 900 of the ~5800 vector
+    // instructions of an attempt, and the kernel is bound by their number: profiles/r05_notes.md).
+    uint32_t f0l = 0, f1l = 0, f2l = 0;
+    uint32_t f0h = (uint32_t)((__popc(x00 & hm0) + __popc(x01 & hm1) + __popc(x02 & hm2)) & 1) << 31,
+             f1h = (uint32_t)((__popc(x10 & hm0) + __popc(x11 & hm1) + __popc(x12 & hm2)) & 1) << 31,
+             f2h = (uint32_t)((__popc(x20 & hm0) + __popc(x21 & hm1) + __popc(x22 & hm2)) & 1) << 31;
+#define OSD_FBIT(XA, XB, XC, FA, FB, FC, SH) { FA |= __builtin_amdgcn_ubfe(XA, bp, 1u) << (SH); FB |= __builtin_amdgcn_ubfe(XB, bp, 1u) << (SH); \
+                                               FC |= __builtin_amdgcn_ubfe(XC, bp, 1u) << (SH); }
+#define OSD_FLIPS(LO, HI, FA, FB, FC, SUB)                                                                                         \
+    for (int i = (LO); i < (HI); i++) {                                                                                            \
+        const int r = __builtin_amdgcn_readfirstlane(fri[i]);                                                                      \
+        const uint32_t bp = (uint32_t)r & 31u, sh = (uint32_t)(i - (SUB));                                                         \
+        if (r < 32) OSD_FBIT(x00, x10, x20, FA, FB, FC, sh)                                                                        \
+        else if (r < 64) OSD_FBIT(x01, x11, x21, FA, FB, FC, sh)                                                                   \
+        else OSD_FBIT(x02, x12, x22, FA, FB, FC, sh)                                                                               \
     }
-    // back to natural column order: ftab[column]
-    ftab[ord0] = f0; ftab[ord1] = f1; if (has2) ftab[ord2] = f2;
+    OSD_FLIPS(0, nflipA < 32 ? nflipA : 32, f0l, f1l, f2l, 0)
+    OSD_FLIPS(32, nflipA, f0h, f1h, f2h, 32)
+    // back to natural column order: ftab[column] (bit i = flip i has a 1 in this column, i < 62; bit 63 = the order-0 codeword bit)
+    ftab[ord0] = ((uint64_t)f0h << 32) | f0l; ftab[ord1] = ((uint64_t)f1h << 32) | f1l; if (has2) ftab[ord2] = ((uint64_t)f2h << 32) | f2l;
     if (wide) {                                            // flips 62 .. nflip - 1 into the second word
         uint32_t g0 = 0, g1 = 0, g2 = 0;
-        for (int i = OSD_FLIPS_A; i < nflip; i++) {
-            const uint32_t r0 = frow[3 * i], r1 = frow[3 * i + 1], r2 = frow[3 * i + 2];
-            g0 |= (uint32_t)(((x00 & r0) | (x01 & r1) | (x02 & r2)) != 0) << (i - OSD_FLIPS_A);
-            g1 |= (uint32_t)(((x10 & r0) | (x11 & r1) | (x12 & r2)) != 0) << (i - OSD_FLIPS_A);
-            g2 |= (uint32_t)(((x20 & r0) | (x21 & r1) | (x22 & r2)) != 0) << (i - OSD_FLIPS_A);
-        }
+        OSD_FLIPS(OSD_FLIPS_A, nflip, g0, g1, g2, OSD_FLIPS_A)
         ftabB[ord0] = g0; ftabB[ord1] = g1; if (has2) ftabB[ord2] = g2;
     }
+#undef OSD_FLIPS
+#undef OSD_FBIT
     __syncthreads();
     OT(5);
     // CRC syndromes (the CRC is linear): lane i < min(nflip, 62) takes flip i, lane 63 the order-0 codeword (flips 62.. in a second round).  The lane gathers its word as a
