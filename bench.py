@@ -65,6 +65,69 @@ PMC_PROFILES = {1: os.path.join(ROOT, "profiles", "pmc_latest.json"), 2: os.path
                 3: os.path.join(ROOT, "profiles", "pmc_config3_latest.json"), 4: os.path.join(ROOT, "profiles", "pmc_config4_latest.json")}
 
 
+SQ_PROFILE = os.path.join(ROOT, "profiles", "sq_latest.json")      # rocprofv3 --pmc SQ_* passes of `bench.py --streams 1 --subbatch 0` (tools/pmc_sq.sh)
+# vector-instruction issue ceiling: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD (a SIMD executes 32 lanes of a
+# plain fp32 / int32 operation per cycle: tools/ubench/valu_rate.hip, profiles/r02_valu_rate.txt), 2.4 GHz
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
+STAGE_KERNELS = {"spectrogram": ["k_spectrogram"], "sync": ["k_sync"], "topk": ["k_topk"], "grid_llr": ["k_grid_llr", "k_worklist_att"], "bp_grid": ["k_bp"],
+                 "select0": ["k_select0"], "cycle_fft": ["k_cyc_a", "k_cyc_bc"], "fine": ["k_fine", "k_worklist"], "bp_fine": ["k_bp", "k_select1"],
+                 "select1": ["k_select1"], "osd": ["k_osd", "k_osd_nan"], "select2": ["k_select2"]}
+
+
+def source_hash():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from src_hash import source_hash as sh
+    return sh()
+
+
+def profile_stale(path):
+    """True when a stored counter profile was collected from other native sources than the tree being benchmarked (None: no stamp)."""
+    try:
+        stamp = json.load(open(path)).get("_source_hash")
+    except Exception:
+        return None
+    return None if stamp is None else stamp != source_hash()
+
+
+def roofline_valu(acc, B, dom):
+    """The roofline that describes this path (VALU / latency bound, not HBM bound): executed vector instructions (wave64
+    instructions, SQ_INSTS_VALU of the committed SQ pass, per 256-frame launch) against the issue ceiling, for the dominant kernel and for
+    the whole step.  k_bp runs four times per step (one grid-stage and three fine-stage launches); the profile holds its per-launch average."""
+    if B != 256 or not os.path.exists(SQ_PROFILE):
+        return None
+    prof = json.load(open(SQ_PROFILE))
+    launches = {"k_bp": 4, "k_select1": 3}
+    insts = {k: v.get("INSTS_VALU", 0.0) * launches.get(k, 1) for k, v in prof.items() if isinstance(v, dict)}
+    step_ms = sum(acc.values())
+    dk = STAGE_KERNELS.get(dom, [dom])[0]
+    if dk not in insts:
+        return None
+    whole = sum(v for k, v in insts.items() if k.startswith("k_") and k not in ("k_synth", "k_fill_row0"))
+    return {"unit": "wave64 VALU instructions", "issue_peak_per_s": VALU_ISSUE_PEAK, "kernel": dk,
+            "insts_per_launch": insts[dk], "kernel_ms": acc[dom], "frac": insts[dk] / (acc[dom] * 1e-3) / VALU_ISSUE_PEAK,
+            "step_insts": whole, "step_ms_sum_of_stages": step_ms, "step_frac": whole / (step_ms * 1e-3) / VALU_ISSUE_PEAK,
+            "source": "profiles/sq_latest.json (rocprofv3 --pmc SQ_INSTS_VALU pass of `bench.py --streams 1 --subbatch 0`, tools/pmc_sq.sh; not measured in this run)",
+            "stale": profile_stale(SQ_PROFILE)}
+
+
+def gpu_use_reading():
+    """One mid-run reading of the driver's own utilisation counter, to stderr (so that a coarse external sampler that reports 0 can be
+    told from an idle GPU): rocm-smi --showuse, or amd-smi metric -u; silent when neither tool is there."""
+    import shutil
+    import subprocess
+    for cmd in (["rocm-smi", "--showuse"], ["amd-smi", "metric", "-u"]):
+        exe = shutil.which(cmd[0]) or (os.path.join("/opt/rocm/bin", cmd[0]) if os.path.exists(os.path.join("/opt/rocm/bin", cmd[0])) else None)
+        if not exe:
+            continue
+        try:
+            out = subprocess.run([exe] + cmd[1:], capture_output=True, text=True, timeout=20).stdout
+            lines = [ln.strip() for ln in out.splitlines() if "use" in ln.lower() or "GFX" in ln or "busy" in ln.lower()]
+            print(f"[bench.py] {' '.join(cmd)} during the timed loop: " + " | ".join(lines[:6]), file=sys.stderr)
+            return
+        except Exception as e:
+            print(f"[bench.py] {' '.join(cmd)} failed: {type(e).__name__}: {e}", file=sys.stderr)
+
+
 def pmc_traffic(kernel_stage, B):
     """HBM bytes per launch of the stage's kernels from the committed PMC profile of this configuration (B = its key in PMC_PROFILES, None
     for a workload no profile was collected for), or None."""
@@ -528,9 +591,16 @@ def main():
     if args.min_seconds > dt:
         n_more = max(1, int((args.min_seconds - dt) / (dt / args.steps)))
         t_e = time.perf_counter()
+        smi = None
+        if rank == 0:                                    # one utilisation reading while the same loop keeps the GPU busy (outside `value`)
+            import threading
+            smi = threading.Thread(target=gpu_use_reading, daemon=True)
+            smi.start()
         run_steps(n_more)
         h.sync()
         extra_steps, extra_dt = n_more, time.perf_counter() - t_e
+        if smi is not None:
+            smi.join(timeout=30)
     # kernel-only rate (no D2H, no host layer), informational
     h.sync()
     t1 = time.perf_counter()
@@ -712,6 +782,7 @@ def main():
                        "host_pointer_pipelined_entry_frames_per_s_pinned": pcie_pinned, "parallelism": f"frames sharded over {world} GPU(s), no collective on the decode path", "gather": gather_note},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, pmc_key),
+                         "traffic_stale": profile_stale(PMC_PROFILES[pmc_key]) if pmc_key in PMC_PROFILES else None,
                          "traffic_source": f"profiles/{os.path.basename(PMC_PROFILES[pmc_key])} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of "
                                            f"`bench.py --config {pmc_key}` at B = {B}, collected by tools/collect_profiles.sh; not measured in this run)" if pmc_traffic(dom, pmc_key) is not None else None,
                          "kernel_ms": dom_ms, "alg_bytes_per_launch": ALG_BYTES[dom] * B,
@@ -735,6 +806,7 @@ def main():
                                           "fine sync 0.78 G of 18 full IFFTs); the kernel executes ONE pruned IFFT, eight frequency-domain scores and a frequency-domain grid "
                                           "per candidate (0.63 MFLOP), fused multiply-adds only where the arithmetic contract names them (the "
                                           "frequency-domain scores are almost all fma: its ceiling lies between the plain-op and the fma rate)"}},
+            "roofline_valu": roofline_valu(acc, B, dom) if default_workload else None,
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "other_configs": other,
             # each rank's own clock over the K timed steps (value uses the max), its kernels-only rate, and where it ran

@@ -340,16 +340,16 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     //     itself and runs the rest with an empty pivot b = 0 -- no column "has a 1 in row b", the update mask is zero everywhere;
     //   * the locked rows exist once (lockU = pivots taken + rows reserved for trivial columns); the steal branch works out which
     //     reserved rows are up for grabs from posrow and the trivial masks;
-    //   * the update: "a 1 in the pivot row" as an all-ones / zero mask (an AND, two v_and_or, a compare, a select), then (mask & m) ^ x
-    //     per word -- one v_bitop3 each on gfx950;
+    //   * the update: "a 1 in the pivot row" as an all-ones / zero mask, then (mask & m) ^ x per word -- one v_bitop3 each on gfx950;
     //   * columns at positions already passed never change again (an accepted one is a unit vector at a locked row, a rejected one has
     //     all its 1s in rows that were locked when it was visited, and a pivot row is an unlocked row): while register set 1 is
     //     walked, set 0 is left alone; while set 2 is walked, sets 0 and 1.
     // TCV: trivial positions before a lane of this register set; BASE: its first position; VIS: its visit mask.  When the basis is
     // complete every visit mask is emptied, which ends this loop and skips the ones that follow.
-#define OSD_UPD(X0, X1, X2) { uint32_t mk = (((X0 & blo) | (X1 & bhi) | (X2 & b2)) != 0u) ? ~0u : 0u; asm volatile("" : "+v"(mk)); \
-                              X0 ^= mk & m0; X1 ^= mk & m1; X2 ^= mk & m2; }
-#define OSD_STEP(XA, XB, XC, ACC, VIS, TCV, BASE, UPDATES)                                                                         \
+    // (the accept step exists three times, once per word the pivot row can lie in -- the lowest eligible row is looked for word by word
+    // anyway -- so that "a 1 in the pivot row" is ONE v_bfe_i32 of a statically known register: 4 vector instructions per register set)
+#define OSD_UPD(XW, X0, X1, X2) { const uint32_t mk = (uint32_t)__builtin_amdgcn_sbfe((int)(XW), bp, 1u); X0 ^= mk & m0; X1 ^= mk & m1; X2 ^= mk & m2; }
+#define OSD_STEP(XA, XB, XC, ACC, VIS, TCV, BASE, UPD0, UPD1, UPD2)                                                                \
     while (VIS != 0) {                                                                                                             \
         const int il = __builtin_ctzll(VIS);                                                                                       \
         OT_VISIT;                                                                                                                  \
@@ -357,39 +357,52 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
         const uint64_t bit = 1ull << il;                                                                                           \
         VIS &= ~bit; ACC |= bit; k++;                                                                                              \
         const uint32_t c0 = __builtin_amdgcn_readlane(XA, il), c1 = __builtin_amdgcn_readlane(XB, il), c2 = __builtin_amdgcn_readlane(XC, il); \
-        const uint64_t c01 = ((uint64_t)c1 << 32) | c0;                                                                            \
-        uint64_t a01 = c01 & ~lockU01; uint32_t a2 = c2 & ~lockU2;                                                                 \
-        if (__builtin_expect(!(a01 | a2), 0)) {                /* rare: nothing outside the locked and reserved rows -- steal, or dependent */ \
+        uint32_t a0 = c0 & ~lockU0, a1 = c1 & ~lockU1, a2 = c2 & ~lockU2;                                                          \
+        if (__builtin_expect(!(a0 | a1 | a2), 0)) {            /* rare: nothing outside the locked and reserved rows -- steal, or dependent */ \
             const int p = (BASE) + il;                                                                                             \
             /* rows of columns that are still trivial and come after this position (lane = row; a robbed column's row is a pivot's) */ \
             const int pa = posrow[lane], pb = posrow[64 + (lane < 27 ? lane : 0)];                                                 \
             const bool ta = pa > p && pa < OSD_TRIV && (((pa < 64 ? triv0 >> pa : triv1 >> (pa - 64)) & 1ull) != 0);               \
             const bool tb = lane < 27 && pb > p && pb < OSD_TRIV && (((pb < 64 ? triv0 >> pb : triv1 >> (pb - 64)) & 1ull) != 0);  \
-            a01 = c01 & __ballot(ta); a2 = c2 & (uint32_t)__ballot(tb);                                                            \
-            if (a01 | a2) {                                                                                                        \
-                const int r = a01 ? __builtin_ctzll(a01) : 64 + __builtin_ctz(a2);                                                 \
+            const uint64_t s01 = (((uint64_t)c1 << 32) | c0) & __ballot(ta);                                                       \
+            a0 = (uint32_t)s01; a1 = (uint32_t)(s01 >> 32); a2 = c2 & (uint32_t)__ballot(tb);                                      \
+            if (a0 | a1 | a2) {                                                                                                    \
+                const int r = s01 ? __builtin_ctzll(s01) : 64 + __builtin_ctz(a2);                                                 \
                 const int q = __builtin_amdgcn_readfirstlane(posrow[r]);   /* the robbed trivial column: visited like any other from now on */ \
                 if (q < 64) { triv0 &= ~(1ull << q); vis0 |= 1ull << q; tc0 -= (lane > q) ? 1 : 0; tc1 -= 1; }                    \
                 else { triv1 &= ~(1ull << (q - 64)); vis1 |= 1ull << (q - 64); tc1 -= (lane > q - 64) ? 1 : 0; }                   \
                 ntriv--;                                                                                                           \
             } else { ACC &= ~bit; k--; }                       /* dependent on the accepted columns */                             \
         }                                                                                                                          \
-        {   /* the accept step: pivot = the lowest eligible row, clear the column's other 1s everywhere, lock the row */            \
-            asm volatile("" : "+s"(a2));                       /* opaque: nothing about the branch above is threaded into the code below */ \
-            const uint64_t b01 = a01 & (0 - a01);                                                                                  \
-            const uint32_t b2 = a01 ? 0u : (a2 & (0u - a2));                                                                       \
-            const uint32_t blo = (uint32_t)b01, bhi = (uint32_t)(b01 >> 32);                                                       \
-            const uint32_t m0 = c0 & ~blo, m1 = c1 & ~bhi, m2 = c2 & ~b2;                                                          \
-            UPDATES                                                                                                                \
-            lockU01 |= b01; lockU2 |= b2;                                                                                          \
+        asm volatile("" : "+s"(a2));                           /* opaque: nothing about the branch above is threaded into the code below */ \
+        /* the accept step: pivot = the lowest eligible row, clear the column's other 1s everywhere, lock the row */                \
+        if (a0) {                                                                                                                  \
+            const uint32_t b = a0 & (0u - a0), bp = __builtin_ctz(a0), m0 = c0 & ~b, m1 = c1, m2 = c2;                             \
+            UPD0                                                                                                                   \
+            lockU0 |= b;                                                                                                           \
+        } else if (a1) {                                                                                                           \
+            const uint32_t b = a1 & (0u - a1), bp = __builtin_ctz(a1), m0 = c0, m1 = c1 & ~b, m2 = c2;                             \
+            UPD1                                                                                                                   \
+            lockU1 |= b;                                                                                                           \
+        } else {                                               /* (a2 = 0: a dependent column -- bit 31 of the third word is never set: mask 0, no row locked) */ \
+            const uint32_t b = a2 & (0u - a2), bp = __builtin_ctz(a2 | 0x80000000u), m0 = c0, m1 = c1, m2 = c2 & ~b;               \
+            UPD2                                                                                                                   \
+            lockU2 |= b;                                                                                                           \
         }                                                                                                                          \
     }
+    uint32_t lockU0 = (uint32_t)lockU01, lockU1 = (uint32_t)(lockU01 >> 32);
     OT(2);
-    OSD_STEP(x00, x01, x02, acc0, vis0, tc0, 0, OSD_UPD(x00, x01, x02) OSD_UPD(x10, x11, x12) OSD_UPD(x20, x21, x22))
-    OSD_STEP(x10, x11, x12, acc1, vis1, tc1, 64, OSD_UPD(x10, x11, x12) OSD_UPD(x20, x21, x22))
+    OSD_STEP(x00, x01, x02, acc0, vis0, tc0, 0,
+             OSD_UPD(x00, x00, x01, x02) OSD_UPD(x10, x10, x11, x12) OSD_UPD(x20, x20, x21, x22),
+             OSD_UPD(x01, x00, x01, x02) OSD_UPD(x11, x10, x11, x12) OSD_UPD(x21, x20, x21, x22),
+             OSD_UPD(x02, x00, x01, x02) OSD_UPD(x12, x10, x11, x12) OSD_UPD(x22, x20, x21, x22))
+    OSD_STEP(x10, x11, x12, acc1, vis1, tc1, 64,
+             OSD_UPD(x10, x10, x11, x12) OSD_UPD(x20, x20, x21, x22),
+             OSD_UPD(x11, x10, x11, x12) OSD_UPD(x21, x20, x21, x22),
+             OSD_UPD(x12, x10, x11, x12) OSD_UPD(x22, x20, x21, x22))
     {
         int tc2 = ntriv;                                      // every trivial position lies before register set 2
-        OSD_STEP(x20, x21, x22, acc2, vis2, tc2, 128, OSD_UPD(x20, x21, x22))
+        OSD_STEP(x20, x21, x22, acc2, vis2, tc2, 128, OSD_UPD(x20, x20, x21, x22), OSD_UPD(x21, x20, x21, x22), OSD_UPD(x22, x20, x21, x22))
     }
 #undef OSD_STEP
 #undef OSD_UPD

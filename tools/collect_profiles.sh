@@ -8,7 +8,7 @@ TAG=${1:-r04}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0 --no-other-configs"
+BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry --streams 1 --subbatch 0 --min-seconds 0 --no-other-configs"
 
 timeout 900 python3 bench.py > "$OUT/${TAG}_bench_b256_default.json" 2> "$OUT/${TAG}_bench_b256_default.err"
 timeout 600 python3 bench.py --streams 4 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_b256_s4.json" 2>> "$OUT/${TAG}_bench_b256_default.err"
@@ -25,7 +25,7 @@ W=$(find "$OUT/${TAG}_pmcW" -name '*counter_collection.csv' | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_pmc.json" "$OUT/${TAG}_pmc_b256.txt" > /dev/null
 
 # BASELINE config 2 as stated (4096 frames, BP 30 iterations, OSD depth 2 = osd_012(30, 2)): rocprofv3 kernel stats + PMC traffic
-B2="python3 bench.py --config 2 --steps 2 --warmup 1 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0"
+B2="python3 bench.py --config 2 --steps 2 --warmup 1 --no-cpu-baseline --no-host-entry --streams 1 --subbatch 0 --min-seconds 0"
 rm -rf "$OUT/${TAG}_c2_stats" "$OUT/${TAG}_c2_pmcF" "$OUT/${TAG}_c2_pmcW"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_c2_stats" -o s -- $B2 > "$OUT/${TAG}_c2_stats.log" 2>&1
 DB=$(find "$OUT/${TAG}_c2_stats" -name '*.db' | head -1)
@@ -39,7 +39,7 @@ timeout 900 $B2 > "$OUT/${TAG}_bench_b4096_config2_bp30.json" 2>> "$OUT/${TAG}_b
 
 # PMC traffic of configs 3 and 4 (bench.py --config 3 / 4 fill roofline.traffic from these)
 for C in 3 4; do
-  BC="python3 bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0"
+  BC="python3 bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-host-entry --streams 1 --subbatch 0 --min-seconds 0"
   rm -rf "$OUT/${TAG}_c${C}_pmcF" "$OUT/${TAG}_c${C}_pmcW"
   timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_c${C}_pmcF" -o f -- $BC > "$OUT/${TAG}_c${C}_pmcF.log" 2>&1
   timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_c${C}_pmcW" -o w -- $BC > "$OUT/${TAG}_c${C}_pmcW.log" 2>&1

@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
 for L in "$@"; do
   N=$(basename "$L" .so)
   rm -rf "$OUT/${TAG}_${N}_st"
-  FT8RX_LIB=$PWD/$L timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_${N}_st" -o s -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0 --no-other-configs > "$OUT/${TAG}_${N}_st.log" 2>&1
+  FT8RX_LIB=$PWD/$L timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_${N}_st" -o s -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry --streams 1 --subbatch 0 --min-seconds 0 --no-other-configs > "$OUT/${TAG}_${N}_st.log" 2>&1
   DB=$(find "$OUT/${TAG}_${N}_st" -name '*.db' | head -1)
   [ -n "$DB" ] && python3 tools/rocprof_summary.py "$DB" "$OUT/${TAG}_${N}_kstats.txt" > /dev/null
   rm -rf "$OUT/${TAG}_${N}_st"

@@ -7,7 +7,7 @@ TAG=$1; LIBV=${2:-}
 OUT=$PWD/gpurun_out; mkdir -p "$OUT"
 export TMPDIR=/tmp
 [ -n "$LIBV" ] && export FT8RX_LIB=$PWD/$LIBV
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-entry --streams 1 --min-seconds 0 --no-other-configs"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-entry --streams 1 --subbatch 0 --min-seconds 0 --no-other-configs"
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"
 P2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS"
 P3="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_LDS SQ_INSTS_SENDMSG SQ_INSTS_FLAT SQ_IFETCH"

@@ -4,7 +4,12 @@ SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over wave
 SQ_WAVE_CYCLES, i.e. per resident wave."""
 import collections
 import csv
+import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from src_hash import source_hash  # noqa: E402
 
 
 def main():
@@ -39,6 +44,10 @@ def main():
                      f"{a.get('SQ_INSTS_VALU', 0) / w:>15.1f}{a.get('SQ_INSTS_SALU', 0) / w:>15.1f}{w:>10.0f}")
     txt = "\n".join(lines) + "\n"
     open(sys.argv[1], "w").write(txt)
+    # the same per-launch averages as JSON (bench.py reads INSTS_VALU from the committed copy, profiles/sq_latest.json)
+    js = {k: {c.replace("SQ_", ""): v for c, v in avg[k].items()} for k in avg}
+    js["_source_hash"] = source_hash()
+    json.dump(js, open(os.path.splitext(sys.argv[1])[0] + ".json", "w"), indent=1)
     print(txt)
 
 

@@ -6,7 +6,11 @@ spectrogram grid write)."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from src_hash import source_hash  # noqa: E402
 
 
 def agg(path):
@@ -24,6 +28,7 @@ def main():
         wa = 1024 * sum(w.get(k, [0.0])) / max(1, len(w.get(k, [0.0])))
         out[k] = {"launches": len(f[k]), "fetch_bytes": fa, "write_bytes": wa, "hbm_bytes": fa + wa}
         lines.append(f"{k:<26}{len(f[k]):>9}{fa/1e6:>14.1f}{wa/1e6:>11.1f}{(fa+wa)/1e6:>15.1f}")
+    out["_source_hash"] = source_hash()          # bench.py: traffic_stale when the benchmarked tree differs
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     txt = "\n".join(lines) + "\n"
     if len(sys.argv) > 4:
