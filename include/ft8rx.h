@@ -11,6 +11,33 @@
  * separate handles are.  All device workspaces are allocated at ft8rx_create(); the hot path
  * allocates nothing.  Pointers are host pointers unless the parameter is named d_*.
  */
+/* MAP OF THE ABI -- which entry points an adopter binds, and which exist for tests and measurements.
+ *
+ *   CORE (the drop-in boundary, SURVEY.md 8b: everything the Python surface of receiver.py / decoders.py needs)
+ *     lifecycle        ft8rx_default_config  ft8rx_create  ft8rx_destroy  ft8rx_last_error  ft8rx_device_count  ft8rx_build_info
+ *     whole path       ft8rx_decode_batch  ft8rx_decode_messages                       (synchronous: host audio -> records / messages)
+ *                      ft8rx_enqueue_batch  ft8rx_enqueue_batch_host  ft8rx_sync  ft8rx_fetch_results  ft8rx_fetch_results_view  (pipelined)
+ *     host messages    ft8rx_package_batch  ft8rx_hashes_create / _destroy / _clear / _add / _size   (a14-a17: unpack, call hashes, dict fields)
+ *     decoders.py      ft8rx_ldpc  ft8rx_osd  ft8rx_crc_valid  ft8rx_valid77                           (ldpc_decode, osd_012, crc_unpack91, unpack)
+ *     streaming        ft8rx_hop_spectrum  ft8rx_sync_search                                       (AudioIn._callback, Receiver.search)
+ *     multi-GPU        ft8rx_set_packed_output  ft8rx_packed_results  ft8rx_packed_output_fence  ft8rx_package_packed  ft8rx_alloc_host
+ *                      ft8rx_free_host  ft8rx_device_pci_bus_id                                     (the gather of decoded messages)
+ *   TUNING AND SERVICE (defaults are the measured best; results never depend on them)
+ *     ft8rx_set_streams  ft8rx_set_subbatch  ft8rx_set_ladder_mode  ft8rx_set_reject_log  ft8rx_staging_audio  ft8rx_copy_to_host
+ *     ft8rx_results_to_device
+ *   EXTENSIONS (no counterpart in the reference's receive path)
+ *     ft8rx_synth_frames  ft8rx_synth_frames_ex                                        (f-1: workload generator)
+ *     ft8rx_subtract  ft8rx_subtraction_list  ft8rx_encode_tones  ft8rx_merge_messages  ft8rx_set_search_mask   (f-4: subtraction passes)
+ *     ft8rx_osd_ext                                                                    (order-3 / distance-gate knobs)
+ *   TEST AND MEASUREMENT AIDS (stage entry points of the parity tests, timers, probes -- an adopter never calls these)
+ *     ft8rx_spectrogram  ft8rx_sync_scores  ft8rx_llr_grid  ft8rx_cycle_spectrum  ft8rx_fine  ft8rx_get_fft_plans
+ *     ft8rx_set_profiling  ft8rx_get_stage_times  ft8rx_math_probe  (and the ft8rx_debug_* symbols of timing-only builds)
+ *
+ * LIMITS of this build against the reference's open-ended kwargs (pyft8_amd.receiver.config_from_kwargs names the kwarg when one is
+ * exceeded; ft8rx_create answers -1): max_cands <= FT8RX_MAX_CANDS = 256 (reference: any; default 200), search_time_range inside
+ * [-6.1, +8.3] s and at most 14.08 s wide (FT8RX_MIN_H0 / FT8RX_MAX_H0), search_freq_range 12.5 .. 3000 Hz (libft8rx.so) / .. 5900 Hz
+ * (libft8rx_wide.so), OSD flip counts <= 91 and <= 16384 trials.
+ */
 #ifndef FT8RX_H
 #define FT8RX_H
 #include <stdint.h>

@@ -201,10 +201,13 @@ struct Scratch {
 // Everything that is not a pipelined batch (stage entry points, the synchronous host entry, subtraction, profiling passes) uses the
 // handle's shared workspaces from the main stream; while the chunk streams run free (launch_batch) their work is not ordered
 // against the main stream, so such calls first wait until the batches in flight are complete.
-static int quiesce(ft8rx_handle* h) {
+static int quiesce(ft8rx_handle* h, bool next_is_batch = false) {
     // the result copy of the last batch waits for every chunk stream (free-running batches) and still reads the slot's device
-    // buffers on the copy stream after a plain one -- either way nothing of a batch is pending once the copy stream is idle
-    if (h->free_running || h->last_slot >= 0) HIPCHK(h, hipStreamSynchronize(h->copy_s));
+    // buffers on the copy stream after a plain one -- either way nothing of a batch is pending once the copy stream is idle.
+    // A plain BATCH after a plain batch need not wait on the host at all: its kernels follow the previous ones on the main stream (the
+    // sub-streams were joined into it), it writes the OTHER result slot, and that slot's previous copy is ordered by ev_done[slot] --
+    // so small pipelined batches (enqueue k + 1 while k's results travel) keep their overlap.
+    if (h->free_running || (h->last_slot >= 0 && !next_is_batch)) HIPCHK(h, hipStreamSynchronize(h->copy_s));
     h->free_running = false;
     h->need_barrier = true;
     return 0;
@@ -618,7 +621,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
         }
         h->free_running = true;
     } else {
-    { const int q = quiesce(h); if (q) return q; }
+    { const int q = quiesce(h, true); if (q) return q; }
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));          // the slot's previous results have left the device
     if (nc <= 1) {
         if (host_audio) HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, h->stream));

@@ -38,6 +38,18 @@ def config_from_kwargs(sync_score_min=85, max_cands=200, search_freq_range=(100,
         sync_score_min=float(sync_score_min), max_cands=int(max_cands),
         f0_lo=int(search_freq_range[0] / df), f0_hi=int(search_freq_range[1] / df),
         h0_lo=int((search_time_range[0] + 0.5) * 4 * SYM_RATE), h0_hi=int((search_time_range[1] + 0.5) * 4 * SYM_RATE))
+    # The reference takes any value here (receiver.py:311-313, 319, 366-367); this build has compile-time layouts.  Say which
+    # kwarg is out of range instead of letting ft8rx_create answer "configuration out of the supported range" (include/ft8rx.h).
+    if not 1 <= cfg.max_cands <= _lib.MAX_CANDS:
+        raise _lib.Ft8rxError(f"max_cands={max_cands}: this build keeps at most {_lib.MAX_CANDS} candidates per frame (FT8RX_MAX_CANDS; "
+                              "the reference's default is 200)")
+    if cfg.h0_lo < _lib.MIN_H0 or cfg.h0_hi > _lib.MAX_H0 or not 0 < cfg.h0_hi - cfg.h0_lo <= 352:
+        raise _lib.Ft8rxError(f"search_time_range={list(search_time_range)}: supported are windows inside [{_lib.MIN_H0 / 25 - 0.5:.1f}, "
+                              f"{_lib.MAX_H0 / 25 - 0.5:.1f}] s of at most {352 / 25:.2f} s (FT8RX_MIN_H0 / FT8RX_MAX_H0: the middle Costas block of "
+                              "every candidate must lie inside the 16-s fine-sync series; the reference's default is [-2, 3])")
+    if cfg.f0_lo < 4 or cfg.f0_hi > _lib.MAX_F0_WIDE or cfg.f0_lo >= cfg.f0_hi:
+        raise _lib.Ft8rxError(f"search_freq_range={list(search_freq_range)}: supported are 12.5 .. {_lib.MAX_F0_WIDE * df:.0f} Hz, low < high "
+                              "(above 3000 Hz the wide build libft8rx_wide.so is used; the reference fails beyond ~5940 Hz, receiver.py:181-182)")
     known = {f[0] for f in _lib.Config._fields_}
     for k, v in ext.items():          # extension knobs: bp_iters_b, osd_single, osd_double, osd_triple, osd_max_hd, ...
         if k not in known:            # like the reference's fixed signature (e.g. the CLI's misspelt `search_timerange`, pyft8.py:137)
