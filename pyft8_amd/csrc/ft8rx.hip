@@ -142,6 +142,33 @@ static void set_err(ft8rx_handle* h, const char* fmt, ...) {
     if (h) h->err = buf; else g_create_err = buf;
 }
 
+// Streams are a PROCESS-WIDE pool per device, created once and never destroyed.  The HIP runtime maps every stream onto one of four
+// hardware queues when it is created, and commands of streams that share a queue execute in submission order.  The streams of the
+// first handle of a process get a queue each (main, copy, H2D, second chunk stream); a handle created after that one had been
+// destroyed used to get another mapping, with both chunk streams of a batch on ONE queue -- no overlap between the two halves of a
+// batch: 82.4 k -> 70.9 k frames/s on the 8192-frame shard (tools/r05_alloc_probe.py, profiles/r05_notes.md).  Handles of one process
+// share the pool (more ordering between them, never less: every wait refers to an event recorded earlier in host order).
+#include <mutex>
+struct StreamPool { hipStream_t main = nullptr, copy = nullptr, h2d = nullptr, sub[8] = {}; };
+static std::mutex g_pool_mu;
+static StreamPool g_pool[64];
+static hipStream_t pool_stream(int device, hipStream_t StreamPool::* which, bool blocking) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    StreamPool& P = g_pool[device & 63];
+    if (!(P.*which)) {
+        hipStream_t s = nullptr;
+        if ((blocking ? hipStreamCreate(&s) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return nullptr;
+        P.*which = s;
+    }
+    return P.*which;
+}
+static hipStream_t pool_sub(int device, int i) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    StreamPool& P = g_pool[device & 63];
+    if (!P.sub[i] && hipStreamCreateWithFlags(&P.sub[i], hipStreamNonBlocking) != hipSuccess) P.sub[i] = nullptr;
+    return P.sub[i];
+}
+
 template <typename T> static int dalloc(ft8rx_handle* h, T** p, size_t n) {
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, n * sizeof(T));
@@ -252,13 +279,15 @@ const char* ft8rx_last_error(ft8rx_handle* h) { return h ? h->err.c_str() : g_cr
 void ft8rx_destroy(ft8rx_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
+    // the streams belong to the process-wide pool and stay: wait for everything this handle has put on them, then free its memory
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->copy_s) hipStreamSynchronize(h->copy_s);
+    if (h->h2d_s) hipStreamSynchronize(h->h2d_s);
+    for (int i = 0; i < 8; i++) { if (h->sub[i]) hipStreamSynchronize(h->sub[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     for (void* p : h->allocs) hipFree(p);
     for (auto& c : h->arena) hipFree(c.p);
     for (auto e : h->pev) hipEventDestroy(e);
-    for (int i = 0; i < 8; i++) { if (h->sub[i]) hipStreamDestroy(h->sub[i]); if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]); }
     for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) if (h->ev_cdone[k][i]) hipEventDestroy(h->ev_cdone[k][i]);
-    if (h->copy_s) hipStreamDestroy(h->copy_s);
-    if (h->h2d_s) hipStreamDestroy(h->h2d_s);
     for (int i = 0; i < 16; i++) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (int k = 0; k < 2; k++) {
@@ -271,7 +300,6 @@ void ft8rx_destroy(ft8rx_handle* h) {
         if (h->h_evpacked[k]) hipHostFree(h->h_evpacked[k]);
         if (h->h_pkhdr[k]) hipHostFree(h->h_pkhdr[k]);
     }
-    if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -299,7 +327,7 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     h->pk_buf[0] = h->pk_buf[1] = nullptr; h->pk_cap = 0; h->d_pkneed = nullptr; h->d_pknrec = nullptr; h->fetched_slot = -1;
     for (int k = 0; k < 2; k++) { h->h_pkhdr[k] = nullptr; h->d_pkhdr[k] = nullptr; h->slot_packed[k] = false; h->pk_fence[k] = nullptr; }
     h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr; h->d_ones = nullptr;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
+    if (hipSetDevice(device) != hipSuccess || !(h->stream = pool_stream(device, &StreamPool::main, true))) { set_err(nullptr, "ft8rx_create: cannot open device %d", device); delete h; return -2; }
     const size_t B = (size_t)max_frames;
     int rc = 0;
     rc |= dalloc(h, &h->d_grid, B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS);
@@ -438,8 +466,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     for (int i = 0; i < 24; i++) { hipEvent_t e = nullptr; okc = okc && hipEventCreate(&e) == hipSuccess; if (e) h->pev.push_back(e); }
     // (the chunk streams h->sub[] are created on first use, launch_batch: every stream that exists competes for one of the
     // runtime's four hardware queues, see the note there)
-    okc = okc && hipStreamCreateWithFlags(&h->copy_s, hipStreamNonBlocking) == hipSuccess;
-    okc = okc && hipStreamCreateWithFlags(&h->h2d_s, hipStreamNonBlocking) == hipSuccess;
+    okc = okc && (h->copy_s = pool_stream(device, &StreamPool::copy, false)) != nullptr;
+    okc = okc && (h->h2d_s = pool_stream(device, &StreamPool::h2d, false)) != nullptr;
     for (int i = 0; i < 16; i++) okc = okc && hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
     okc = okc && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < 2; k++) {
@@ -583,7 +611,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     // had finished (profiles/r03_notes.md).  Four streams in use = a queue each.
     const int ns = h->n_streams;
     for (int i = 1; i < ns && nc > 1; i++) if (!h->sub[i - 1]) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->sub[i - 1], hipStreamNonBlocking));
+        if (!(h->sub[i - 1] = pool_sub(h->device, i - 1))) { set_err(h, "cannot create a chunk stream"); return -2; }
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[i - 1], hipEventDisableTiming));
     }
     auto chunk_stream = [&](int k) { const int i = k % ns; return i == 0 ? h->stream : h->sub[i - 1]; };
