@@ -394,7 +394,7 @@ def main():
     ap.add_argument("--osd", type=int, nargs=2, default=None, metavar=("SINGLE", "DOUBLE"), help="extension knob: osd_012 flip counts (reference 30 2)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams a batch is cut across (1 = one chain of whole-batch launches)")
     ap.add_argument("--subbatch", type=int, default=None, help="frames per kernel chain inside a stream's share of a batch (ft8rx_set_subbatch; "
-                    "default: the library's 128; 0 = the whole share in one chain, the round-4 behaviour)")
+                    "default: the library's 256; 0 = the whole share in one chain, the round-4 behaviour)")
     ap.add_argument("--config", type=int, default=None, choices=(1, 2, 3, 4), help="BASELINE.json configuration preset (per GPU): 1 = 256 frames; "
                     "2 = 4096 frames, BP 30 iterations, OSD depth 2; 3 = 8192 frames per GPU (65 536 over 8 GPUs) + record gather; "
                     "4 = 2048 frames per GPU (16 384 over 8), <= 10 signals at -24..-20 dB, OSD order 3 over 30 positions with the distance gate at 32")

@@ -232,7 +232,7 @@ int  ft8rx_set_streams(ft8rx_handle* h, int n);
 /* frames per kernel chain inside a stream's share of a batch (default FT8RX_SUBBATCH_DEFAULT; 0 = the whole share in one chain): a
  * large batch runs as a sequence of cache-sized sub-batches, each through the whole path before the next starts, so that a stage
  * reads what the stage before it wrote from L2 / MALL instead of HBM.  Records, events and messages do not depend on it. */
-#define FT8RX_SUBBATCH_DEFAULT 128
+#define FT8RX_SUBBATCH_DEFAULT 256    /* measured: 128 .. 256 are equal on dense frames (BASELINE configs 2, 3), 256 is 10 % better on sparse ones (config 4) */
 int  ft8rx_set_subbatch(ft8rx_handle* h, int frames);
 /* how the fine-stage BP attempts of a batch are launched; records and messages are identical either way:
  * 0 (default) = in the reference's ladder order (receiver.py:84-98) as three launches, candidates that are decided dropping out in

@@ -374,7 +374,7 @@ class Handle:
         self._chk(self._L.ft8rx_set_streams(self._h, int(n)), "ft8rx_set_streams")
 
     def set_subbatch(self, frames):
-        """Frames per kernel chain inside a stream's share of a batch (ft8rx_set_subbatch; default 128, 0 = the whole share at once)."""
+        """Frames per kernel chain inside a stream's share of a batch (ft8rx_set_subbatch; default 256, 0 = the whole share at once)."""
         self._chk(self._L.ft8rx_set_subbatch(self._h, int(frames)), "ft8rx_set_subbatch")
 
     def set_ladder_mode(self, mode):
