@@ -819,7 +819,12 @@ def main():
             # the CPU oracle timed on this box's host cores: rank 0 at N = 1 only (the contract); null in multi-GPU runs
             os.sched_setaffinity(0, orig_affinity)      # the CPU baseline may use every host core, not this rank's slice
             line["cpu_baseline"] = cpu_baseline(frames) if world == 1 else None
-        print(json.dumps(line))
+        try:                                  # whatever native libraries hold in their stdio buffers (RCCL's version banner) goes out first:
+            import ctypes                     # the JSON line is the LAST line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
     if gather is not None:
         gather.close()
     if dist.is_initialized():

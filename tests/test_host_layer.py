@@ -511,6 +511,9 @@ pool = np.load(sys.argv[2])
 total, nb = int(sys.argv[4]), 3                                 # `total` frames per batch over the ranks (uneven), nb batches
 start, count = shard(total, rank, world)
 grow = len(sys.argv) > 5 and sys.argv[5] == "grow"
+straggler = len(sys.argv) > 5 and sys.argv[5] == "straggler"
+if straggler:
+    nb = 12
 def batch(k):                                                   # global frame g of batch k = pool frame (g + 5 k) % n
     idx = [(start + i + 5 * k) % len(pool["cnt"]) for i in range(count)]
     if grow and k == 0:
@@ -519,11 +522,17 @@ def batch(k):                                                   # global frame g
 h = FakeHandle([batch(k) for k in range(nb)])
 if grow:
     PackedGather.MIN_ROW = 1024                                 # rank 0's receive rows start at twice the first batch's largest part
-g = PackedGather(h, shard(total, 0, world)[1], dst=0, repeat=2 if grow else 1)
+g = PackedGather(h, shard(total, 0, world)[1], dst=0, repeat=2 if grow else 1, depth=16 if straggler else 4)
 got = []
+import time
+t_loop = time.perf_counter()
 for k in range(nb):                                             # the bench loop's order: fetch k, submit k, (collect k - 1)
+    if straggler and rank == 1:
+        time.sleep(0.05)                                        # one slow rank: nobody but rank 0's collect() may wait for it
     h.fetch()
     g.submit()
+    if straggler:
+        continue
     if k > 0:
         parts = g.collect()
         if rank == 0:
@@ -532,6 +541,23 @@ for k in range(nb):                                             # the bench loop
             assert [p.n_frames for p in parts] == [shard(total, r, world)[1] for r in range(world)]
         else:
             assert parts is None
+t_loop = time.perf_counter() - t_loop
+if straggler:
+    # every rank's own submit loop, before anybody drains: the senders other than the straggler (and rank 0, whose ring is deep enough)
+    # did not wait for it; then the batches arrive complete and in order
+    times = [None] * world
+    dist.all_gather_object(times, t_loop)
+    assert times[1] >= 0.05 * nb and all(times[r] < 0.5 * times[1] for r in range(world) if r != 1), times
+    assert max(g.seconds) < 0.04, max(g.seconds)
+    for k in range(nb):
+        parts = g.collect()
+        if rank == 0:
+            got.append([[" ".join(x.decode() for x in m["f"]) for m in ms[:n]] for p in parts for ms, n in zip(*_lib.package_packed(p))])
+    if rank == 0:
+        json.dump(got, open(sys.argv[3], "w"))
+    g.close()
+    dist.barrier(); dist.destroy_process_group()
+    sys.exit(0)
 parts = g.drain()
 if rank == 0:
     assert len(parts) == world * (2 if grow else 1)
@@ -547,12 +573,14 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,total,mode", [(2, 5, ""), (8, 8 * 2 + 3, ""), (3, 7, "grow")])
+@pytest.mark.parametrize("world,total,mode", [(2, 5, ""), (8, 8 * 2 + 3, ""), (3, 7, "grow"), (4, 9, "straggler")])
 def test_packed_gather_gloo_uneven_shards(tmp_path, world, total, mode):
     """PackedGather over gloo at world sizes 2 and 8 (the rank-count-dependent paths: uneven shard() blocks, byte counts that differ
     per rank, point-to-point sends announced through the store, several batches in flight) on CPU with a stand-in handle that packs oracle records: rank 0 ends up with every
     rank's frames in shard order, batch after batch, and renders the golden messages from the packed form.  "grow": the first batch is
-    small, so rank 0's receive buffers (sized from the byte counts seen) are re-allocated while a gather is in flight; repeat = 2."""
+    small, so rank 0's receive buffers (sized from the byte counts seen) are re-allocated while a gather is in flight; repeat = 2.
+    "straggler": rank 1 sleeps 50 ms before every batch -- no rank but the straggler itself notices (there is no rendezvous: each rank
+    waits for its own sends only, rank 0's ring holds 16 batches), and all twelve batches still arrive complete and in order."""
     from pyft8_amd import _lib
     names = ["synth_200000", "test_09", "synth_100000", "test_08", "synth_000000"]
     rec, cnt, ev, evc = _dense_goldens(names)
@@ -565,7 +593,7 @@ def test_packed_gather_gloo_uneven_shards(tmp_path, world, total, mode):
                           env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1"), timeout=900, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
     got = json.load(open(out))
     want = [[" ".join(m["msg_tuple"]) for m in load_golden(nm)[2]["messages"]] for nm in names]
-    assert len(got) == 3
+    assert len(got) == (12 if mode == "straggler" else 3)
     for k, batch in enumerate(got):
         assert batch == [want[0 if (mode == "grow" and k == 0) else (g + 5 * k) % len(names)] for g in range(total)], k
 

@@ -4,7 +4,7 @@
 # rocprofv3 passes are separate runs (kernel trace + stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE), each with the
 # program itself after `--`.  Everything is bounded by `timeout`.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
