@@ -13,7 +13,7 @@
 #define FINE_NT 128
 #endif
 #ifndef FINE_WV
-#define FINE_WV 2
+#define FINE_WV 3          /* <= 168 VGPRs: with 29.1 KB of LDS five 2-wave blocks fit a CU, i.e. three waves on two of its SIMDs */
 #endif
 #define FINE_INV 0.0003125f
 
@@ -410,16 +410,19 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
                             const int32_t* __restrict__ trip, int32_t* __restrict__ t_out /*[n][5]*/,
                             float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
     __shared__ cpx z[3200];
-    __shared__ cpx slice[FINE_SLICE];  // the candidate's 1064 spectrum bins, read by the first stage of all ten IFFTs
+    // The candidate's 1064 spectrum bins (the slice every tweak reads) are NOT staged in LDS beside the transform image: the time scan's
+    // first stage reads its 13 values per thread straight from global memory, and while the time scan is scored the slice is copied
+    // global -> LDS by the DMA path (global_load_lds_dwordx4: no registers, no wait) into the part of the image the scoring does not
+    // read -- below or above it, by the candidate's start time -- for the frequency scan and the final grid, whose tables take the
+    // other part.  37.6 -> 29.1 KB of LDS per block = 5 blocks (10 waves) per CU instead of 4 (profiles/r05_notes.md section 6).
     __shared__ cpx w400[400];          // W3200[8 t]: every twiddle of the [4,4] stage of the ONE transform (the time scan's); dead after it, then
     float* mg = reinterpret_cast<float*>(w400);      // [640] scoring (on, off) sums as fp64, later the [79][8] grid -- first written after that transform
     static_assert(sizeof(cpx) * 400 >= sizeof(float) * 640, "mg overlays w400");
-    float* p = reinterpret_cast<float*>(slice);      // [464] the slice is dead once the last IFFT has run: reuse it
-    float* llr = p + 464;                            // [176]
-    float* sq = llr + 176;                           // [176]
+    // (keeping w400 apart from mg and staging it once per block would save four loads and a barrier per candidate and still fit five
+    // blocks per CU, but hipcc's register allocator crashes on that form under the ILP scheduling strategy: ROCm 7.2)
+    __shared__ cpx w32[32];
     __shared__ float sc[16];
     __shared__ int ish[4];
-    __shared__ cpx w32[32];
     const int lane = tid & 63;
     int frame, ci = 0, f0, h0;
     if (trip) { frame = trip[3 * bid]; f0 = trip[3 * bid + 1]; h0 = trip[3 * bid + 2]; }
@@ -430,28 +433,20 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         if (r.status != FT8RX_ST_ACTIVE) return;
         f0 = r.f0_idx; h0 = r.h0_idx;
     }
-    const cpx w32v = T.W32[tid & 31];                             // requested with the window loads below, stored before the barrier
+    const cpx w32v = T.W32[tid & 31];                             // requested with the twiddle loads below, stored before the barrier
     const int fb0 = 50 * f0;                                      // int(0.5 + fHz*16)
     {
-        const cpx* __restrict__ Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
-        // the candidate's spectrum window and the stage-2 twiddles: all loads requested together, then stored (a load->store loop waits
-        // for every load separately: 3.07 -> 2.99 ms)
-        {
-            constexpr int NS = (FINE_SLICE + FINE_NT - 1) / FINE_NT, NW = (400 + FINE_NT - 1) / FINE_NT;
-            cpx sv[NS], wv[NW];
+        // the stage-2 twiddles (and the symbol-DFT twiddles) go to LDS; the slice stays in global memory for the time scan
+        constexpr int NW = (400 + FINE_NT - 1) / FINE_NT;
+        cpx wv[NW];
 #pragma unroll
-            for (int q = 0; q < NS; q++) { const int i = tid + FINE_NT * q; sv[q] = Sg[i < FINE_SLICE ? i : 0]; }
+        for (int q = 0; q < NW; q++) { const int i = tid + FINE_NT * q; wv[q] = T.W3200[8 * (i < 400 ? i : 0)]; }
 #pragma unroll
-            for (int q = 0; q < NW; q++) { const int i = tid + FINE_NT * q; wv[q] = T.W3200[8 * (i < 400 ? i : 0)]; }
-#pragma unroll
-            for (int q = 0; q < NS; q++) { const int i = tid + FINE_NT * q; if (i < FINE_SLICE) slice[i] = sv[q]; }
-#pragma unroll
-            for (int q = 0; q < NW; q++) { const int i = tid + FINE_NT * q; if (i < 400) w400[i] = wv[q]; }
-            if (tid < 32) w32[tid] = w32v;
-        }
+        for (int q = 0; q < NW; q++) { const int i = tid + FINE_NT * q; if (i < 400) w400[i] = wv[q]; }
+        if (tid < 32) w32[tid] = w32v;
         __syncthreads();
     }
-    const cpx* S = slice;
+    const cpx* __restrict__ Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);      // global: slice bin i at Sg[i]
     FT_DECL
     cpx wq[8];
     sym32_twiddles(w32, tid & 3, wq);                             // every symbol DFT of this thread uses n2 = tid & 3
@@ -461,9 +456,30 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     // S1 = sum_a on_a, S2 = sum_a off_a (a ascending) and score = (float)(S1 + w6 S2) -- no serial chain, no broadcast.
     double* dsum = reinterpret_cast<double*>(mg);              // [8][7][2] (on, off); mg is free until the final grid
     // --- time tweaks at ftweak 0: range(-8,8,2) -> 8 x 7 symbols, 4 lanes each
-    fine_fft(S, 182, z, w400, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43 FT_PASS);   // the 8 time tweaks of the middle Costas block
+    fine_fft(Sg, 182, z, w400, T, tid, tb0 - 8 + 32 * 36, tb0 + 6 + 32 * 43 FT_PASS);   // the 8 time tweaks of the middle Costas block
     FsLane L;
     fscore_fetch(L, T, tid);                                   // the frequency scan's constants: requested here, used after the time scan
+    // The scoring below reads samples [tb0 + 1144, tb0 + 1382) of the image (clamped).  The slice copy -- 9 chunks of 64 lanes x 16 bytes,
+    // the last one running 88 bins past the slice on both sides -- goes to z[0, 1152) when that range lies above it, else to
+    // z[2048, 3200); the frequency scan's tables (1780 slots) and the final grid's (1600) start at z[1152) resp. z[0).
+    const bool lowslice = tb0 >= 667;                          // block-uniform
+    cpx* slice = z + (lowslice ? 0 : 2048);
+    cpx* zi = z + (lowslice ? 1152 : 0);
+    static_assert(9 * 128 <= 1152 && 2048 + 9 * 128 <= 3200 && 1152 + 1780 <= 3200 && 1780 <= 2048, "slice copy and scan tables share the image");
+    {
+        const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const int ch = wv + 2 * c;                         // chunk: bins [128 ch, 128 ch + 128)
+            if (ch < 9)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Sg + 128 * ch + 2 * ln),
+                                                 (__attribute__((address_space(3))) void*)(slice + 128 * ch), 16, 0, 0);
+        }
+    }
+    const cpx* S = slice;                                      // valid after the wait + barrier in front of the frequency scan
+    float* p = reinterpret_cast<float*>(slice);                // [464] the slice is dead once the final grid exists: reuse it
+    float* llr = p + 464;                                      // [176]
+    float* sq = llr + 176;                                     // [176]
 #pragma unroll 1
     for (int r = 0; r < (224 + FINE_NT - 1) / FINE_NT; r++) {
         const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
@@ -497,17 +513,18 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     FT(26);
     // --- frequency tweaks: range(-32,33,8)
     float best = 0.0f; int ft = 0;
-    fscore_prepare(L, z, T, tb0 + tt + 32 * 36, tid);         // the time scan is done with the series: the image takes the tables of the frequency scan
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): the slice copy has landed (made visible by fscore_prepare's barrier)
+    fscore_prepare(L, zi, T, tb0 + tt + 32 * 36, tid);         // the time scan is done with the series: the image takes the tables of the frequency scan
     FT(18);
 #pragma unroll 1
     for (int n = 0; n < 8; n++) {                              // tweak 0 is the time scan's winner: same series, same offset, identical value
-        fine_fscore(S, 182 - 32 + 8 * (n < 4 ? n : n + 1), L, z, n, tid FT_PASS);
+        fine_fscore(S, 182 - 32 + 8 * (n < 4 ? n : n + 1), L, zi, n, tid FT_PASS);
         FT(15);
     }
     __syncthreads();
     if (tid < 56) {                                            // (on, off) of symbol a of tweak n: the contract of the time scan, b ascending in fp64
         const int n = tid / 7, a = tid - 7 * n, c = d_COSTAS[a];
-        const float* mags = reinterpret_cast<const float*>(z + FS_MAG) + n * 56 + a * 8;
+        const float* mags = reinterpret_cast<const float*>(zi + FS_MAG) + n * 56 + a * 8;
         double off = 0.0, on = 0.0;
 #pragma unroll
         for (int b = 0; b < 7; b++) { const double m = (double)mags[b]; on = (b == c) ? m : on; off += (b == c) ? 0.0 : m; }
@@ -532,8 +549,8 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     // 100 = 10 x 10 (r = 10 r1 + r2, s = s1 + 10 s2): 80 lanes transform the ten r1 of their (tone, r2), twiddle, 80 lanes the ten r2 of their
     // (tone, s1).  No 3200-point transform, no symbol DFTs: 0.5 k instead of 1.4 k instructions per wave.
     const int tb = tb0 + tt;
-    cpx* Hc = z;                       // [8][100]
-    cpx* Ab = z + 800;                 // [8][10 s1][10 r2]
+    cpx* Hc = zi;                      // [8][100]
+    cpx* Ab = zi + 800;                // [8][10 s1][10 r2]
     {
         const int t = (tid < 80) ? tid / 10 : 0, c10 = (tid < 80) ? tid - 10 * t : 0;
         cpx tw[9];

@@ -509,15 +509,16 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     // 91-bit column set (bit `bitsel` of every ftab entry), then each of the 14 syndrome bits is a masked parity (d_SYNM)
     {
         const int bitsel = (lane < nflipA) ? lane : 63;
-        const bool up = bitsel >= 32;
-        const int sh = bitsel & 31;
+        const uint32_t sh = (uint32_t)bitsel & 31u;
+        // the lane reads only the 32-bit half of each entry that holds its bit (two addresses per read: both broadcast), then a
+        // v_bfe_u32 and a v_lshl_or_b32 per entry
+        const uint32_t* fh = reinterpret_cast<const uint32_t*>(ftab) + (bitsel >= 32 ? 1 : 0);
         uint32_t ra = 0, rb = 0, rc = 0;
 #pragma unroll 8
         for (int v = 0; v < 32; v++) {
-            const uint64_t a = ftab[v], b = ftab[32 + v], c = ftab[64 + (v < 27 ? v : 0)];
-            ra |= (((up ? (uint32_t)(a >> 32) : (uint32_t)a) >> sh) & 1u) << v;
-            rb |= (((up ? (uint32_t)(b >> 32) : (uint32_t)b) >> sh) & 1u) << v;
-            rc |= (((up ? (uint32_t)(c >> 32) : (uint32_t)c) >> sh) & 1u) << v;
+            ra |= __builtin_amdgcn_ubfe(fh[2 * v], sh, 1u) << v;
+            rb |= __builtin_amdgcn_ubfe(fh[2 * (32 + v)], sh, 1u) << v;
+            rc |= __builtin_amdgcn_ubfe(fh[2 * (64 + (v < 27 ? v : 0))], sh, 1u) << v;
         }
         rc &= (1u << 27) - 1;
         unsigned sy = 0;
