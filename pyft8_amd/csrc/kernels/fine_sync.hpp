@@ -394,12 +394,14 @@ FT8_DEV void fine_fscore(const cpx* S, int off, const FsLane& L, cpx* zi, int n,
         FT(19);
 #pragma unroll
         for (int s = 0; s < 7; s++) { acc[s].x = row16_sum(acc[s].x); acc[s].y = row16_sum(acc[s].y); }
-        if (t < 7 && c < 7) {
+        {   // every lane forms a magnitude and stores it -- lanes without one (c >= 7; tone 7) into the unused tone-7 slots: with the
+            // store under `if (t < 7 && c < 7)` the compiler sinks the last row-sum step into the branch, where the DPP operand can no
+            // longer be fused into the add (14 v_mov_dpp + 14 zero moves per tweak)
             cpx v = acc[0];
 #pragma unroll
             for (int s = 1; s < 7; s++) v = (c == s) ? acc[s] : v;
             const float re = v.x * FINE_INV, im = v.y * FINE_INV;
-            mags[c * 8 + t] = sqrtf(re * re + im * im);
+            mags[c < 7 ? c * 8 + t : 7] = sqrtf(re * re + im * im);
         }
     }
     FT(14);
@@ -487,6 +489,10 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         const int ti = valid ? qd / 7 : 0, a = valid ? qd - 7 * ti : 0;
         float mag[8];
         fine_sym_quad<7>(z, tb0 - 8 + 2 * ti + 32 * (36 + a), n2, wq, mag);
+        // the magnitudes are pinned in front of the branch: sunk into it (only the quad leaders use them), the quad sums lose their
+        // fused DPP operands (42 v_mov_dpp per round)
+#pragma unroll
+        for (int b = 0; b < 7; b++) asm volatile("" :: "v"(mag[b]));
         if (valid && n2 == 0) {
             const int c = d_COSTAS[a];
             double off = 0.0, on = 0.0;         // branch-free: adding +0.0 for the Costas tone leaves the running sum unchanged
