@@ -565,11 +565,15 @@ def main():
                     rendered[0] += int(_lib.package_packed(pk, n_threads=pk_threads)[1].sum())
         return _lib.package_batch(*view, n_threads=pk_threads)
 
-    def run_steps(n):
+    step_marks = []                     # host clock after every step's host side (the timed region fills it: where a slow run lost its time)
+
+    def run_steps(n, marks=None):
         for i in range(n):
             h.enqueue(d_audio.data_ptr(), B)
             if i > 0:
                 host_side(h.fetch_view(B))
+                if marks is not None:
+                    marks.append(time.perf_counter())
         out = host_side(h.fetch_view(B))
         if gather is not None:
             gather.drain()                  # the last batch's results have reached rank 0's host memory
@@ -578,13 +582,20 @@ def main():
     if args.warmup:
         run_steps(args.warmup)
     h.sync()
+    # the interpreter's cyclic collector stays out of the timed region (a full collection in the middle of a 60-ms region is a
+    # double-digit percentage of it): collect now, switch it off, back on afterwards
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
-    msgs_, mc_ = run_steps(args.steps)
+    msgs_, mc_ = run_steps(args.steps, step_marks)
     h.sync()
     dt_own = time.perf_counter() - t0          # this rank's own K steps (its gathers drained), before it meets the others
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    step_gaps = np.diff(np.array([t0] + step_marks)) * 1e3 if step_marks else np.zeros(1)
     # keep the GPU busy for --min-seconds in total (identical steps, not part of `value`): a 0.16-s timed region is invisible to
     # a GPU-activity sampler with a period of seconds
     extra_steps, extra_dt = 0, 0.0
@@ -771,6 +782,9 @@ def main():
             # this rank only (PCIe inclusive; `value` has the audio resident in HBM as the bench contract asks)
             "value_incl_h2d": pcie_pinned, "value_incl_h2d_sync_call": pcie_sync, "value_incl_h2d_sync_call_pageable": pcie,
             "extra_steps": extra_steps, "extra_steps_frames_per_s": (job_frames * extra_steps / extra_dt) if extra_steps else None,
+            # host-side gaps between consecutive steps of the timed region on rank 0 (the first one includes the pipeline fill)
+            "step_gap_ms": {"p50": float(np.median(step_gaps)), "p90": float(np.percentile(step_gaps, 90)), "max": float(step_gaps.max()),
+                            "argmax": int(step_gaps.argmax()), "over_2x_median": int((step_gaps > 2 * np.median(step_gaps)).sum())},
             "config": {"workload": f"{'config 1: ' if (B, args.signals, reference_knobs) == (256, 50, True) else ''}batch of {B} synthetic 15-s frames "
                                    f"per GPU ({data_desc}), {args.signals} signals/frame, {args.snr[0]:+.0f}..{args.snr[1]:+.0f} dB SNR, "
                                    f"{'Receiver defaults' if reference_knobs else 'extension knobs'} ({knobs})",

@@ -150,7 +150,7 @@ class PackedGather:
         ...                                          # (next enqueue / host message layer of this rank's own frames)
         parts = g.collect()                          # rank dst: [Packed of rank 0, rank 1, ...] of the oldest submitted batch; else None
 
-    No collective and no cross-rank rendezvous (round 5): a rank other than dst starts the point-to-point send of its buffer (RCCL
+    No collective and no cross-rank rendezvous per batch (round 5; the constructor holds the only one, _handshake): a rank other than dst starts the point-to-point send of its buffer (RCCL
     send on a side stream / gloo isend) and then drops one control message (batch number, byte count, overflow flag) into the process
     group's store -- it never waits for another rank's batch, only (two batches later, before the same buffer is packed again) for its
     OWN send to have been taken.  Rank dst looks into the mailbox whenever it is in submit() / collect() / drain() and posts the data
@@ -170,6 +170,7 @@ class PackedGather:
     MIN_ROW = 1 << 20          # smallest receive row rank dst allocates (bytes); tests lower it to reach the growth path with small frames
     TIMEOUT = 300.0           # seconds any wait may take before it raises instead of hanging (a peer died, a transport is stuck)
     TAG_DATA = 12
+    TAG_HELLO = 13
     _instances = 0             # PackedGathers constructed in this process: the mailbox prefix
 
     def __init__(self, handle, n_frames, dst=0, group=None, force=False, per_frame=None, repeat=1, depth=4):
@@ -221,6 +222,28 @@ class PackedGather:
                 if r != self.dst:
                     self.announced[r] = []
                     self.next_ctrl[r] = 0
+        self._handshake()
+
+    def _handshake(self):
+        """One tiny blocking send / recv per (peer, dst) pair, peers in rank order -- the only rendezvous of the object, at construction.
+        torch's NCCL backend creates a communicator per pair of ranks at their FIRST point-to-point call, and creating it is a
+        rendezvous of the two (the later one blocks the earlier one's host thread).  submit() starts its send BEFORE it announces it and
+        rank dst posts a receive only AFTER the announcement: left to the first batch, that first send would wait for a receive that is
+        never posted.  Here both sides call unconditionally, so the pair's communicator exists before the first batch and every later
+        isend / irecv is an asynchronous launch.  (gloo connects all pairs when the group is made; the same exchange runs there so that
+        the CPU tests walk this code.)"""
+        if not (self.active and self.world > 1):
+            return
+        dev = self.src[0].device if self.nccl else torch.device("cpu")
+        token = torch.zeros(64, dtype=torch.uint8, device=dev)
+        if self.rank == self.dst:
+            for r in range(self.world):
+                if r != self.dst:
+                    dist.recv(token, src=self._g(r), group=self.group, tag=self.TAG_HELLO)
+        else:
+            dist.send(token, dst=self._g(self.dst), group=self.group, tag=self.TAG_HELLO)
+        if self.nccl:
+            torch.cuda.current_stream().synchronize()
 
     # ---- plumbing
     def _set_output(self, p0, p1, cap, owners):
