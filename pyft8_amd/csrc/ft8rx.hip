@@ -521,7 +521,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     STAGE("topk");
     k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c, evc, wc, h->use_mask ? h->d_colmask + F * NF0MAX : nullptr);
     STAGE("grid_llr");
-    k_grid_llr<<<B * MAXC, 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr, att0, ev, evc);
+    k_grid_llr<<<XCD_GRID(B, MAXC), 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr, att0, ev, evc, B);
     k_worklist_att<<<(B * MAXC * 5 + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_BP0]);
     STAGE("bp_grid");
     k_bp<<<B * MAXC * 5, 64, 0, s>>>(0, llr0, rec, ncand, nullptr, att0, nullptr, ev, evc, c, c.bp_nc0_a, c.bp_iters_a, wl[WL_BP0], 0, 5);
@@ -998,7 +998,7 @@ int ft8rx_llr_grid(ft8rx_handle* h, const float* grid, int B, int n, const int32
     float* d_llr = S.get<float>((size_t)n * 174); NEED(d_llr);
     float* d_sd = S.get<float>(n); NEED(d_sd);
     int32_t* d_snr = S.get<int32_t>(n); NEED(d_snr);
-    k_grid_llr<<<n, 64, 0, h->stream>>>(h->d_grid, nullptr, nullptr, d_llr, h->cfg, d_trip, d_sd, d_snr, nullptr, nullptr, nullptr);
+    k_grid_llr<<<n, 64, 0, h->stream>>>(h->d_grid, nullptr, nullptr, d_llr, h->cfg, d_trip, d_sd, d_snr, nullptr, nullptr, nullptr, n);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(llr, d_llr, sizeof(float) * (size_t)n * 174, hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(sd, d_sd, sizeof(float) * n, hipMemcpyDeviceToHost));

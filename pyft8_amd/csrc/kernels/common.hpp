@@ -34,6 +34,17 @@ __device__ __constant__ uint8_t d_PAYSYM[58] = {7,8,9,10,11,12,13,14,15,16,17,18
 // order is whatever the atomics give -- every attempt writes its own result slot and the host sorts the event log, so results do
 // not depend on it.
 struct WorkList { int32_t* items; int32_t* count; };
+
+// XCD-aware block map for kernels whose blocks of one FRAME read the same memory (the frame's dB grid): consecutive workgroup ids go
+// round-robin over the 8 XCDs, each with an L2 of its own, so with the plain map (frame = id / per) the `per` blocks of a frame land on
+// all eight and every XCD fetches the frame's lines again.  Here workgroup id L -> XCD L % 8 takes frame 8 (j / per) + L % 8, block
+// j % per (j = L / 8): a frame's blocks share one L2.  Launch ((B + 7) / 8) * 8 * per blocks; false = no such frame (B % 8 != 0).
+FT8_DEV bool xcd_frame_map(int L, int per, int B, int& frame, int& idx) {
+    const int x = L & 7, j = L >> 3;
+    frame = 8 * (j / per) + x; idx = j % per;
+    return frame < B;
+}
+#define XCD_GRID(B, per) ((((B) + 7) / 8) * 8 * (per))
 enum { WL_BP0 = 0, WL_FINE = 1, WL_BP1 = 2, WL_BP1B = 3, WL_BP1C = 4, WL_OSD = 5, WL_OSDNAN = 6, WL_N = 7 };      // WL_BP0 lists attempts (x 5), WL_OSDNAN OSD attempts (x 10)
 
 #define W6 ((double)(-0.16666667163372040f))     /* np.float32(-1/6), receiver.py:323,198 */

@@ -660,8 +660,18 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
                                                   float* __restrict__ t_sd, float* __restrict__ t_sgrid, WorkList work) {
     if (trip) { fine_candidate(threadIdx.x, blockIdx.x, spec, rec, ncand, llr0, T, cfg, trip, t_out, t_sd, t_sgrid); return; }
     const int n = *work.count;
+    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, the list holds a frame's candidates next to each other,
+    // and their spectrum slices overlap -- so XCD x takes runs of FINE_RUN consecutive items (run = 8 k + x) and a frame's slices are
+    // fetched into one L2 instead of eight (the launch grid is a multiple of 8)
+#ifndef FINE_RUN
+#define FINE_RUN 256
+#endif
+    const int nu = (n + 8 * FINE_RUN - 1) / (8 * FINE_RUN) * (8 * FINE_RUN);
 #pragma unroll 1
-    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+    for (int u = blockIdx.x; u < nu; u += gridDim.x) {
+        const int x = u & 7, j = u >> 3;
+        const int item = (j / FINE_RUN) * (8 * FINE_RUN) + x * FINE_RUN + (j % FINE_RUN);
+        if (item >= n) continue;
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));                               // opaque per item: nothing thread-specific is hoisted across candidates (register pressure)
         fine_candidate(tid, work.items[item], spec, rec, ncand, llr0, T, cfg, nullptr, nullptr, nullptr, nullptr);

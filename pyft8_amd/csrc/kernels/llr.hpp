@@ -135,15 +135,17 @@ __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid,
                                                  const int32_t* __restrict__ ncand, float* __restrict__ llr0,
                                                  ft8rx_config cfg, const int32_t* __restrict__ trip, float* __restrict__ t_sd,
                                                  int32_t* __restrict__ t_snr, Att* __restrict__ att0, ft8rx_event* ev,
-                                                 int32_t* evcount) {
+                                                 int32_t* evcount, int B) {
     __shared__ float p[464];
     __shared__ float llr[174];
     __shared__ float sq[174];
     const int lane = threadIdx.x;
     int frame, ci, f0, h0;
+    size_t slot = blockIdx.x;                   // where this block's outputs go: the triple's index, or the candidate's
     if (trip) { frame = trip[3 * blockIdx.x]; f0 = trip[3 * blockIdx.x + 1]; h0 = trip[3 * blockIdx.x + 2]; ci = 0; }
     else {
-        frame = blockIdx.x / MAXC; ci = blockIdx.x % MAXC;
+        if (!xcd_frame_map(blockIdx.x, MAXC, B, frame, ci)) return;      // a frame's candidates gather from one XCD's L2
+        slot = (size_t)frame * MAXC + ci;
         if (ci >= ncand[frame]) return;
         const ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
         f0 = r.f0_idx; h0 = r.h0_idx;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid,
     __syncthreads();
     float sd; int snr;
     llr_from_p(p, llr, sq, lane, true, &sd, &snr);
-    float* out = llr0 + (size_t)blockIdx.x * 174;
+    float* out = llr0 + slot * 174;
     for (int i = lane; i < 174; i += 64) out[i] = llr[i];
     if (lane == 0) {
         if (trip) { t_sd[blockIdx.x] = sd; t_snr[blockIdx.x] = snr; }
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid,
         }
     }
     if (att0 && !(sd <= cfg.llr_sd_min))        // pipeline: the candidate stays ACTIVE -> pre-check its five ipass-0 attempts
-        bp0_precheck(lane, llr, cm, frame, ci, att0 + (size_t)blockIdx.x * 5, ev, evcount, cfg.bp_nc0_a, cfg.bp_iters_a);
+        bp0_precheck(lane, llr, cm, frame, ci, att0 + slot * 5, ev, evcount, cfg.bp_nc0_a, cfg.bp_iters_a);
 }
 #endif  // FT8RX_ILP_UNIT
 
