@@ -26,6 +26,10 @@ import time
 
 import numpy as np
 
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC: RCCL fails with hipIpcGetMemHandle otherwise);
+# the image exports it, a bare environment may not -- set before anything loads the HIP runtime
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

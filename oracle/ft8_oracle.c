@@ -69,8 +69,8 @@ float ft8o_log10f(float x) {
 }
 
 /* tanh: single-branch clamped rational x P(x^2) / Q(x^2) (odd degree 13 over even degree 6, the classic fast-tanh
- * coefficient set), <= 3.5e-7 relative error on the whole line, exactly +-1 beyond |x| ~ 7.9.  Replaces np.tanh
- * (decoders.py:142).  Plain mul/add in the written order, one IEEE division. */
+ * coefficient set) evaluated as x (P / Q), <= 3.5e-7 relative error on the whole line, exactly +-1 beyond |x| ~ 7.9.
+ * Replaces np.tanh (decoders.py:142).  Plain mul/add in the written order, one IEEE division. */
 float ft8o_tanhf(float x) {
     if (x != x) return x;
     float xc = x;
@@ -85,12 +85,13 @@ float ft8o_tanhf(float x) {
     p = fmaf(p, x2, 1.48572235717979e-05f);
     p = fmaf(p, x2, 6.37261928875436e-04f);
     p = fmaf(p, x2, 4.89352455891786e-03f);
-    p = p * xc;
     float q = 1.19825839466702e-06f;
     q = fmaf(q, x2, 1.18534705686654e-04f);
     q = fmaf(q, x2, 2.26843463243900e-03f);
     q = fmaf(q, x2, 4.89352518554385e-03f);
-    return p / q;
+    /* contract (round 5): the quotient first, then the multiplication by x -- the division's operands are then in
+     * [4.9e-3, 0.91] for every x, which lets the kernel drop the range repairs of its division sequence */
+    return xc * (p / q);
 }
 
 static inline cpx cmul(cpx a, cpx w) { cpx r; r.re = fmaf(a.re, w.re, -(a.im * w.im)); r.im = fmaf(a.re, w.im, a.im * w.re); return r; }

@@ -14,6 +14,22 @@ typedef float2 cpx;
 #define FT8_DEV __device__ __forceinline__
 
 // ------------------------------------------------------------------------------------ elementary math
+// a / b, correctly rounded, for operands that need none of the range repairs of the compiler's division: b finite and normal with
+// 2^-32 <= |b| <= 2^32, a = 0 or normal with |a| in the same range (or either one NaN).  It IS the compiler's sequence
+// (v_rcp_f32, two Newton steps on the reciprocal, the quotient and two residual corrections) without the v_div_scale pair that rescales
+// denormal / huge operands, with a plain fma where v_div_fmas would apply that scale, and without v_div_fixup (infinities, zero
+// divisors): for these operands all three are identities, so the value is the IEEE quotient the CPU oracle gets from `/` -- 8
+// instructions instead of 11 and no VCC hazard.
+FT8_DEV float ft8_div_inrange(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = a * r;
+    e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e, r, q);
+}
 FT8_DEV float ft8_log10f(float x) {
     if (!(x > 0.0f)) return (x == 0.0f) ? -__builtin_inff() : __builtin_nanf("");
     if (x > 3.0e38f) return __builtin_inff();
@@ -23,7 +39,7 @@ FT8_DEV float ft8_log10f(float x) {
     e += (int)(ix >> 23) - 127;
     float m = __uint_as_float((ix & 0x007fffffu) | 0x3f800000u);
     if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
-    float s = (m - 1.0f) / (m + 1.0f);
+    float s = ft8_div_inrange(m - 1.0f, m + 1.0f);        // |m - 1| = 0 or in [2^-24, 0.42], m + 1 in [1.7, 2.42]
     float s2 = s * s;
     float p = 0.11111111f;                              // contract: Horner steps and the final combination as named fmas
     p = __builtin_fmaf(p, s2, 0.14285715f);
@@ -43,7 +59,7 @@ FT8_DEV float ft8_log10f_normal(float x) {
     float m = __uint_as_float((ix & 0x007fffffu) | 0x3f800000u);
     const bool big = m > 1.41421356f;
     m = big ? m * 0.5f : m; e += big ? 1 : 0;
-    float s = (m - 1.0f) / (m + 1.0f);
+    float s = ft8_div_inrange(m - 1.0f, m + 1.0f);        // |m - 1| = 0 or in [2^-24, 0.42], m + 1 in [1.7, 2.42]
     float s2 = s * s;
     float p = 0.11111111f;                              // contract: Horner steps and the final combination as named fmas
     p = __builtin_fmaf(p, s2, 0.14285715f);
@@ -55,11 +71,14 @@ FT8_DEV float ft8_log10f_normal(float x) {
     return __builtin_fmaf(fe, 0.301025390625f, __builtin_fmaf(fe, 4.6050390e-6f, lnm * 0.4342945f));
 }
 
-// single-branch clamped rational (no divergence inside a wavefront): x P(x^2) / Q(x^2), one IEEE division
+// single-branch clamped rational (no divergence inside a wavefront): x (P(x^2) / Q(x^2)), one IEEE division.  The quotient is formed
+// BEFORE the multiplication by x (contract, round 5): P in [4.9e-3, 0.115], Q in [4.9e-3, 0.91] for every x, so the division never
+// needs the range repairs that a numerator P x (tiny for tiny x) would -- see ft8_div_inrange.
 FT8_DEV float ft8_tanhf(float x) {
-    float xc = x;                    // NaN fails both clamps and propagates through P / Q (the oracle returns x itself: same NaN-ness)
-    if (xc > 7.90531111f) xc = 7.90531111f;
-    if (xc < -7.90531111f) xc = -7.90531111f;
+    // clamp = the median of (x, -c, c): one instruction, the sign of a zero survives; a NaN does not (v_med3_f32 returns a number),
+    // so the NaN argument is put back at the end (the oracle returns x itself: same NaN-ness) -- three instructions where two
+    // compare-and-select pairs took four
+    const float xc = __builtin_amdgcn_fmed3f(x, -7.90531111f, 7.90531111f);
     const float x2 = xc * xc;
     float p = -2.76076847742355e-16f;                   // contract: Horner steps as named fmas
     p = __builtin_fmaf(p, x2, 2.00018790482477e-13f);
@@ -68,12 +87,12 @@ FT8_DEV float ft8_tanhf(float x) {
     p = __builtin_fmaf(p, x2, 1.48572235717979e-05f);
     p = __builtin_fmaf(p, x2, 6.37261928875436e-04f);
     p = __builtin_fmaf(p, x2, 4.89352455891786e-03f);
-    p = p * xc;
     float q = 1.19825839466702e-06f;
     q = __builtin_fmaf(q, x2, 1.18534705686654e-04f);
     q = __builtin_fmaf(q, x2, 2.26843463243900e-03f);
     q = __builtin_fmaf(q, x2, 4.89352518554385e-03f);
-    return p / q;
+    const float t = xc * ft8_div_inrange(p, q);
+    return (x != x) ? x : t;
 }
 
 // ------------------------------------------------------------------------------------ complex helpers / DFT primitives

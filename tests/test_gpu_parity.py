@@ -43,10 +43,18 @@ def test_native_library_loaded():
 
 def test_elementary_functions_bit_exact(H):
     rng = np.random.default_rng(0)
-    x = np.concatenate([np.logspace(-38, 38, 20001), rng.uniform(0.5, 2.0, 20000), [0.0, 1.0, 1e-45, 3.4e38]]).astype(np.float32)
+    x = np.concatenate([np.logspace(-38, 38, 200001), rng.uniform(0.5, 2.0, 200000), [0.0, 1.0, 1e-45, 3.4e38],
+                        np.nextafter(np.float32(1.0), np.float32([0.0, 2.0])), np.float32(2.0) ** np.arange(-126, 128)]).astype(np.float32)
     assert bits_equal(H.math_probe(0, x), O.log10f(x))
-    t = np.concatenate([rng.uniform(-12, 12, 40000), rng.standard_normal(20000) * 1e-3, [0.0, -0.0, 1.0, -1.0, 50.0, -50.0, np.nan, np.inf, -np.inf]]).astype(np.float32)
-    assert bits_equal(H.math_probe(1, t), O.tanhf(t))
+    # (the kernel's divisions run without the compiler's range repairs, ft8_div_inrange: the tanh quotient P / Q has operands in
+    # [4.9e-3, 0.91] whatever x is -- tiny, denormal, huge and special arguments included here)
+    t = np.concatenate([rng.uniform(-12, 12, 400000), rng.standard_normal(20000) * 1e-3, np.logspace(-44, 1, 4001), -np.logspace(-44, 1, 4001),
+                        [0.0, -0.0, 1.0, -1.0, 50.0, -50.0, 1e-45, -1e-45, 1.2e-38, 3e38, -3e38, 7.90531111, np.nextafter(np.float32(7.90531111), np.float32(8)),
+                         np.nan, np.inf, -np.inf]]).astype(np.float32)
+    got, want = H.math_probe(1, t), O.tanhf(t)
+    assert bits_equal(got, want)
+    z = t == 0
+    assert np.array_equal(np.signbit(got[z]), np.signbit(t[z]))          # tanh(-0.0) = -0.0
 
 
 def test_fft_bit_exact(H, ocfg):
