@@ -31,6 +31,7 @@ def main():
     n = 0
     rss0 = None
     dev = None
+    trend = []
     while time.time() - t0 < budget:
         B = int(rng.choice([1, 2, 7, 8, 16, 33, 48]))
         ns = int(rng.choice([1, 2, 4, 8]))
@@ -64,10 +65,14 @@ def main():
         n += 1
         if n == 50:
             rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        if n % 5000 == 0:                              # the trend, not only the end points: a leak grows linearly, an allocator's high-water mark does not
+            with open("/proc/self/statm") as f:
+                trend.append((n, int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") // 1024))
     rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     with open("/proc/self/statm") as f:
         cur = int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") // 1024
     print(f"{n} decode calls in {time.time() - t0:.0f} s, all identical to the first pass; max RSS after 50 calls {rss0} kB, at the end {rss1} kB (resident now: {cur} kB)")
+    print("resident kB every 5000 calls:", " ".join(f"{k}" for _, k in trend))
     assert rss0 is None or rss1 < rss0 * 1.2 + 50000
 
 
