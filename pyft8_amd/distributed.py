@@ -236,12 +236,13 @@ class PackedGather:
             return
         dev = self.src[0].device if self.nccl else torch.device("cpu")
         token = torch.zeros(64, dtype=torch.uint8, device=dev)
+        kw = {} if self.nccl else {"tag": self.TAG_HELLO}          # (the NCCL backend has no tags)
         if self.rank == self.dst:
             for r in range(self.world):
                 if r != self.dst:
-                    dist.recv(token, src=self._g(r), group=self.group, tag=self.TAG_HELLO)
+                    dist.recv(token, src=self._g(r), group=self.group, **kw)
         else:
-            dist.send(token, dst=self._g(self.dst), group=self.group, tag=self.TAG_HELLO)
+            dist.send(token, dst=self._g(self.dst), group=self.group, **kw)
         if self.nccl:
             torch.cuda.current_stream().synchronize()
 
