@@ -19,7 +19,68 @@
 #include <vector>
 #include <thread>
 #include <unordered_map>
+#include <condition_variable>
+#include <functional>
+#include <unistd.h>
 namespace hostmsg {
+// Persistent worker threads of the packaging entry points.  Creating and joining n std::threads per call was ~1 ms of the 1.2 ms a
+// 256-frame batch took at 32 threads (and, with one process per GPU, tens of thousands of thread creations per second on the host).
+// run(n, fn) executes fn on up to n threads -- the caller and pool threads 1 .. n - 1 (created on first need, detached, parked on a
+// condition variable between calls); fn must hand out its own work (an atomic counter) and return when none is left.  The caller
+// returns when its own fn has returned and every pool thread that ENTERED fn has left it: a pool thread that wakes up late (a loaded
+// host) finds the run closed and is not waited for.  One run at a time per process; the state is never freed (threads may still be
+// parked on it at exit) and is rebuilt in a forked child, whose copy of it has no threads behind it.
+class HostPool {
+    struct State {
+        std::mutex run_m, m;
+        std::condition_variable cv_go, cv_done;
+        const std::function<void(int)>* job = nullptr;
+        int n_threads = 0, job_n = 0, entered = 0, exited = 0;
+        bool open = false;
+        uint64_t gen = 0;
+        pid_t pid = 0;
+    };
+    static State*& state() { static State* st = nullptr; return st; }
+    static void worker(State* st, int idx) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(st->m);
+        for (;;) {
+            st->cv_go.wait(lk, [&] { return st->gen != seen; });
+            seen = st->gen;
+            if (st->open && idx < st->job_n) {
+                const std::function<void(int)>* j = st->job;
+                st->entered++;
+                lk.unlock();
+                (*j)(idx);
+                lk.lock();
+                if (++st->exited == st->entered) st->cv_done.notify_one();
+            }
+        }
+    }
+public:
+    static void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 1) { fn(0); return; }
+        static std::mutex create_m;
+        State* st;
+        {
+            std::lock_guard<std::mutex> g(create_m);
+            if (!state() || state()->pid != getpid()) { state() = new State; state()->pid = getpid(); }
+            st = state();
+        }
+        std::lock_guard<std::mutex> g(st->run_m);
+        {
+            std::unique_lock<std::mutex> lk(st->m);
+            while (st->n_threads < n - 1) { const int idx = ++st->n_threads; std::thread(worker, st, idx).detach(); }
+            st->job = &fn; st->job_n = n; st->entered = st->exited = 0; st->open = true; st->gen++;
+        }
+        st->cv_go.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(st->m);
+        st->open = false;                                           // nobody enters from here on
+        st->cv_done.wait(lk, [&] { return st->exited == st->entered; });
+        st->job = nullptr; st->job_n = 0;
+    }
+};
 // optional reject log: the reference appends every call that fails simple_validate_call to 'rejected_callsigns.txt' in the
 // working directory (decoders.py:114-115).  Off by default; ft8rx_set_reject_log(path) turns it on for the process.
 static std::string g_reject_log;
@@ -275,9 +336,10 @@ static int package_batch(const ft8rx_record* records, const int32_t* counts, con
     if (!records || !counts || !events || !event_counts || !out || !out_counts || n_frames < 1 || max_cands < 1 || max_msgs < 1) return -1;
     if (n_threads < 1 || table) n_threads = 1;
     if (n_threads > n_frames) n_threads = n_frames;
-    auto work = [&](int t) {
+    std::atomic<int> next{0};                                     // frames are handed out one by one: they differ in length
+    auto work = [&](int) {
         Hashes local;                                             // one table per worker, emptied for every frame
-        for (int f = t; f < n_frames; f += n_threads) {
+        for (int f = next.fetch_add(1, std::memory_order_relaxed); f < n_frames; f = next.fetch_add(1, std::memory_order_relaxed)) {
             int fl = 0;
             int nev = event_counts[f];
             if (nev > FT8RX_EVENT_CAP) { nev = FT8RX_EVENT_CAP; fl |= FT8RX_PKG_EVENTS_TRUNCATED; }
@@ -289,10 +351,7 @@ static int package_batch(const ft8rx_record* records, const int32_t* counts, con
             if (flags) flags[f] = fl;
         }
     };
-    if (n_threads == 1) { work(0); return 0; }
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_threads; t++) pool.emplace_back(work, t);
-    for (auto& th : pool) th.join();
+    HostPool::run(n_threads, work);
     return 0;
 }
 // The same from a packed result buffer (header | frame table | kept records | used events; include/ft8rx.h): frames
@@ -317,9 +376,10 @@ static int package_packed(const void* packed, uint64_t bytes, int frame_lo, int 
     }
     if (n_threads < 1 || table) n_threads = 1;
     if (n_threads > n_frames) n_threads = n_frames;
-    auto work = [&](int th) {
+    std::atomic<int> next{0};
+    auto work = [&](int) {
         Hashes local;
-        for (int i = th; i < n_frames; i += n_threads) {
+        for (int i = next.fetch_add(1, std::memory_order_relaxed); i < n_frames; i = next.fetch_add(1, std::memory_order_relaxed)) {
             const ft8rx_packed_frame& t = tab[frame_lo + i];
             int fl = 0, nev = t.n_ev < 0 ? 0 : t.n_ev;
             if (nev > FT8RX_EVENT_CAP) { nev = FT8RX_EVENT_CAP; fl |= FT8RX_PKG_EVENTS_TRUNCATED; }
@@ -329,10 +389,7 @@ static int package_packed(const void* packed, uint64_t bytes, int frame_lo, int 
             if (flags) flags[i] = fl;
         }
     };
-    if (n_threads == 1) { work(0); return 0; }
-    std::vector<std::thread> pool;
-    for (int th = 0; th < n_threads; th++) pool.emplace_back(work, th);
-    for (auto& th : pool) th.join();
+    HostPool::run(n_threads, work);
     return 0;
 }
 // Multi-pass decoding (extension): append the messages of a later pass that are new for their frame.
