@@ -313,6 +313,66 @@ def test_native_packager_throughput():
     assert B / dt > 3000, f"native packager only {B / dt:.0f} frames/s on one thread"
 
 
+def test_native_packager_worker_pool_thread_counts_and_concurrent_callers():
+    """The packaging entry points run on a persistent worker pool (host_messages.hpp: HostPool): the result does not depend on the thread
+    count, the pool grows and shrinks between calls, callers on several Python threads (ctypes releases the GIL) are serialised, and a
+    child process that imported after a fork-free spawn builds its own pool (covered by the gloo tests, which package in every rank)."""
+    import threading
+    from pyft8_amd import _lib
+    audio, gold, js = load_golden("synth_000000")
+    rec, n, ev, nev = records_from_oracle(oracle_frame(audio))
+    evp = np.zeros(_lib.EVENT_CAP, _lib.EVENT_DTYPE); evp[:len(ev)] = ev
+    B = 97
+    recs = np.stack([rec] * B); evs = np.stack([evp] * B)
+    cnt = np.full(B, n, np.int32); evc = np.full(B, nev, np.int32)
+    cnt[::7] = 0; evc[::5] = 0                                     # uneven frames: the pool hands frames out one by one
+    want, wc = _lib.package_batch(recs, cnt, evs, evc, n_threads=1)
+    for nt in (2, 32, 3, 64, 1, 8):
+        got, gc_ = _lib.package_batch(recs, cnt, evs, evc, n_threads=nt)
+        assert np.array_equal(gc_, wc) and got.tobytes() == want.tobytes(), nt
+    errs = []
+
+    def caller(k):
+        try:
+            for i in range(40):
+                got, gc_ = _lib.package_batch(recs, cnt, evs, evc, n_threads=(4, 16, 7, 32)[(k + i) % 4])
+                assert np.array_equal(gc_, wc) and got.tobytes() == want.tobytes()
+        except Exception as e:                                      # noqa: BLE001
+            errs.append(repr(e))
+    ths = [threading.Thread(target=caller, args=(k,)) for k in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not errs and not any(t.is_alive() for t in ths), errs
+
+
+def test_native_packager_worker_pool_survives_fork(tmp_path):
+    """A forked child has the parent's pool object but none of its threads: the pool notices the new pid and starts its own
+    (os.fork in a process of its own: the pytest process has other threads)."""
+    script = tmp_path / "fork_pool.py"
+    script.write_text(f'''
+import os, sys, signal
+import numpy as np
+sys.path.insert(0, {ROOT!r})
+from pyft8_amd import _lib
+B = 64
+rec = np.zeros((B, 8), _lib.RECORD_DTYPE); ev = np.zeros((B, _lib.EVENT_CAP), _lib.EVENT_DTYPE)
+cnt = np.zeros(B, np.int32); evc = np.zeros(B, np.int32)
+want = _lib.package_batch(rec, cnt, ev, evc, n_threads=8)[1].tobytes()          # the parent's pool exists now
+pid = os.fork()
+if pid == 0:
+    signal.alarm(30)                                                            # a child waiting for threads it does not have dies here
+    ok = _lib.package_batch(rec, cnt, ev, evc, n_threads=8)[1].tobytes() == want
+    os._exit(0 if ok else 3)
+_, status = os.waitpid(pid, 0)
+assert _lib.package_batch(rec, cnt, ev, evc, n_threads=8)[1].tobytes() == want  # the parent's pool is untouched
+sys.exit(0 if os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0 else 4)
+''')
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+
+
 def test_ragged_and_invalid_frames():
     """Host-side input handling: short frames are padded with silence, bad input raises Ft8rxError (no asserts, no UB)."""
     from pyft8_amd import _lib
