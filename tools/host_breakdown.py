@@ -43,7 +43,8 @@ def main():
     print(f"kernels only: {1e3 * dt / steps:.3f} ms/step; host time to enqueue one batch {1e3 * (t1 - t0) / steps:.3f} ms")
     # package alone on one fetched batch
     v = h.fetch(B)
-    for nt in (32, 16, 8, 4, 1):
+    for nt in (64, 48, 32, 16, 8, 4, 1):
+        _lib.package_batch(*v, n_threads=nt)
         t0 = time.perf_counter()
         for _ in range(20):
             _lib.package_batch(*v, n_threads=nt)
