@@ -404,6 +404,9 @@ def main():
                     "4 = 2048 frames per GPU (16 384 over 8), <= 10 signals at -24..-20 dB, OSD order 3 over 30 positions with the distance gate at 32")
     ap.add_argument("--osd3", type=int, default=None, help="extension knob: OSD order-3 depth (triple flips over the first N basis positions; 0 = off)")
     ap.add_argument("--osd-max-hd", type=int, default=None, help="extension knob: accept an OSD trial only within this Hamming distance of the hard decisions (0 = off)")
+    ap.add_argument("--queue-depth", type=int, default=2, choices=(1, 2), help="batches queued on the GPU behind the one that computes: 2 = "
+                    "results are copied out of their slot and the slot is re-enqueued before the batch is packaged (absorbs host-side delays "
+                    "of up to a step); 1 = the round-4 loop (views of the result slot, one batch queued)")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="after the K timed steps keep stepping (untimed for `value`, reported as "
                     "extra_steps) until the GPU has been busy this long, so that coarse GPU-activity samplers see the run")
     args = ap.parse_args()
@@ -558,7 +561,7 @@ def main():
             gather = None
     rendered = [0]
 
-    def host_side(view):
+    def gather_side():
         if args.delay_rank is not None and rank == args.delay_rank:
             time.sleep(args.delay_ms * 1e-3)
         if gather is not None:
@@ -567,18 +570,40 @@ def main():
                 parts = gather.collect() if gather.outstanding() > 1 else None      # the batch before: its gather has landed
                 for pk in parts or []:
                     rendered[0] += int(_lib.package_packed(pk, n_threads=pk_threads)[1].sum())
+
+    def host_side(view):
+        gather_side()
         return _lib.package_batch(*view, n_threads=pk_threads)
 
     step_marks = []                     # host clock after every step's host side (the timed region fills it: where a slow run lost its time)
 
     def run_steps(n, marks=None):
-        for i in range(n):
-            h.enqueue(d_audio.data_ptr(), B)
-            if i > 0:
-                host_side(h.fetch_view(B))
-                if marks is not None:
+        if args.queue_depth < 2:
+            # one batch queued behind the one that computes: while batch i computes the host fetches and packages batch i - 1
+            # (views of the handle's page-locked result buffers, no copy)
+            for i in range(n):
+                h.enqueue(d_audio.data_ptr(), B)
+                if i > 0:
+                    host_side(h.fetch_view(B))
+                    if marks is not None:
+                        marks.append(time.perf_counter())
+            out = host_side(h.fetch_view(B))
+        else:
+            # two batches queued: the results of batch i are COPIED out of their slot (ft8rx_fetch_results), its gather is started, and
+            # batch i + 2 is enqueued into that slot before batch i is packaged -- the GPU always has a whole batch waiting behind the
+            # one that computes, so a host-side delay of up to one step (a loaded host: the packaging threads or this thread lose
+            # their CPUs for milliseconds) no longer idles it
+            out = None
+            for i in range(min(2, n)):
+                h.enqueue(d_audio.data_ptr(), B)
+            for i in range(n):
+                res = h.fetch(B)
+                gather_side()               # (before the enqueue: the pack kernels of batch i + 2 wait for this send through the fence)
+                if i + 2 < n:
+                    h.enqueue(d_audio.data_ptr(), B)
+                out = _lib.package_batch(*res, n_threads=pk_threads)
+                if marks is not None and i + 1 < n:
                     marks.append(time.perf_counter())
-        out = host_side(h.fetch_view(B))
         if gather is not None:
             gather.drain()                  # the last batch's results have reached rank 0's host memory
         return out
@@ -794,7 +819,7 @@ def main():
                                    f"{'Receiver defaults' if reference_knobs else 'extension knobs'} ({knobs})",
                        "frames_per_gpu": B, "decoded_candidates_per_frame": n_dec / B,
                        "unique_messages_first16": n_msgs, "messages_per_frame": float(mc_.mean()),
-                       "kernel_only_frames_per_s_this_rank": kernel_only, "host_message_threads": pk_threads,
+                       "kernel_only_frames_per_s_this_rank": kernel_only, "host_message_threads": pk_threads, "queue_depth": args.queue_depth,
                        "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "host_pointer_sync_entry_frames_per_s_pageable": pcie, "host_pointer_sync_entry_frames_per_s_pinned": pcie_sync,
                        "host_pointer_pipelined_entry_frames_per_s_pinned": pcie_pinned, "parallelism": f"frames sharded over {world} GPU(s), no collective on the decode path", "gather": gather_note},
