@@ -575,6 +575,7 @@ def main():
         gather_side()
         return _lib.package_batch(*view, n_threads=pk_threads)
 
+    reuse = {}                          # result / message arrays of the two-deep loop, allocated by its first step
     step_marks = []                     # host clock after every step's host side (the timed region fills it: where a slow run lost its time)
 
     def run_steps(n, marks=None):
@@ -597,11 +598,13 @@ def main():
             for i in range(min(2, n)):
                 h.enqueue(d_audio.data_ptr(), B)
             for i in range(n):
-                res = h.fetch(B)
+                res = h.fetch(B, out=reuse.get("res"))        # (into the same arrays every step: no 10 MB of allocation, first-touch
+                reuse["res"] = res                             #  faults and unmapping per 3-ms step under 64 threads)
                 gather_side()               # (before the enqueue: the pack kernels of batch i + 2 wait for this send through the fence)
                 if i + 2 < n:
                     h.enqueue(d_audio.data_ptr(), B)
-                out = _lib.package_batch(*res, n_threads=pk_threads)
+                reuse["msg"] = _lib.package_batch(*res, n_threads=pk_threads, return_flags=True, out=reuse.get("msg"))
+                out = reuse["msg"][:2]
                 if marks is not None and i + 1 < n:
                     marks.append(time.perf_counter())
         if gather is not None:

@@ -296,8 +296,15 @@ class Handle:
     def sync(self):
         self._chk(self._L.ft8rx_sync(self._h), "ft8rx_sync")
 
-    def fetch(self, B):
-        rec, cnt, ev, evc = self._alloc_out(B)
+    def fetch(self, B, out=None):
+        """ft8rx_fetch_results: the oldest unfetched batch's results, copied into fresh arrays -- or into `out` = a (rec, cnt, ev, evc)
+        tuple an earlier call returned (a loop that fetches every few milliseconds then allocates nothing; event entries beyond
+        the counts are stale in a reused set)."""
+        rec, cnt, ev, evc = out if out is not None else self._alloc_out(B)
+        if out is not None and (rec.shape != (B, self.cfg.max_cands) or ev.shape != (B, EVENT_CAP) or rec.dtype != RECORD_DTYPE or ev.dtype != EVENT_DTYPE
+                                or cnt.shape != (B,) or evc.shape != (B,) or cnt.dtype != np.int32 or evc.dtype != np.int32
+                                or not all(a.flags.c_contiguous and a.flags.writeable for a in (rec, cnt, ev, evc))):
+            raise Ft8rxError("fetch: `out` is not a result set of this handle and batch size")
         rc = self._L.ft8rx_fetch_results(self._h, int(B), rec.ctypes.data_as(C.c_void_p), _ptr(cnt, C.c_int32),
                                        ev.ctypes.data_as(C.c_void_p), _ptr(evc, C.c_int32))
         self._chk(rc, "ft8rx_fetch_results")
@@ -653,11 +660,13 @@ def _warn_truncation(flags, who):
                       f"message list truncated in {nmsg} frame(s)", Ft8rxTruncationWarning, stacklevel=3)
 
 
-def package_batch(rec, cnt, ev, evc, max_msgs=None, n_threads=None, table=None, return_flags=False):
+def package_batch(rec, cnt, ev, evc, max_msgs=None, n_threads=None, table=None, return_flags=False, out=None):
     """Native host message layer (ft8rx_package_batch): records/events of B frames -> (messages[B, max_msgs], counts[B]).
     Pure host code: works without a GPU.  max_msgs defaults to the record capacity (so the list cannot be truncated); table = a
     CallHashTable shared by the frames in order (streaming) instead of a fresh table per frame.  An overflowed event log or
-    message list raises Ft8rxTruncationWarning (warnings module) and is reported per frame in the flags (return_flags=True)."""
+    message list raises Ft8rxTruncationWarning (warnings module) and is reported per frame in the flags (return_flags=True).
+    out = the (messages, counts, flags) arrays of an earlier call with return_flags=True: written in place instead of fresh arrays
+    (message slots beyond the counts are stale then)."""
     rec = np.ascontiguousarray(rec)
     ev = np.ascontiguousarray(ev)
     cnt = np.ascontiguousarray(cnt, np.int32)
@@ -667,9 +676,15 @@ def package_batch(rec, cnt, ev, evc, max_msgs=None, n_threads=None, table=None, 
         raise Ft8rxError("package_batch: records/events are not the arrays returned by decode_batch/fetch")
     if max_msgs is None:
         max_msgs = max(mc, 1)
-    out = np.zeros((B, max_msgs), MESSAGE_DTYPE)
-    oc = np.zeros(B, np.int32)
-    flags = np.zeros(B, np.int32)
+    if out is not None:
+        out, oc, flags = out
+        if (out.shape != (B, max_msgs) or out.dtype != MESSAGE_DTYPE or oc.shape != (B,) or oc.dtype != np.int32 or flags.shape != (B,)
+                or flags.dtype != np.int32 or not all(a.flags.c_contiguous and a.flags.writeable for a in (out, oc, flags))):
+            raise Ft8rxError("package_batch: `out` does not fit this batch")
+    else:
+        out = np.zeros((B, max_msgs), MESSAGE_DTYPE)
+        oc = np.zeros(B, np.int32)
+        flags = np.zeros(B, np.int32)
     if n_threads is None:
         n_threads = min(32, os.cpu_count() or 1)
     L = lib()

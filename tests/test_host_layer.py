@@ -330,6 +330,13 @@ def test_native_packager_worker_pool_thread_counts_and_concurrent_callers():
     for nt in (2, 32, 3, 64, 1, 8):
         got, gc_ = _lib.package_batch(recs, cnt, evs, evc, n_threads=nt)
         assert np.array_equal(gc_, wc) and got.tobytes() == want.tobytes(), nt
+    # written in place into the arrays of an earlier call: the same counts and the same used messages (slots beyond the counts are stale)
+    held = _lib.package_batch(recs, cnt[::-1].copy(), evs, evc, n_threads=8, return_flags=True)
+    again = _lib.package_batch(recs, cnt, evs, evc, n_threads=8, return_flags=True, out=held)
+    assert again[0] is held[0] and np.array_equal(again[1], wc)
+    assert all(again[0][f, :wc[f]].tobytes() == want[f, :wc[f]].tobytes() for f in range(B))
+    with pytest.raises(_lib.Ft8rxError):
+        _lib.package_batch(recs[:5], cnt[:5], evs[:5], evc[:5], return_flags=True, out=held)
     errs = []
 
     def caller(k):
