@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle parity sweep (GPU box): many frames with random recipes and Receiver kwargs / decoder knobs, every
 candidate record and every rendered message compared with the CPU oracle (oracle/ = the checker; nothing here is product code).
-Usage: python tools/parity_sweep.py [n_batches] [frames_per_batch]  -> one line per batch, a summary at the end"""
+Usage: python tools/parity_sweep.py [n_batches] [frames_per_batch] [seed] [first_frame_index]  -> one line per batch, a summary at the end"""
 import os
 import sys
 import time
@@ -82,7 +82,9 @@ def run_sweep(nb=20, fpb=16, seed=20260102, kw_list=None, first_index=9000000, v
 def main():
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     fpb = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-    tot = run_sweep(nb, fpb)
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 20260102              # other frames and recipes: another seed / first frame index
+    first = int(sys.argv[4]) if len(sys.argv) > 4 else 9000000
+    tot = run_sweep(nb, fpb, seed=seed, first_index=first)
     print(f"{tot['frames']} frames, {tot['cands']} candidate records, {tot['msgs']} messages: {tot['bad']} frames differ from the oracle "
           f"({tot['seconds']:.0f} s)")
     sys.exit(1 if tot["bad"] else 0)
