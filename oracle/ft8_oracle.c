@@ -604,8 +604,8 @@ static float fine_fscore(const float* spec, int fb, int nb0) {
  *                                       T[s1 + 10 s2] = DFT10_{r2}(A[r2][s1])[s2]
  * DFT10 (forward) by the prime-factor map: a0[n] = x[2n mod 10] + x[(5 + 2n) mod 10], a1[n] = their difference, n = 0 .. 4; dft5 of both;
  * y[6 k mod 10] = a0[k], y[(5 + 6 k) mod 10] = a1[k].  Magnitude: re = T.re * (1/3200), im = T.im * (1/3200), sqrtf(re re + im im).
- * The reference clamps a symbol's first sample to [0, 3168] (receiver.py:189-195: fine_symbol above): every symbol with tb + 32 s < 0
- * reads the samples 0 .. 31, every one with tb + 32 s > 3168 the samples 3168 .. 3199.  Those get the grid row of position p = 0 / 3168:
+ * The reference clamps a symbol's first sample to [0, 3168] (receiver.py:189-195: fine_symbol above): every symbol with tb + 32 s <= 0
+ * reads the samples 0 .. 31, every one with tb + 32 s >= 3168 the samples 3168 .. 3199.  Those get the grid row of position p = 0 / 3168:
  * H with nb0 = p, |T[t]| = 1/3200 |sum_r H[t][r]| as 16 partial sums over r = c, c + 16, ... combined as the binary tree of fine_fscore. */
 static void fscore_H(const cpx* S, int fb, int nb0, int ntone, cpx H[8][100]) {
     const cpx* W = get_twiddle(3200);
@@ -666,6 +666,11 @@ static void fine_grid_freq(const float* spec, int fb, int tb, float* g /*[79][8]
     int s_lo = 0, s_hi = 78;
     while (s_lo <= 78 && tb + 32 * s_lo < 0) s_lo++;                 /* symbols 0 .. s_lo - 1 read position 0 */
     while (s_hi >= 0 && tb + 32 * s_hi > 3168) s_hi--;               /* symbols s_hi + 1 .. 78 read position 3168 */
+    /* A symbol that starts exactly AT the clamp position reads the very samples the clamped ones read (clip() returns the same index):
+     * in the reference its row is bit-identical to theirs, and osd_012's argsort sees exact |LLR| ties between them.  So whenever some
+     * symbol lies strictly beyond, the boundary symbol takes the clamp row too; alone, it is an ordinary symbol (nothing to tie with). */
+    if (s_lo > 0 && s_lo <= 78 && tb + 32 * s_lo == 0) s_lo++;
+    if (s_hi < 78 && s_hi >= 0 && tb + 32 * s_hi == 3168) s_hi--;
     for (int side = 0; side < 2; side++) {
         if (side == 0 ? (s_lo == 0) : (s_hi == 78)) continue;
         fscore_H(S, fb, side == 0 ? 0 : 3168, 8, H);

@@ -592,8 +592,11 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
     }
     // the reference clamps a symbol's first sample to [0, 3168]: the symbols before sample 0 all read the samples 0 .. 31, symbol 78 beyond
     // 3168 the last 32 -- their rows are the row of that position (block-uniform; a candidate has at most one of the two)
-    const int n_lo = (tb < 0) ? min(79, (31 - tb) / 32) : 0;        // symbols 0 .. n_lo - 1 start before sample 0
-    const int s_up = (tb > 3168) ? 0 : min(79, (3168 - tb) / 32 + 1);  // symbols s_up .. 78 start beyond sample 3168 (default search range: at most symbol 78)
+    // A symbol that starts exactly AT a clamp position reads the same samples as the clamped ones (bit-identical rows in the reference:
+    // exact |LLR| ties for osd_012's argsort), so it takes the clamp row whenever some symbol lies strictly beyond; alone it is ordinary.
+    const int n_lo = (tb < 0) ? min(79, (-tb) / 32 + 1) : 0;        // symbols 0 .. n_lo - 1 start at or before sample 0 (tb < 0: symbol 0 strictly)
+    const int s_strict = (tb > 3168) ? 0 : (3168 - tb) / 32 + 1;    // first symbol strictly beyond sample 3168
+    const int s_up = (s_strict < 79) ? max(0, (3168 - tb + 31) / 32) : 79;  // symbols s_up .. 78 start at or beyond 3168 (default search range: at most symbol 78)
     if (n_lo > 0 || s_up < 79) {
         __syncthreads();                                             // the rows above are written, Hc is free
         fscore_phases(L, T, n_lo > 0 ? 0 : 3168);
