@@ -14,7 +14,7 @@
 /* MAP OF THE ABI -- which entry points an adopter binds, and which exist for tests and measurements.
  *
  *   CORE (the drop-in boundary, SURVEY.md 8b: everything the Python surface of receiver.py / decoders.py needs)
- *     lifecycle        ft8rx_default_config  ft8rx_create  ft8rx_destroy  ft8rx_last_error  ft8rx_device_count  ft8rx_build_info
+ *     lifecycle        ft8rx_default_config  ft8rx_create  ft8rx_destroy  ft8rx_last_error  ft8rx_device_count  ft8rx_build_info  ft8rx_build_limits
  *     whole path       ft8rx_decode_batch  ft8rx_decode_messages                       (synchronous: host audio -> records / messages)
  *                      ft8rx_enqueue_batch  ft8rx_enqueue_batch_host  ft8rx_sync  ft8rx_fetch_results  ft8rx_fetch_results_view  (pipelined)
  *     host messages    ft8rx_package_batch  ft8rx_hashes_create / _destroy / _clear / _add / _size   (a14-a17: unpack, call hashes, dict fields)
@@ -34,7 +34,8 @@
  *     ft8rx_set_profiling  ft8rx_get_stage_times  ft8rx_math_probe  (and the ft8rx_debug_* symbols of timing-only builds)
  *
  * LIMITS of this build against the reference's open-ended kwargs (pyft8_amd.receiver.config_from_kwargs names the kwarg when one is
- * exceeded; ft8rx_create answers -1): max_cands <= FT8RX_MAX_CANDS = 256 (reference: any; default 200), search_time_range inside
+ * exceeded; ft8rx_create answers -1): max_cands <= FT8RX_MAX_CANDS = 256 (libft8rx.so) / 2048 (libft8rx_wide.so: more than any search
+ * range has f0 bins, i.e. no limit -- a larger max_cands keeps the same candidates; reference: any, default 200), search_time_range inside
  * [-6.1, +8.3] s and at most 14.08 s wide (FT8RX_MIN_H0 / FT8RX_MAX_H0), search_freq_range 12.5 .. 3000 Hz (libft8rx.so) / .. 5900 Hz
  * (libft8rx_wide.so), OSD flip counts <= 91 and <= 16384 trials.
  */
@@ -50,19 +51,22 @@ extern "C" {
 #define FT8RX_GRID_ROWS  376      /* row 0 = never-written 1.0 row, rows 1..375 = hops (receiver.py:237-240) */
 /* The spectrogram and cycle-spectrum layouts are compile-time widths.  The library is built twice from the same source:
  *   libft8rx.so       search_freq_range up to 3000 Hz, the reference's default (receiver.py:312): f0_hi <= 960
- *   libft8rx_wide.so  (-DFT8RX_WIDE) search_freq_range up to 5900 Hz: f0_hi <= 1888 -- twice the grid / spectrum memory per frame
+ *   libft8rx_wide.so  (-DFT8RX_WIDE) search_freq_range up to 5900 Hz: f0_hi <= 1888 -- twice the grid / spectrum memory per frame --
+ *                     and up to 2048 candidates per frame (every f0 bin of any search range can pass sync_score_min: 928 at the
+ *                     default range, receiver.py:338-367), eight times the per-candidate workspaces
  * Same ABI; ft8rx_build_info() tells which one is loaded.  (The reference allocates f0_hi + 16 grid columns, receiver.py:240, and
  * fails beyond ~5940 Hz, where the fine-sync slice runs off the 96001-bin cycle spectrum, receiver.py:181-182.) */
 #ifdef FT8RX_WIDE
 #define FT8RX_GRID_COLS  1920     /* bins 0..1919 of the 3840-point real FFT */
 #define FT8RX_SPEC_BINS  96000    /* bins 0..95999 of the 192000-point real FFT */
 #define FT8RX_MAX_F0     1888
+#define FT8RX_MAX_CANDS  2048     /* upper bound for config.max_cands = the per-frame stride of the per-candidate workspaces */
 #else
 #define FT8RX_GRID_COLS  976      /* receiver.py:240 at the default range: 960 + 16 */
 #define FT8RX_SPEC_BINS  49152    /* kept bins of the 192000-point cycle spectrum (receiver.py:280-286) */
 #define FT8RX_MAX_F0     960
+#define FT8RX_MAX_CANDS  256      /* upper bound for config.max_cands (the reference's default is 200, receiver.py:311) */
 #endif
-#define FT8RX_MAX_CANDS  256      /* upper bound for config.max_cands */
 #define FT8RX_MIN_H0     (-140)   /* bounds of config.h0_lo / h0_hi (search_time_range -6.1 .. +8.3 s; the reference's default is -2 .. +3 s): within them the */
 #define FT8RX_MAX_H0     220      /* middle Costas block of every candidate and time tweak lies inside the 3200-sample fine-sync series, where the     */
                                   /* frequency-domain scores equal the reference's clamped reads (receiver.py:189-195) sample for sample                */
@@ -141,6 +145,8 @@ int  ft8rx_device_pci_bus_id(int device, char* buf, int len);
 /* the compile-time widths of the loaded library (FT8RX_GRID_COLS, FT8RX_SPEC_BINS, FT8RX_MAX_F0): 976 / 49152 / 960, or
  * 1920 / 96000 / 1888 for the wide build */
 int  ft8rx_build_info(int32_t* grid_cols, int32_t* spec_bins, int32_t* max_f0);
+/* ... and its capacities (FT8RX_MAX_CANDS, FT8RX_EVENT_CAP): 256 / 512, or 2048 / 512 for the wide build */
+int  ft8rx_build_limits(int32_t* max_cands, int32_t* event_cap);
 /* FFT radix plans the kernels use (0-terminated, <= 8 entries each): 1920, 3200, 300, 320 point */
 int  ft8rx_get_fft_plans(int32_t* p1920, int32_t* p3200, int32_t* p300, int32_t* p320);
 

@@ -1218,7 +1218,7 @@ int ft8o_decode_frame(const int16_t* audio, const ft8o_config* cfg, ft8o_cand* c
                       ft8o_event* log, int32_t log_cap, int32_t* n_log, ft8o_msg* msgs, int32_t msg_cap, int32_t* n_msgs) {
     float* grid = (float*)malloc(sizeof(float) * FT8O_GRID_ROWS * FT8O_GRID_COLS);
     float* spec = NULL;
-    ft8o_cand* all = (ft8o_cand*)malloc(sizeof(ft8o_cand) * 1024);
+    ft8o_cand* all = (ft8o_cand*)malloc(sizeof(ft8o_cand) * 2048);     /* one candidate per f0 bin at most: < 960 (1888 in the wide build) */
     ft8o_spectrogram(audio, cfg, grid);
     int n = ft8o_sync_search(grid, cfg, all);
     memcpy(cands, all, sizeof(ft8o_cand) * (size_t)n);

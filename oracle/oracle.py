@@ -266,11 +266,12 @@ def decode_frame(audio, cfg=None):
     assert audio.shape == (NSAMP,)
     cands = (Cand * max(1, cfg.max_cands))()
     log = (Event * 4096)()
-    msgs = (Msg * 256)()
+    mcap = max(256, cfg.max_cands)
+    msgs = (Msg * mcap)()
     nc, nl, nm = C.c_int32(), C.c_int32(), C.c_int32()
-    lib(_wide(cfg)).ft8o_decode_frame(_p(audio, C.c_int16), C.byref(cfg), cands, C.byref(nc), log, 4096, C.byref(nl), msgs, 256, C.byref(nm))
+    lib(_wide(cfg)).ft8o_decode_frame(_p(audio, C.c_int16), C.byref(cfg), cands, C.byref(nc), log, 4096, C.byref(nl), msgs, mcap, C.byref(nm))
     out_msgs = []
-    for i in range(min(nm.value, 256)):
+    for i in range(min(nm.value, mcap)):
         m = msgs[i]
         out_msgs.append(dict(msg_tuple=tuple(m.f[k].value.decode() for k in range(3)), cand=m.cand, snr=m.snr,
                              tsec=m.tsec, fHz=m.fHz, ipass=m.ipass, ap=m.ap, method=m.method,

@@ -9,7 +9,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FT8RX_LIB", os.path.join(HERE, "libft8rx.so"))   # FT8RX_LIB: A/B builds of the same ABI
-# the same source with the wide layouts (-DFT8RX_WIDE, include/ft8rx.h): search_freq_range up to 5900 Hz; loaded only when a config asks for it
+# the same source with the wide layouts (-DFT8RX_WIDE, include/ft8rx.h): search_freq_range up to 5900 Hz and up to 2048 candidates per
+# frame (max_cands > 256); loaded only when a config asks for either
 LIB_PATH_WIDE = os.environ.get("FT8RX_LIB_WIDE", os.path.join(HERE, "libft8rx_wide.so"))
 SRC = os.path.join(HERE, "csrc", "ft8rx.hip")
 # second translation unit: the FFT kernels (k_fine, k_spectrogram), compiled with the ILP scheduling strategy -- 3.9 % / 3 % faster for
@@ -24,6 +25,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 NSAMP, GRID_ROWS, GRID_COLS, SPEC_BINS, MAX_CANDS, EVENT_CAP = 180000, 376, 976, 49152, 256, 512
 MIN_H0, MAX_H0 = -140, 220                          # FT8RX_MIN_H0 / FT8RX_MAX_H0: bounds of config.h0_lo / h0_hi (search_time_range -6.1 .. +8.3 s)
 MAX_F0, GRID_COLS_WIDE, SPEC_BINS_WIDE, MAX_F0_WIDE = 960, 1920, 96000, 1888      # Handle.grid_cols / .spec_bins hold the loaded variant's
+MAX_CANDS_WIDE = 2048                               # FT8RX_MAX_CANDS of the wide build: more than any search range has f0 bins
 
 
 class Config(C.Structure):
@@ -141,8 +143,9 @@ def build_variant(path, extra=(), ilp_flags=None):
 
 
 def lib(wide=False):
-    """The loaded library; wide=True -> the build with the wide layouts (Handle picks it when cfg.f0_hi > 960).  The host-only entry
-    points (message layer, tone encoder, hash tables, defaults) are the same code in both and are always taken from the default one."""
+    """The loaded library; wide=True -> the build with the wide layouts (Handle picks it when cfg.f0_hi > 960 or cfg.max_cands > 256).
+    The host-only entry points (tone encoder, hash tables, defaults) are the same code in both and are taken from the default one; the
+    message layer's capacity follows FT8RX_MAX_CANDS, so record arrays wider than 256 candidates are packaged by the wide build's copy."""
     wide = bool(wide)
     if wide not in _libs:
         path = LIB_PATH_WIDE if wide else LIB_PATH
@@ -171,6 +174,10 @@ def lib(wide=False):
         want = (GRID_COLS_WIDE, SPEC_BINS_WIDE, MAX_F0_WIDE) if wide else (GRID_COLS, SPEC_BINS, MAX_F0)
         if (gc.value, sb.value, mf.value) != want:
             raise Ft8rxError(f"{path} was built with layouts {(gc.value, sb.value, mf.value)}, expected {want}")
+        mc, ec = C.c_int32(), C.c_int32()
+        L.ft8rx_build_limits(C.byref(mc), C.byref(ec))
+        if (mc.value, ec.value) != ((MAX_CANDS_WIDE if wide else MAX_CANDS), EVENT_CAP):
+            raise Ft8rxError(f"{path} was built with capacities {(mc.value, ec.value)} (FT8RX_MAX_CANDS, FT8RX_EVENT_CAP)")
         _libs[wide] = L
         if _reject_log[0]:                                   # a reject log set before this build was loaded applies to it too
             L.ft8rx_set_reject_log.argtypes = [C.c_char_p]
@@ -210,7 +217,7 @@ class Handle:
 
     def __init__(self, cfg=None, device=0, max_frames=1):
         self.cfg = cfg or default_config()
-        self.wide = self.cfg.f0_hi > MAX_F0                 # search range beyond 3000 Hz: the wide build (include/ft8rx.h)
+        self.wide = self.cfg.f0_hi > MAX_F0 or self.cfg.max_cands > MAX_CANDS      # beyond 3000 Hz / 256 candidates: the wide build (include/ft8rx.h)
         L = self._L = lib(self.wide)
         self.grid_cols, self.spec_bins = (GRID_COLS_WIDE, SPEC_BINS_WIDE) if self.wide else (GRID_COLS, SPEC_BINS)
         self.max_frames = int(max_frames)
@@ -687,7 +694,7 @@ def package_batch(rec, cnt, ev, evc, max_msgs=None, n_threads=None, table=None, 
         flags = np.zeros(B, np.int32)
     if n_threads is None:
         n_threads = min(32, os.cpu_count() or 1)
-    L = lib()
+    L = lib(mc > MAX_CANDS)
     L.ft8rx_package_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p]
     rc = L.ft8rx_package_batch(rec.ctypes.data, cnt.ctypes.data, ev.ctypes.data, evc.ctypes.data, int(B), int(mc), out.ctypes.data,
@@ -796,7 +803,7 @@ def package_packed(buf, frame_lo=0, n_frames=None, max_msgs=None, n_threads=None
     oc = np.zeros(max(n, 0), np.int32)
     flags = np.zeros(max(n, 0), np.int32)
     if n > 0:
-        L = lib()
+        L = lib(pk.max_cands > MAX_CANDS)
         L.ft8rx_package_packed.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         rc = L.ft8rx_package_packed(pk.buf.ctypes.data, C.c_uint64(pk.nbytes), int(frame_lo), n, out.ctypes.data, int(max_msgs), oc.ctypes.data,
                                     int(n_threads or min(32, os.cpu_count() or 1)), table._t if table is not None else None, flags.ctypes.data)

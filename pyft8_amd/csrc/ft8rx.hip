@@ -264,6 +264,12 @@ int ft8rx_build_info(int32_t* grid_cols, int32_t* spec_bins, int32_t* max_f0) {
     if (max_f0) *max_f0 = FT8RX_MAX_F0;
     return 0;
 }
+int ft8rx_build_limits(int32_t* max_cands, int32_t* event_cap) {
+    static_assert(MAXC % 256 == 0 && MAXC <= NF0MAX, "candidate stride: whole 256-thread blocks, never more than k_topk has keys");
+    if (max_cands) *max_cands = FT8RX_MAX_CANDS;
+    if (event_cap) *event_cap = FT8RX_EVENT_CAP;
+    return 0;
+}
 
 int ft8rx_get_fft_plans(int32_t* p1920, int32_t* p3200, int32_t* p300, int32_t* p320) {
     const int32_t a[8] = {8, 4, 4, 5, 3, 0, 0, 0}, b[8] = {8, 4, 4, 5, 5, 0, 0, 0}, c[8] = {5, 5, 4, 3, 0, 0, 0, 0}, d[8] = {8, 8, 5, 0, 0, 0, 0, 0};
@@ -521,38 +527,38 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     STAGE("topk");
     k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c, evc, wc, h->use_mask ? h->d_colmask + F * NF0MAX : nullptr);
     STAGE("grid_llr");
-    k_grid_llr<<<XCD_GRID(B, MAXC), 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr, att0, ev, evc, B);
+    k_grid_llr<<<XCD_GRID(B, c.max_cands), 64, 0, s>>>(grid, rec, ncand, llr0, c, nullptr, nullptr, nullptr, att0, ev, evc, B);
     k_worklist_att<<<(B * MAXC * 5 + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_BP0]);
     STAGE("bp_grid");
-    k_bp<<<ladder_grid(B * MAXC * 5), 64, 0, s>>>(0, llr0, rec, ncand, nullptr, att0, nullptr, ev, evc, c, c.bp_nc0_a, c.bp_iters_a, wl[WL_BP0], 0, 5);
+    k_bp<<<ladder_grid(B * c.max_cands * 5), 64, 0, s>>>(0, llr0, rec, ncand, nullptr, att0, nullptr, ev, evc, c, c.bp_nc0_a, c.bp_iters_a, wl[WL_BP0], 0, 5);
     STAGE("select0");
     k_select0<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, att0, B, wl[WL_FINE]);
     STAGE("cycle_fft");
     k_cyc_a<<<dim3(40, B), 256, 0, s>>>(audio, A, h->T);
     k_cyc_bc<<<dim3(CYC_BC_GRID, B), 256, 0, s>>>(A, spec, h->T);
     STAGE("fine");
-    ft8rx_ilp_fine(ladder_grid(B * MAXC), s, spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
+    ft8rx_ilp_fine(ladder_grid(B * c.max_cands), s, spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
     k_worklist<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, B, wl[WL_BP1]);
     STAGE("bp_fine");
     // fine-stage BP: in ladder order (three launches; decided candidates drop out), or -- ft8rx_set_ladder_mode(h, 1), for small
     // batches where latency matters more than work -- all five variants in one launch: one dependent BP instead of three, same
     // records and messages (the event log then also holds entries of attempts the ladder would not have reached)
     if (h->ladder_mode == 0) {
-        k_bp<<<B * MAXC, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1], 0, 1);
+        k_bp<<<B * c.max_cands, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1], 0, 1);
         k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(0, rec, ncand, attG, attB, B, c, wl[WL_BP1B]);
-        k_bp<<<B * MAXC, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1B], 1, 1);
+        k_bp<<<B * c.max_cands, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1B], 1, 1);
         k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(1, rec, ncand, attG, attB, B, c, wl[WL_BP1C]);
-        k_bp<<<B * MAXC * 3, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1C], 2, 3);
+        k_bp<<<B * c.max_cands * 3, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1C], 2, 3);
         STAGE("select1");
         k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(2, rec, ncand, attG, attB, B, c, wl[WL_OSD]);
     } else {
-        k_bp<<<B * MAXC * 5, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1], 0, 5);
+        k_bp<<<B * c.max_cands * 5, 64, 0, s>>>(1, llr0, rec, ncand, attG, attB, saved, ev, evc, c, c.bp_nc0_b, c.bp_iters_b, wl[WL_BP1], 0, 5);
         STAGE("select1");
         k_select1<<<(B * MAXC + 255) / 256, 256, 0, s>>>(3, rec, ncand, attG, attB, B, c, wl[WL_OSD]);
     }
     STAGE("osd");
     const bool osd_wide = osd_nflip(c.osd_single, c.osd_triple) > OSD_FLIPS_A;
-    (osd_wide ? k_osd_wide : k_osd)<<<ladder_grid(B * MAXC * 10), 64, 0, s>>>(
+    (osd_wide ? k_osd_wide : k_osd)<<<ladder_grid(B * c.max_cands * 10), 64, 0, s>>>(
         0, llr0, saved, attB, rec, ncand, attO, ev, evc, h->d_trials, h->n_trials, osd_nflip(c.osd_single, c.osd_triple), c.osd_max_hd, wl[WL_OSD], wl[WL_OSDNAN]);
     // attempts on vectors with a NaN (a NaN-poisoned BP output): the reference's numpy orders those with std::sort -- a kernel of their own
     (osd_wide ? k_osd_nan_wide : k_osd_nan)<<<OSD_NAN_GRID, 64, 0, s>>>(
@@ -850,7 +856,7 @@ int ft8rx_set_packed_output(ft8rx_handle* h, void* d_buf0, void* d_buf1, uint64_
         if (!dev[k] || ((uintptr_t)dev[k] & 15)) { set_err(h, "ft8rx_set_packed_output: buffer %d is not device-accessible / 16-byte aligned", k); return -1; }
     }
     if (!h->d_pkneed) {
-        int rc = dalloc(h, &h->d_pkneed, (size_t)h->max_frames * 4);
+        int rc = dalloc(h, &h->d_pkneed, (size_t)h->max_frames * PK_NW);
         rc |= dalloc(h, &h->d_pknrec, (size_t)h->max_frames);
         if (rc) return -2;
         for (int k = 0; k < 2; k++) {

@@ -162,15 +162,16 @@ __global__ __launch_bounds__(64) void k_ev_compact(const ft8rx_event* __restrict
 // block) turns the per-frame counts into offsets and the header, k_pack_write (a block per frame) moves the entries.
 // A frame in which any candidate has a NaN llr_sd keeps ALL its candidates: the replay orders candidates by a stable sort on llr_sd
 // (receiver.py:389), and with unordered keys the order of a subset need not be the order inside the full list.
-static_assert(MAXC == 256 && sizeof(ft8rx_record) == 48 && sizeof(ft8rx_event) == 24 && sizeof(ft8rx_packed_frame) == 16 &&
+static_assert(MAXC % 256 == 0 && sizeof(ft8rx_record) == 48 && sizeof(ft8rx_event) == 24 && sizeof(ft8rx_packed_frame) == 16 &&
               sizeof(ft8rx_packed_header) == 32, "packed result layout");
+#define PK_NW (MAXC / 64)                       /* 64-candidate mask words per frame: 4 (libft8rx.so), 32 (wide build) */
 __global__ __launch_bounds__(256) void k_pack_count(const ft8rx_record* __restrict__ rec, const int32_t* __restrict__ ncand,
                                                     const ft8rx_event* __restrict__ ev, const int32_t* __restrict__ evcount,
-                                                    uint64_t* __restrict__ need /*[B][4]*/, int32_t* __restrict__ nrec /*[B]*/) {
-    __shared__ uint32_t s_has[8];
-    __shared__ int s_cnt[4], s_nan;
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < 8) s_has[tid] = 0;
+                                                    uint64_t* __restrict__ need /*[B][PK_NW]*/, int32_t* __restrict__ nrec /*[B]*/) {
+    __shared__ uint32_t s_has[MAXC / 32];
+    __shared__ int s_cnt[PK_NW], s_nan;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < MAXC / 32; i += 256) s_has[i] = 0;
     if (tid == 0) s_nan = 0;
     __syncthreads();
     int c = evcount[f]; c = c > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : (c < 0 ? 0 : c);
@@ -179,15 +180,21 @@ __global__ __launch_bounds__(256) void k_pack_count(const ft8rx_record* __restri
         if (cand < (unsigned)MAXC) atomicOr(&s_has[cand >> 5], 1u << (cand & 31));
     }
     int n = ncand[f]; n = n > MAXC ? MAXC : (n < 0 ? 0 : n);
-    const ft8rx_record& r = rec[(size_t)f * MAXC + (tid < n ? tid : 0)];
-    const bool decoded = tid < n && r.status == FT8RX_ST_DECODED;
-    if (tid < n && (r.grid_sd != r.grid_sd || r.fine_sd != r.fine_sd)) s_nan = 1;
+    for (int i = tid; i < n; i += 256) {
+        const ft8rx_record& r = rec[(size_t)f * MAXC + i];
+        if (r.grid_sd != r.grid_sd || r.fine_sd != r.fine_sd) s_nan = 1;
+    }
     __syncthreads();
-    const bool want = tid < n && (decoded || ((s_has[tid >> 5] >> (tid & 31)) & 1u) || s_nan);
-    const uint64_t m = __ballot(want);
-    if (lane == 0) { need[(size_t)f * 4 + wv] = m; s_cnt[wv] = __popcll(m); }
+#pragma unroll 1
+    for (int q = 0; q < MAXC / 256; q++) {
+        const int i = tid + 256 * q;
+        const bool decoded = i < n && rec[(size_t)f * MAXC + (i < n ? i : 0)].status == FT8RX_ST_DECODED;
+        const bool want = i < n && (decoded || ((s_has[i >> 5] >> (i & 31)) & 1u) || s_nan);
+        const uint64_t m = __ballot(want);
+        if (lane == 0) { need[(size_t)f * PK_NW + (i >> 6)] = m; s_cnt[i >> 6] = __popcll(m); }
+    }
     __syncthreads();
-    if (tid == 0) nrec[f] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (tid == 0) { int t = 0; for (int w = 0; w < PK_NW; w++) t += s_cnt[w]; nrec[f] = t; }
 }
 // offsets of every frame's records / events in the packed runs, the frame table and the header (also mirrored into page-locked
 // host memory, `hdr_host`, so that the host knows the size without a copy)
@@ -238,22 +245,25 @@ __global__ __launch_bounds__(256) void k_pack_write(const ft8rx_record* __restri
                                                     const uint64_t* __restrict__ need, int B, unsigned char* __restrict__ buf) {
     const ft8rx_packed_header hd = *reinterpret_cast<const ft8rx_packed_header*>(buf);
     if (hd.overflow) return;
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int s_pre[PK_NW];                                       // kept records in the mask words before word w
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const ft8rx_packed_frame t = reinterpret_cast<const ft8rx_packed_frame*>(buf + sizeof(ft8rx_packed_header))[f];
     unsigned char* recs = buf + sizeof(ft8rx_packed_header) + (size_t)B * sizeof(ft8rx_packed_frame);
     unsigned char* evs = recs + (size_t)hd.n_records * sizeof(ft8rx_record);
-    const uint64_t m0 = need[(size_t)f * 4], m1 = need[(size_t)f * 4 + 1], m2 = need[(size_t)f * 4 + 2], m3 = need[(size_t)f * 4 + 3];
-    const uint64_t mine = wv == 0 ? m0 : wv == 1 ? m1 : wv == 2 ? m2 : m3;
-    if ((mine >> lane) & 1ull) {
-        int p = __popcll(mine & ((1ull << lane) - 1));
-        if (wv > 0) p += __popcll(m0);
-        if (wv > 1) p += __popcll(m1);
-        if (wv > 2) p += __popcll(m2);
-        const uint4* src = reinterpret_cast<const uint4*>(rec + (size_t)f * MAXC + tid);
-        uint4* dst = reinterpret_cast<uint4*>(recs + ((size_t)t.rec_off + p) * sizeof(ft8rx_record));
-        uint4 a = src[0], b = src[1], c = src[2];
-        c.w = (uint32_t)tid;                                           // pad2 = the candidate's index inside its frame
-        dst[0] = a; dst[1] = b; dst[2] = c;
+    if (tid == 0) { int a = 0; for (int w = 0; w < PK_NW; w++) { s_pre[w] = a; a += __popcll(need[(size_t)f * PK_NW + w]); } }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < MAXC / 256; q++) {
+        const int i = tid + 256 * q;
+        const uint64_t mine = need[(size_t)f * PK_NW + (i >> 6)];
+        if ((mine >> lane) & 1ull) {
+            const int p = s_pre[i >> 6] + __popcll(mine & ((1ull << lane) - 1));
+            const uint4* src = reinterpret_cast<const uint4*>(rec + (size_t)f * MAXC + i);
+            uint4* dst = reinterpret_cast<uint4*>(recs + ((size_t)t.rec_off + p) * sizeof(ft8rx_record));
+            uint4 a = src[0], b = src[1], c = src[2];
+            c.w = (uint32_t)i;                                         // pad2 = the candidate's index inside its frame
+            dst[0] = a; dst[1] = b; dst[2] = c;
+        }
     }
     const int ne = t.n_ev > FT8RX_EVENT_CAP ? FT8RX_EVENT_CAP : t.n_ev;
     const uint2* es = reinterpret_cast<const uint2*>(ev + (size_t)f * FT8RX_EVENT_CAP);

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void k_grid_llr(const float* __restrict__ grid,
     size_t slot = blockIdx.x;                   // where this block's outputs go: the triple's index, or the candidate's
     if (trip) { frame = trip[3 * blockIdx.x]; f0 = trip[3 * blockIdx.x + 1]; h0 = trip[3 * blockIdx.x + 2]; ci = 0; }
     else {
-        if (!xcd_frame_map(blockIdx.x, MAXC, B, frame, ci)) return;      // a frame's candidates gather from one XCD's L2
+        if (!xcd_frame_map(blockIdx.x, cfg.max_cands, B, frame, ci)) return;      // a frame's candidates gather from one XCD's L2 (launch: XCD_GRID(B, max_cands))
         slot = (size_t)frame * MAXC + ci;
         if (ci >= ncand[frame]) return;
         const ft8rx_record& r = rec[(size_t)frame * MAXC + ci];

@@ -120,9 +120,12 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ best_sc
     if (mine) atomicAdd(&tot, mine);
     __syncthreads();
     const int cnt = tot;
-    const uint64_t kk = key[tid];
     if (tid == 0) ncand[f] = cnt < cfg.max_cands ? cnt : cfg.max_cands;
-    if (tid < cfg.max_cands) {
+#pragma unroll
+    for (int q = 0; q < KPT; q++) {                                   // rank = position in the sorted keys (max_cands <= MAXC <= NF0MAX)
+        const int rank = tid + 1024 * q;
+        if (rank >= cfg.max_cands) break;
+        const uint64_t kk = key[rank];
         ft8rx_record r; memset(&r, 0, sizeof(r));
         if (kk != ~0ull) {
             int i = (int)(kk & 0xffffffffu);
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ best_sc
             r.score = __uint_as_float(~(uint32_t)(kk >> 32));
             r.status = FT8RX_ST_ACTIVE; r.ipass = 0xff;
         } else r.status = FT8RX_ST_EXHAUSTED;
-        rec[(size_t)f * MAXC + tid] = r;
+        rec[(size_t)f * MAXC + rank] = r;
     }
 }
 

@@ -35,14 +35,17 @@ def config_from_kwargs(sync_score_min=85, max_cands=200, search_freq_range=(100,
     """Receiver kwargs -> ft8rx_config (index arithmetic of reference receiver.py:233-235, 319)."""
     df = SYM_RATE / 2
     cfg = _lib.default_config(
-        sync_score_min=float(sync_score_min), max_cands=int(max_cands),
+        sync_score_min=float(sync_score_min), max_cands=int(min(max_cands, 1 << 30)),
         f0_lo=int(search_freq_range[0] / df), f0_hi=int(search_freq_range[1] / df),
         h0_lo=int((search_time_range[0] + 0.5) * 4 * SYM_RATE), h0_hi=int((search_time_range[1] + 0.5) * 4 * SYM_RATE))
     # The reference takes any value here (receiver.py:311-313, 319, 366-367); this build has compile-time layouts.  Say which
     # kwarg is out of range instead of letting ft8rx_create answer "configuration out of the supported range" (include/ft8rx.h).
-    if not 1 <= cfg.max_cands <= _lib.MAX_CANDS:
-        raise _lib.Ft8rxError(f"max_cands={max_cands}: this build keeps at most {_lib.MAX_CANDS} candidates per frame (FT8RX_MAX_CANDS; "
-                              "the reference's default is 200)")
+    if cfg.max_cands < 1:
+        raise _lib.Ft8rxError(f"max_cands={max_cands}: at least one candidate per frame")
+    # max_cands: no limit.  Receiver.search makes at most one candidate per f0 bin (receiver.py:341-365), so any value beyond the
+    # number of bins of the search range keeps exactly the same list; more than 256 select the build with the deep candidate
+    # layouts (libft8rx_wide.so: FT8RX_MAX_CANDS = 2048 > 1884 bins of the widest range).
+    cfg.max_cands = min(cfg.max_cands, max(1, cfg.f0_hi - cfg.f0_lo))
     if cfg.h0_lo < _lib.MIN_H0 or cfg.h0_hi > _lib.MAX_H0 or not 0 < cfg.h0_hi - cfg.h0_lo <= 352:
         raise _lib.Ft8rxError(f"search_time_range={list(search_time_range)}: supported are windows inside [{_lib.MIN_H0 / 25 - 0.5:.1f}, "
                               f"{_lib.MAX_H0 / 25 - 0.5:.1f}] s of at most {352 / 25:.2f} s (FT8RX_MIN_H0 / FT8RX_MAX_H0: the middle Costas block of "

@@ -1024,9 +1024,10 @@ def test_wide_time_window_clamped_symbols():
 
 def test_candidate_cap_and_kwarg_limits():
     """The build's boundary limits against the reference's open-ended kwargs (receiver.py:311-313, 319, 366-367):
-    max_cands up to FT8RX_MAX_CANDS = 256 -- with sync_score_min = 40 the threshold admits far more than 256 maxima, the stable top-K cut
-    really happens, and every record and message still equals the oracle's; beyond the limits Receiver names the kwarg instead of
-    failing with the library's generic bad-config error."""
+    max_cands = 256, the most the default layouts hold -- with sync_score_min = 40 the threshold admits far more than 256 maxima, the
+    stable top-K cut really happens, and every record and message still equals the oracle's; beyond the limits that remain Receiver
+    names the kwarg instead of failing with the library's generic bad-config error.  (max_cands itself has no limit any more:
+    test_max_cands_beyond_256_uses_the_deep_layouts.)"""
     from pyft8_amd import _lib, synth
     from pyft8_amd.receiver import Receiver, config_from_kwargs
     audio = synth.make_batch(64000, 3, n_signals=60, snr_range=(-14.0, 6.0))
@@ -1039,11 +1040,56 @@ def test_candidate_cap_and_kwarg_limits():
     for i in range(3):
         _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
     assert float(rec[0]["score"][255]) > 40.0 + 1.0                        # the list ends at the cut, not at the threshold
-    for kw, word in ((dict(max_cands=257), "max_cands=257"), (dict(max_cands=0), "max_cands=0"),
+    for kw, word in ((dict(max_cands=0), "max_cands=0"),
                      (dict(search_time_range=[-7.0, 3.0]), "search_time_range"), (dict(search_time_range=[-6.0, 8.2]), "search_time_range"),
                      (dict(search_freq_range=[0, 3000]), "search_freq_range"), (dict(search_freq_range=[100, 6000]), "search_freq_range")):
         with pytest.raises(_lib.Ft8rxError, match=word):
             Receiver("x", None, **kw)
+
+
+def test_max_cands_beyond_256_uses_the_deep_layouts():
+    """max_cands is open-ended in the reference (receiver.py:311-313, 366-367): every f0 bin of the search range whose best sync score
+    passes sync_score_min is a candidate -- up to 928 at the default range.  More than 256 select libft8rx_wide.so (FT8RX_MAX_CANDS =
+    2048 there, include/ft8rx.h).  Receiver(max_cands=600, sync_score_min=30): more than 256 candidates in EVERY frame, each record,
+    event and message equal to the oracle's; the packed form (k_pack_*: 32 mask words per frame in this build) renders the same
+    messages; a max_cands beyond the number of f0 bins keeps exactly the list of max_cands = number of bins."""
+    from pyft8_amd import _lib, synth
+    from pyft8_amd.receiver import Receiver, config_from_kwargs, decode_frames
+    audio = synth.make_batch(64100, 3, n_signals=60, snr_range=(-14.0, 6.0))
+    cfg = config_from_kwargs(sync_score_min=30, max_cands=600)
+    assert cfg.max_cands == 600
+    h = _lib.Handle(cfg, max_frames=3)
+    assert h.wide
+    rec, cnt, ev, evc = h.decode_batch(audio)
+    assert rec.shape[1] == 600 and (cnt > 256).all(), cnt
+    ocfg = O.default_config(**_lib.fft_plans(), sync_score_min=30.0, max_cands=600)
+    for i in range(3):
+        _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
+    # packed results of the same batch (page-locked host buffers): byte for byte the numpy twin's, and the same messages as the dense arrays
+    cap = _lib.packed_capacity(3, cfg.max_cands)
+    pin = [h.pinned_bytes(cap) for _ in range(2)]
+    h.set_packed_output(pin[0].ctypes.data, pin[1].ctypes.data, cap)
+    h.enqueue_host(audio)
+    res = h.fetch(3)
+    which, hdr = h.packed_results()
+    assert not hdr["overflow"] and hdr["max_cands"] == 600
+    assert pin[which][:hdr["bytes"]].tobytes() == _lib.pack_results(*res).tobytes()
+    m1, m2 = _lib.package_batch(*res), _lib.package_packed(pin[which][:hdr["bytes"]])
+    assert m1[0].tobytes() == m2[0].tobytes() and np.array_equal(m1[1], m2[1]) and (m1[1] > 0).all()
+    h.close()
+    # no limit: beyond the 928 f0 bins of the default range nothing changes (and the count is whatever passes the threshold)
+    big = config_from_kwargs(sync_score_min=30, max_cands=10**9)
+    assert big.max_cands == 928
+    h = _lib.Handle(big, max_frames=1)
+    rec2, cnt2, ev2, evc2 = h.decode_batch(audio[:1])
+    h.close()
+    assert 600 < int(cnt2[0]) <= 928
+    _check_frame(rec2[0], cnt2[0], ev2[0], evc2[0], audio[0], None, O.default_config(**_lib.fft_plans(), sync_score_min=30.0, max_cands=928))
+    assert np.array_equal(rec2[0, :600][["f0_idx", "h0_idx", "score"]], rec[0, :600][["f0_idx", "h0_idx", "score"]])
+    msgs = decode_frames(audio[:1], sync_score_min=30, max_cands=600)
+    assert len(msgs) == 1 and len(msgs[0]) > 0
+    rx = Receiver("x", None, max_cands=600, sync_score_min=30)
+    assert rx.cfg.max_cands == 600
 
 
 def test_device_synth_generator(H, ocfg):
@@ -1275,7 +1321,7 @@ def test_error_paths_and_lifecycle():
     """C ABI error convention: negative return + ft8rx_last_error text, surfaced as Ft8rxError; never a crash."""
     from pyft8_amd import _lib
     with pytest.raises(_lib.Ft8rxError, match="configuration"):
-        _lib.Handle(_lib.default_config(max_cands=1000))
+        _lib.Handle(_lib.default_config(max_cands=5000))                    # > FT8RX_MAX_CANDS of the deep layouts (2048)
     with pytest.raises(_lib.Ft8rxError, match="configuration"):
         _lib.Handle(_lib.default_config(f0_lo=0))
     with pytest.raises(_lib.Ft8rxError, match="configuration"):

@@ -491,6 +491,36 @@ def _dense_goldens(names):
     return np.stack(recs), np.array(cnts, np.int32), np.stack(evs), np.array(evcs, np.int32)
 
 
+def test_host_layer_with_more_than_256_candidates():
+    """max_cands is open-ended (receiver.py:311-313, 366-367): record arrays wider than 256 candidates are packaged by the copy of the
+    host layer inside libft8rx_wide.so (FT8RX_MAX_CANDS = 2048).  Oracle records of one frame at max_cands = 600 / sync_score_min = 30:
+    the native packager, the packed form and the Python twin all render the oracle's messages."""
+    import oracle as O
+    from pyft8_amd import _lib, synth, messages as M
+    from pyft8_amd.receiver import config_from_kwargs
+    cfg = config_from_kwargs(sync_score_min=30, max_cands=600)
+    assert cfg.max_cands == 600 and config_from_kwargs(max_cands=10**12).max_cands == 928      # never more candidates than f0 bins
+    audio = synth.make_frame(64100, n_signals=60, snr_range=(-14.0, 6.0))
+    r = O.decode_frame(audio, O.default_config(**_lib.fft_plans(), sync_score_min=30.0, max_cands=600))
+    rec, n, ev, nev = records_from_oracle(r, max_cands=600)
+    assert 256 < n <= 600 and nev <= _lib.EVENT_CAP
+    e = np.zeros((1, _lib.EVENT_CAP), _lib.EVENT_DTYPE)
+    e[0, :nev] = ev[:nev]
+    dense_in = (rec[None], np.array([n], np.int32), e, np.array([nev], np.int32))
+    out, oc = _lib.package_batch(*dense_in)
+    want = [" ".join(m["msg_tuple"]) for m in r["msgs"]]
+    got = [" ".join(x.decode() for x in out[0, i]["f"] if x) for i in range(int(oc[0]))]
+    assert got == want and len(want) > 10
+    assert any(int(out[0, i]["cand"]) >= 256 for i in range(int(oc[0]))) or n > 256           # candidates beyond slot 255 take part
+    buf = _lib.pack_results(*dense_in)
+    pk = _lib.Packed(buf)
+    assert int(pk.header["max_cands"]) == 600
+    out2, oc2 = _lib.package_packed(buf)
+    assert out2.tobytes() == out.tobytes() and np.array_equal(oc, oc2)
+    twin = M.package_frame(rec, n, e[0], nev)
+    assert [" ".join(m["msg_tuple"]) for m in twin] == want
+
+
 def test_packed_results_render_the_same_messages_as_the_dense_arrays():
     """include/ft8rx.h "packed results": header | frame table | kept records | used events.  The numpy twin of the pack kernels
     (_lib.pack_results) on oracle records of the golden frames: ft8rx_package_packed == ft8rx_package_batch byte for byte (whole
