@@ -8,14 +8,17 @@ tests).  The reference has no counterpart.
 The gather the measured path uses (bench.py, inside the timed step):
   PackedGather(handle, n_frames)          every batch ends with three small kernels that pack what the host message layer reads of it
                                           (records of the candidates that decoded or logged an unpack() call + the used event log,
-                                          ~4 KB per config-1 frame instead of 13-24 KB; include/ft8rx.h "packed results") into a
-                                          device buffer; submit() exchanges the byte counts on the host (gloo, 8 bytes per rank) and
-                                          gathers the packed buffers to rank `dst` on a side stream (RCCL over xGMI), where one D2H
-                                          copy per rank lands them in
-                                          page-locked host memory -- all of it overlapping the next batch's kernels.  Rank `dst`
-                                          keeps the packed form (a view per rank / frame, `_lib.Packed`) and can render any frame's
-                                          messages from it (`_lib.package_packed`).  With gloo (flow tests) the GPU writes the packed
-                                          buffer straight into page-locked host memory and the gather moves host bytes.
+                                          ~6 KB per config-1 frame instead of 13-24 KB; include/ft8rx.h "packed results") into a
+                                          device buffer.  submit() has NO rendezvous: a sending rank starts a point-to-point send of
+                                          its buffer to rank `dst` on a side stream (RCCL over xGMI) and drops a three-number
+                                          announcement into the process group's store; rank `dst` polls that mailbox, starts the
+                                          receives announced so far as ONE group (dist.batch_isend_irecv) into one flat device
+                                          buffer per batch, parts back to back, and moves a complete batch to page-locked host
+                                          memory with ONE D2H copy and one event -- all of it overlapping the next batches'
+                                          kernels.  Rank `dst` keeps the packed form (a view per rank / frame, `_lib.Packed`) and
+                                          can render any frame's messages from it (`_lib.package_packed`).  With gloo (flow tests)
+                                          the GPU writes the packed buffer straight into page-locked host memory and the gather
+                                          moves host bytes.
 The dense variants (fixed-capacity blocks; kept for tools and as a cross-check, same result on rank `dst` = the concatenation over
 ranks in rank order = global frame order for shard()):
   gather_results(rec, cnt, ev, evc)       host arrays in, through the backend's device (gloo: CPU tensors; nccl: one H2D per rank)
@@ -194,11 +197,15 @@ class PackedGather:
         self.row = 0
         self.row_history = []              # rank dst: every row size the receive sets have had (growth is visible to tests)
         self.recv = self.host = None       # rank dst: allocated by _room() from the first byte counts seen
+        self._ops = []                     # rank dst, device path: receives collected by _receive and not started yet (_flush)
+        self.recv_groups = self.d2h_copies = 0      # rank dst, device path: receive groups started / D2H copies made so far
         # control messages travel on the host, through the store: a device-side exchange would make the host wait for the side stream,
         # which shares one of the runtime's few hardware queues with a chunk stream of the decode (135 ms per step at config 3, r04)
         PackedGather._instances += 1
         self.store = _store() if (self.active and self.world > 1) else None
-        self.prefix = f"ft8rx_pg{PackedGather._instances}"
+        # mailbox prefix: the n-th PackedGather of this process, and rank dst's GLOBAL rank -- two disjoint sub-groups that each build
+        # their first PackedGather have different dst ranks, so their control messages cannot cross
+        self.prefix = f"ft8rx_pg{PackedGather._instances}_d{self._g(dst) if self.active else 0}"
         if self.nccl:
             dev = torch.device("cuda", torch.cuda.current_device())
             self.stream = torch.cuda.Stream(device=dev)
@@ -294,8 +301,10 @@ class PackedGather:
         return True
 
     def _room(self, m):
-        """Rank dst: `depth` receive sets with rows of at least m bytes for world x repeat parts.  Sized to twice the first part seen; a
-        later part that needs more gets new, larger sets -- parts already received (or being received) keep their old memory alive."""
+        """Rank dst: `depth` receive sets with room for world x repeat parts of at least m bytes each.  Sized to twice the first part seen;
+        a later part that needs more gets new, larger sets -- parts already received (or being received) keep their old memory alive.
+        A set is ONE flat device buffer and ONE flat page-locked host buffer: a batch's parts are packed back to back in arrival order
+        (256-byte aligned), so that one D2H copy moves a whole batch (_close_segment)."""
         if m <= self.row:
             return
         self.row = min(self.cap, max(2 * m, self.MIN_ROW))
@@ -304,15 +313,45 @@ class PackedGather:
         n = self.world * self.repeat
         if self.nccl:
             dev = self.src[0].device
-            self.recv = [torch.empty((n, self.row), dtype=torch.uint8, device=dev) for _ in range(self.depth)]
-            self.host = [torch.empty((n, self.row), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
+            self.recv = [torch.empty(n * self.row, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
+            self.host = [torch.empty(n * self.row, dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
         else:
             self.host = [torch.empty((n, self.row), dtype=torch.uint8) for _ in range(self.depth)]
 
     def _batch(self, k):
         if k not in self.batches:
-            self.batches[k] = {"parts": [None] * (self.world * self.repeat), "left": self.world * self.repeat, "err": None, "open": []}
+            self.batches[k] = {"parts": [None] * (self.world * self.repeat), "left": self.world * self.repeat, "err": None, "open": [],
+                               "posted": 0, "seg": None}
         return self.batches[k]
+
+    def _close_segment(self, b):
+        """Device path: ONE D2H copy and ONE event for everything of this batch that has been received into the current segment of its
+        set (rounds 4-5 made a copy and an event per part: eight of each per step on rank dst of an 8-rank job, every one a command in
+        a hardware queue the decode streams share).  Called when the last part of the batch has been posted (the copy then waits, on
+        the side stream, for every receive of the batch) or when the sets are replaced by larger ones in the middle of a batch."""
+        seg, b["seg"] = b["seg"], None
+        if not seg or seg["hi"] == 0:
+            return
+        with torch.cuda.stream(self.stream):
+            seg["host"][:seg["hi"]].copy_(seg["dev"][:seg["hi"]], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.d2h_copies += 1
+        for i, o, nbytes in seg["items"]:
+            b["open"].append((i, ev, seg["host"][o:o + nbytes], nbytes))
+
+    def _flush(self):
+        """Device path: start the receives collected by _receive as ONE group (dist.batch_isend_irecv = one ncclGroupStart / End on the
+        side stream), then close the segment of every batch whose parts have all been posted."""
+        if self._ops:
+            ops, self._ops = self._ops, []
+            with torch.cuda.stream(self.stream):
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()                                         # (the side stream waits; the host does not)
+            self.recv_groups += 1
+        for b in self.batches.values():
+            if b["seg"] is not None and b["posted"] >= self.world * self.repeat:
+                self._close_segment(b)
 
     def _set_free(self, k):
         """May parts of batch k be received now?  (a) Its receive set last held batch k - depth, which must be complete -- an uncollected
@@ -327,48 +366,73 @@ class PackedGather:
         return True
 
     def _receive(self, r, k, nbytes, flag, slot=None):
-        """Rank dst: post the data receive(s) of peer r's batch k (or take the local copy for r == dst)."""
+        """Rank dst: post the data receive(s) of peer r's batch k (or take the local copy for r == dst).  Device path: the receive is only
+        COLLECTED here (self._ops) and the part gets its place in the batch's segment; _flush() starts what has been collected."""
         b = self._batch(k)
         if flag:
             b["err"] = f"rank {r} reported a packed-buffer overflow for batch {k} ({nbytes} bytes needed; raise per_frame)"
             b["left"] -= self.repeat               # no data follows; this rank's parts stay None
+            b["posted"] += self.repeat
             return
         m = (nbytes + 255) & ~255
         self._room(m)
         s = k % self.depth
+        if self.nccl:
+            seg = b["seg"]
+            if seg is None or seg["dev"] is not self.recv[s]:       # first part of the batch, or the sets have just been replaced by larger ones
+                if seg is not None:
+                    self._flush_ops_only()
+                    self._close_segment(b)
+                seg = b["seg"] = {"dev": self.recv[s], "host": self.host[s], "hi": 0, "items": []}
+            for rep in range(self.repeat):
+                i = rep * self.world + r
+                o = seg["hi"]
+                seg["hi"] = o + m
+                drow = seg["dev"][o:o + m]
+                if r == self.dst:
+                    with torch.cuda.stream(self.stream):
+                        drow.copy_(self.src[slot][:m], non_blocking=True)
+                else:
+                    self._ops.append(dist.P2POp(dist.irecv, drow, self._g(r), self.group))
+                seg["items"].append((i, o, nbytes))
+            b["posted"] += self.repeat
+            return
         for rep in range(self.repeat):
             i = rep * self.world + r
             hrow = self.host[s][i]
-            if self.nccl:
-                with torch.cuda.stream(self.stream):
-                    drow = self.recv[s][i]
-                    if r == self.dst:
-                        drow[:m].copy_(self.src[slot][:m], non_blocking=True)
-                    else:
-                        dist.irecv(drow[:m], src=self._g(r), group=self.group).wait()      # (wait = the side stream waits; the host does not)
-                    hrow[:m].copy_(drow[:m], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(self.stream)
-                comp = ev
+            if r == self.dst:
+                hrow[:m].copy_(self.src[slot][:m])
+                comp = None
             else:
-                if r == self.dst:
-                    hrow[:m].copy_(self.src[slot][:m])
-                    comp = None
-                else:
-                    comp = dist.irecv(hrow[:m], src=self._g(r), group=self.group, tag=self.TAG_DATA)
+                comp = dist.irecv(hrow[:m], src=self._g(r), group=self.group, tag=self.TAG_DATA)
             b["open"].append((i, comp, hrow, nbytes))
+        b["posted"] += self.repeat
         return
+
+    def _flush_ops_only(self):
+        if self._ops:
+            ops, self._ops = self._ops, []
+            with torch.cuda.stream(self.stream):
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            self.recv_groups += 1
 
     def _progress(self):
         """Rank dst: take the control messages that have arrived, post the data receives they announce (in order per peer, while the ring
         has room), note the parts that have landed, move completed batches to `ready` (in batch order).  Never blocks."""
         if not (self.active and self.rank == self.dst):
             return
+        # in lockstep operation every peer's next announcement is there at the same time: one store round trip tells (check() is true
+        # only if ALL keys exist); otherwise the peers are asked one by one
+        peers = list(self.announced)
+        all_there = len(peers) > 1 and self.store.check([f"{self.prefix}/{r}/{self.next_ctrl[r]}" for r in peers])
         for r, q in self.announced.items():
+            first = True
             while True:
                 key = f"{self.prefix}/{r}/{self.next_ctrl[r]}"
-                if not self.store.check([key]):
+                if not (first and all_there) and not self.store.check([key]):
                     break
+                first = False
                 k, nbytes, flag = (int(x) for x in self.store.get(key).decode().split(","))
                 self.store.delete_key(key)
                 q.append((k, nbytes, flag))
@@ -376,6 +440,8 @@ class PackedGather:
             while q and self._set_free(q[0][0]):
                 k, nbytes, flag = q.pop(0)
                 self._receive(r, k, nbytes, flag)
+        if self.nccl:
+            self._flush()                  # everything announced by now: one receive group; complete batches: one D2H each
         for k in sorted(self.batches):
             b = self.batches[k]
             still = []
@@ -467,7 +533,9 @@ class PackedGather:
         self._receive(self.dst, k, nbytes, 1 if overflow else 0, slot)
         if self.nccl and not overflow:
             # the local copy reads src[slot] on the side stream: fence the next pack into it, like a send
-            ev = self.batches[k]["open"][-1][1]
+            with torch.cuda.stream(self.stream):
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
             self.h.packed_fence(slot, ev.cuda_event, keep=ev)
         self._progress()
         mark("issue")

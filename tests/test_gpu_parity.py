@@ -1556,8 +1556,15 @@ def test_bench_contract_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["unit"] == "frames/s" and "workload" in d["config"]
+    # the line says what was measured: `value` = audio resident in HBM, the same batch every step; the SURVEY 8d
+    # metric (page-locked host audio -> H2D -> kernels -> D2H -> messages) over the SAME number of steps under its own name
+    assert "resident in HBM" in d["config"]["workload"] and "same batch every step" in d["config"]["workload"]
+    assert "resident in HBM" in d["value_definition"]
+    assert d["value_8d_host_audio"] > 1000 and d["value_8d_steps"] == d["steps"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0
+    assert "counter_frac" in r and (r["counter_frac"] is None or (r["traffic"] is not None and 0 < r["counter_frac"] < 1
+                                                                 and abs(r["counter_frac"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-9))
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s"
     assert d["value"] > 1000
