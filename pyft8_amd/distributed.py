@@ -11,11 +11,10 @@ The gather the measured path uses (bench.py, inside the timed step):
                                           ~6 KB per config-1 frame instead of 13-24 KB; include/ft8rx.h "packed results") into a
                                           device buffer.  submit() has NO rendezvous: a sending rank starts a point-to-point send of
                                           its buffer to rank `dst` on a side stream (RCCL over xGMI) and drops a three-number
-                                          announcement into the process group's store; rank `dst` polls that mailbox, starts the
-                                          receives announced so far as ONE group (dist.batch_isend_irecv) into one flat device
-                                          buffer per batch, parts back to back, and moves a complete batch to page-locked host
-                                          memory with ONE D2H copy and one event -- all of it overlapping the next batches'
-                                          kernels.  Rank `dst` keeps the packed form (a view per rank / frame, `_lib.Packed`) and
+                                          announcement into the process group's store; rank `dst` polls that mailbox, posts the
+                                          receives announced so far into one flat device buffer per batch, parts back to back,
+                                          and moves a complete batch to page-locked host memory with ONE D2H copy and one event
+                                          (rounds 4-5: one of each per part) -- all of it overlapping the next batches' kernels.  Rank `dst` keeps the packed form (a view per rank / frame, `_lib.Packed`) and
                                           can render any frame's messages from it (`_lib.package_packed`).  With gloo (flow tests)
                                           the GPU writes the packed buffer straight into page-locked host memory and the gather
                                           moves host bytes.
@@ -25,11 +24,15 @@ ranks in rank order = global frame order for shard()):
   gather_results_device(handle, n_frames) nccl only: the latest batch's results go device -> device into torch buffers
                                           (ft8rx_results_to_device), RCCL gathers them over xGMI, and rank `dst` makes the single
                                           D2H copy -- no host round trip on the sending ranks."""
+import os
 import weakref
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+_DIAG = os.environ.get("FT8RX_GATHER_DIAG", "")      # measurement aid only (tools/r06_gather_diag.sh)
 
 
 def shard(n_frames, rank, world):
@@ -197,8 +200,7 @@ class PackedGather:
         self.row = 0
         self.row_history = []              # rank dst: every row size the receive sets have had (growth is visible to tests)
         self.recv = self.host = None       # rank dst: allocated by _room() from the first byte counts seen
-        self._ops = []                     # rank dst, device path: receives collected by _receive and not started yet (_flush)
-        self.recv_groups = self.d2h_copies = 0      # rank dst, device path: receive groups started / D2H copies made so far
+        self.d2h_copies = 0                # rank dst, device path: D2H copies made so far (one per batch)
         # control messages travel on the host, through the store: a device-side exchange would make the host wait for the side stream,
         # which shares one of the runtime's few hardware queues with a chunk stream of the decode (135 ms per step at config 3, r04)
         PackedGather._instances += 1
@@ -333,7 +335,8 @@ class PackedGather:
         if not seg or seg["hi"] == 0:
             return
         with torch.cuda.stream(self.stream):
-            seg["host"][:seg["hi"]].copy_(seg["dev"][:seg["hi"]], non_blocking=True)
+            if _DIAG != "nod2h":
+                seg["host"][:seg["hi"]].copy_(seg["dev"][:seg["hi"]], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.d2h_copies += 1
@@ -341,14 +344,7 @@ class PackedGather:
             b["open"].append((i, ev, seg["host"][o:o + nbytes], nbytes))
 
     def _flush(self):
-        """Device path: start the receives collected by _receive as ONE group (dist.batch_isend_irecv = one ncclGroupStart / End on the
-        side stream), then close the segment of every batch whose parts have all been posted."""
-        if self._ops:
-            ops, self._ops = self._ops, []
-            with torch.cuda.stream(self.stream):
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()                                         # (the side stream waits; the host does not)
-            self.recv_groups += 1
+        """Device path: close the segment of every batch whose parts have all been posted (one D2H + one event per batch)."""
         for b in self.batches.values():
             if b["seg"] is not None and b["posted"] >= self.world * self.repeat:
                 self._close_segment(b)
@@ -366,8 +362,8 @@ class PackedGather:
         return True
 
     def _receive(self, r, k, nbytes, flag, slot=None):
-        """Rank dst: post the data receive(s) of peer r's batch k (or take the local copy for r == dst).  Device path: the receive is only
-        COLLECTED here (self._ops) and the part gets its place in the batch's segment; _flush() starts what has been collected."""
+        """Rank dst: post the data receive(s) of peer r's batch k (or take the local copy for r == dst).  Device path: the part gets its
+        place in the batch's segment (flat buffer, parts back to back); _flush() copies a completely posted batch to the host."""
         b = self._batch(k)
         if flag:
             b["err"] = f"rank {r} reported a packed-buffer overflow for batch {k} ({nbytes} bytes needed; raise per_frame)"
@@ -381,7 +377,6 @@ class PackedGather:
             seg = b["seg"]
             if seg is None or seg["dev"] is not self.recv[s]:       # first part of the batch, or the sets have just been replaced by larger ones
                 if seg is not None:
-                    self._flush_ops_only()
                     self._close_segment(b)
                 seg = b["seg"] = {"dev": self.recv[s], "host": self.host[s], "hi": 0, "items": []}
             for rep in range(self.repeat):
@@ -389,11 +384,15 @@ class PackedGather:
                 o = seg["hi"]
                 seg["hi"] = o + m
                 drow = seg["dev"][o:o + m]
-                if r == self.dst:
-                    with torch.cuda.stream(self.stream):
-                        drow.copy_(self.src[slot][:m], non_blocking=True)
-                else:
-                    self._ops.append(dist.P2POp(dist.irecv, drow, self._g(r), self.group))
+                with torch.cuda.stream(self.stream):
+                    if r == self.dst:
+                        if _DIAG != "nocopies":
+                            drow.copy_(self.src[slot][:m], non_blocking=True)
+                    else:
+                        # a plain irecv per part, matching the peers' plain isend on the per-pair communicator _handshake created
+                        # (dist.batch_isend_irecv would move the receives to the group's collective communicator, where a
+                        # peer's plain isend never meets them)
+                        dist.irecv(drow, src=self._g(r), group=self.group).wait()      # (wait = the side stream waits; the host does not)
                 seg["items"].append((i, o, nbytes))
             b["posted"] += self.repeat
             return
@@ -408,14 +407,6 @@ class PackedGather:
             b["open"].append((i, comp, hrow, nbytes))
         b["posted"] += self.repeat
         return
-
-    def _flush_ops_only(self):
-        if self._ops:
-            ops, self._ops = self._ops, []
-            with torch.cuda.stream(self.stream):
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            self.recv_groups += 1
 
     def _progress(self):
         """Rank dst: take the control messages that have arrived, post the data receives they announce (in order per peer, while the ring
@@ -441,13 +432,13 @@ class PackedGather:
                 k, nbytes, flag = q.pop(0)
                 self._receive(r, k, nbytes, flag)
         if self.nccl:
-            self._flush()                  # everything announced by now: one receive group; complete batches: one D2H each
+            self._flush()                  # complete batches: one D2H each
         for k in sorted(self.batches):
             b = self.batches[k]
             still = []
             for i, comp, hrow, nbytes in b["open"]:
                 if self._done(comp):
-                    b["parts"][i] = self._lib.Packed(hrow.numpy()[:nbytes])
+                    b["parts"][i] = self._lib.Packed(hrow.numpy()[:nbytes]) if not _DIAG else None
                     b["left"] -= 1
                 else:
                     still.append((i, comp, hrow, nbytes))
@@ -476,6 +467,12 @@ class PackedGather:
             ph[name] = ph.get(name, 0.0) + now - _t[0]
             _t[0] = now
         slot, hdr = self.h.packed_results()
+        if _DIAG == "header":              # measurement aid (tools/r06_gather_diag.sh): the pack kernels and the header read only
+            self.seq += 1
+            self.collected = self.done_upto = self.seq
+            self.seconds.append(time.perf_counter() - t0)
+            self.phases.append(ph)
+            return
         overflow = bool(hdr["overflow"])
         nbytes = int(hdr["bytes"])
         mark("header")
