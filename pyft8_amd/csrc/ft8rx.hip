@@ -417,10 +417,19 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     bool ok = true;
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CHK_N), FT8_CHK_N, sizeof(FT8_CHK_N)) == hipSuccess;
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CHK_V), FT8_CHK_V, sizeof(FT8_CHK_V)) == hipSuccess;
-    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_CHK_E0), FT8_CHK_E0, sizeof(FT8_CHK_E0)) == hipSuccess;
-    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_EDGE_V), FT8_EDGE_V, sizeof(FT8_EDGE_V)) == hipSuccess;
-    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_EDGE_C), FT8_EDGE_C, sizeof(FT8_EDGE_C)) == hipSuccess;
-    ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_VAR_E), FT8_VAR_E, sizeof(FT8_VAR_E)) == hipSuccess;
+    {   // k_bp's edge slots, renumbered slot-major (round 6): edge j of check c lives at 83 j + c (j < 6), the seventh edge of the 24
+        // degree-7 checks (c >= 59) at 498 + (c - 59).  The check-parallel products then read CONSECUTIVE words, tl[c + 83 j] -- with
+        // the generated row-major numbering (check c's edges at 6 c .. 6 c + 5) lane c read word 6 c + j: 16 banks, four lanes each.
+        // Only the names of the slots change: products still run over j ascending, a variable's three deltas are still added in
+        // the order of FT8_VAR_E (ascending ROW-MAJOR edge number = np.add.at's order, decoders.py:150).
+        static uint8_t ev[522], ec[522]; static uint16_t ve[174][3];
+        auto slot = [](int e) { const int c = FT8_EDGE_C[e], j = e - FT8_CHK_E0[c]; return j < 6 ? 83 * j + c : 498 + (c - 59); };
+        for (int e = 0; e < 522; e++) { ev[slot(e)] = FT8_EDGE_V[e]; ec[slot(e)] = FT8_EDGE_C[e]; }
+        for (int v = 0; v < 174; v++) for (int k = 0; k < 3; k++) ve[v][k] = (uint16_t)slot(FT8_VAR_E[v][k]);
+        ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_EDGE_V), ev, sizeof(ev)) == hipSuccess;
+        ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_EDGE_C), ec, sizeof(ec)) == hipSuccess;
+        ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_VAR_E), ve, sizeof(ve)) == hipSuccess;
+    }
     ok &= hipMemcpyToSymbol(HIP_SYMBOL(d_G0), FT8_G0, sizeof(FT8_G0)) == hipSuccess;
     {   // per-check membership masks (3 x 64 bits), so a lane gets its two checks' masks with 6 coalesced loads
         static uint64_t cm[128][3];

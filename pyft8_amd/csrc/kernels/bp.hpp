@@ -83,7 +83,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
     // unsatisfied-check test (decoders.py:159), so they are loaded lazily below
     int ev_[9], ec_[9];
     uint32_t ve_[3] = {0u, 0u, 0u};          // the three edges of this lane's variables (lane, 64 + lane, 128 + lane), 10 bits each
-    int n0 = 0, e00 = 0, n1 = 0, e01 = 0;
+    int n0 = 0, n1 = 0;
     bool tables = false;
     float mc[9];
 #pragma unroll
@@ -115,8 +115,8 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
             tables = true;
 #pragma unroll
             for (int i = 0; i < 9; i++) { int e = lane + 64 * i; ev_[i] = (e < 522) ? d_EDGE_V[e] : 174; ec_[i] = (e < 522) ? d_EDGE_C[e] : 83; }
-            n0 = d_CHK_N[c0]; e00 = d_CHK_E0[c0];
-            n1 = (c1 < 83) ? d_CHK_N[c1] : 0; e01 = (c1 < 83) ? d_CHK_E0[c1] : 0;
+            n0 = d_CHK_N[c0];
+            n1 = (c1 < 83) ? d_CHK_N[c1] : 0;
             // (these used to be read from the global table in EVERY iteration: three dependent global loads in front of the LDS reads)
 #pragma unroll
             for (int q = 0; q < 3; q++) {
@@ -133,16 +133,18 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
         BT(2);
         __syncthreads();
         {
-            float Pp = tl[e00];
+            // edge j of check c sits in slot 83 j + c, the seventh edge of a degree-7 check (c >= 59) in slot 498 + c - 59
+            // (ft8rx_create): consecutive lanes read consecutive words
+            float Pp = tl[c0];
 #pragma unroll
-            for (int j = 1; j < 6; j++) Pp = Pp * tl[e00 + j];
-            if (n0 == 7) Pp = Pp * tl[e00 + 6];
+            for (int j = 1; j < 6; j++) Pp = Pp * tl[c0 + 83 * j];
+            if (n0 == 7) Pp = Pp * tl[439 + c0];
             P[c0] = Pp;
             if (c1 < 83) {
-                float Q = tl[e01];
+                float Q = tl[c1];
 #pragma unroll
-                for (int j = 1; j < 6; j++) Q = Q * tl[e01 + j];
-                if (n1 == 7) Q = Q * tl[e01 + 6];
+                for (int j = 1; j < 6; j++) Q = Q * tl[c1 + 83 * j];
+                if (n1 == 7) Q = Q * tl[439 + c1];
                 P[c1] = Q;
             }
         }

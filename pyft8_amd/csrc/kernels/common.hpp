@@ -58,7 +58,6 @@ __device__ __constant__ int8_t d_AP_END[3][19] = {{0,1, 1,1,1,1,1, 0,0,1,1,1, 0,
 // LDPC tables in device memory (copies of ft8_tables.h)
 __device__ uint8_t  d_CHK_N[83];
 __device__ int16_t  d_CHK_V[83][7];
-__device__ uint16_t d_CHK_E0[83];
 __device__ uint8_t  d_EDGE_V[522];
 __device__ uint8_t  d_EDGE_C[522];
 __device__ uint16_t d_VAR_E[174][3];
