@@ -21,7 +21,7 @@
  *     decoders.py      ft8rx_ldpc  ft8rx_osd  ft8rx_crc_valid  ft8rx_valid77                           (ldpc_decode, osd_012, crc_unpack91, unpack)
  *     streaming        ft8rx_hop_spectrum  ft8rx_sync_search                                       (AudioIn._callback, Receiver.search)
  *     multi-GPU        ft8rx_set_packed_output  ft8rx_packed_results  ft8rx_packed_output_fence  ft8rx_package_packed  ft8rx_alloc_host
- *                      ft8rx_free_host  ft8rx_device_pci_bus_id                                     (the gather of decoded messages)
+ *                      ft8rx_free_host  ft8rx_d2h_async / _query / _event  ft8rx_device_pci_bus_id                                     (the gather of decoded messages)
  *   TUNING AND SERVICE (defaults are the measured best; results never depend on them)
  *     ft8rx_set_streams  ft8rx_set_subbatch  ft8rx_set_ladder_mode  ft8rx_set_reject_log  ft8rx_staging_audio  ft8rx_copy_to_host
  *     ft8rx_results_to_device
@@ -342,6 +342,14 @@ int  ft8rx_set_reject_log(const char* path);
 /* the handle's own device audio buffer ([max_frames][180000] int16) and a D2H copy helper (tests, tools) */
 int16_t* ft8rx_staging_audio(ft8rx_handle* h);
 int  ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes);
+/* Asynchronous device -> page-locked-host copies on the handle's result-copy stream (the one stream no decode kernel waits behind; a
+ * copy on any other stream of the process shares a hardware queue with a decode stream and holds its kernels back while it runs).
+ * For consumers of device-side results -- the gather on rank `dst` (pyft8_amd/distributed.py).  At most 32 in flight.
+ *   ft8rx_d2h_async: enqueue; *ticket identifies the copy     ft8rx_d2h_query: 1 landed, 0 not yet, < 0 error
+ *   ft8rx_d2h_event: the hipEvent_t recorded behind the copy (valid until 32 more copies were issued), e.g. for ft8rx_packed_output_fence */
+int   ft8rx_d2h_async(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes, int32_t* ticket);
+int   ft8rx_d2h_query(ft8rx_handle* h, int32_t ticket);
+void* ft8rx_d2h_event(ft8rx_handle* h, int32_t ticket);
 /* ---- signal subtraction ------------------------------------------------------
  * One decoded signal to remove: its 79 tones (Costas + Gray-coded codeword), refined frequency and start time.  96 bytes. */
 typedef struct {

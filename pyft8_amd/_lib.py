@@ -361,6 +361,28 @@ class Handle:
         if getattr(self, "_packed_keep", None) is not None:
             self._packed_keep["fence"][int(which)] = keep
 
+    def d2h_async(self, dst_ptr, src_ptr, nbytes):
+        """ft8rx_d2h_async: device -> page-locked host copy on the handle's result-copy stream; -> ticket (d2h_done / d2h_event)."""
+        L = self._L
+        L.ft8rx_d2h_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_int32)]
+        t = C.c_int32()
+        self._chk(L.ft8rx_d2h_async(self._h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), C.c_uint64(int(nbytes)), C.byref(t)), "ft8rx_d2h_async")
+        return int(t.value)
+
+    def d2h_done(self, ticket):
+        L = self._L
+        L.ft8rx_d2h_query.argtypes = [C.c_void_p, C.c_int32]
+        r = L.ft8rx_d2h_query(self._h, int(ticket))
+        if r < 0:
+            raise Ft8rxError(f"ft8rx_d2h_query failed ({r}): {L.ft8rx_last_error(self._h).decode()}")
+        return r == 1
+
+    def d2h_event(self, ticket):
+        L = self._L
+        L.ft8rx_d2h_event.argtypes = [C.c_void_p, C.c_int32]
+        L.ft8rx_d2h_event.restype = C.c_void_p
+        return L.ft8rx_d2h_event(self._h, int(ticket))
+
     def packed_results(self):
         """ft8rx_packed_results: (which of the two packed buffers, its header as a dict) for the batch the last fetch returned."""
         which = C.c_int32()

@@ -124,6 +124,7 @@ struct ft8rx_handle {
     unsigned char* pk_buf[2]; uint64_t pk_cap; uint64_t* d_pkneed; int32_t* d_pknrec;
     ft8rx_packed_header* h_pkhdr[2]; ft8rx_packed_header* d_pkhdr[2]; bool slot_packed[2]; int fetched_slot;
     hipEvent_t pk_fence[2];                      // ft8rx_packed_output_fence: the consumer's "done reading this buffer" event
+    hipEvent_t d2h_ev[32]; uint32_t d2h_next;    // ft8rx_d2h_async: tickets (a ring of events on the result-copy stream)
     // signal subtraction (extension, allocated on first use): float32 working copy, per-chunk partial sums, GFSK tables
     float* d_wf; double2* d_part; double* d_pulse; double* d_pc; ft8rx_subsig* d_sigs; int32_t* d_sigcnt; int sig_cap;
     float2 *d_zdec, *d_model, *d_adec; SubdCtx* d_subctx;      // decimated-baseband refinement (refine = 2), allocated on first use
@@ -294,6 +295,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
     for (auto& c : h->arena) hipFree(c.p);
     for (auto e : h->pev) hipEventDestroy(e);
     for (int k = 0; k < 2; k++) for (int i = 0; i < 8; i++) if (h->ev_cdone[k][i]) hipEventDestroy(h->ev_cdone[k][i]);
+    for (int i = 0; i < 32; i++) if (h->d2h_ev[i]) hipEventDestroy(h->d2h_ev[i]);
     for (int i = 0; i < 16; i++) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (int k = 0; k < 2; k++) {
@@ -330,6 +332,8 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     h->free_running = false; h->need_barrier = true; h->part_B = h->part_n = 0;
     h->d_wf = nullptr; h->d_part = nullptr; h->d_pulse = nullptr; h->d_pc = nullptr; h->d_sigs = nullptr; h->d_sigcnt = nullptr; h->sig_cap = 0;
     h->d_colmask = nullptr; h->use_mask = false;
+    for (int i = 0; i < 32; i++) h->d2h_ev[i] = nullptr;
+    h->d2h_next = 0;
     h->pk_buf[0] = h->pk_buf[1] = nullptr; h->pk_cap = 0; h->d_pkneed = nullptr; h->d_pknrec = nullptr; h->fetched_slot = -1;
     for (int k = 0; k < 2; k++) { h->h_pkhdr[k] = nullptr; h->d_pkhdr[k] = nullptr; h->slot_packed[k] = false; h->pk_fence[k] = nullptr; }
     h->d_zdec = nullptr; h->d_model = nullptr; h->d_adec = nullptr; h->d_subctx = nullptr; h->d_ones = nullptr;
@@ -481,6 +485,9 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
     for (int i = 0; i < 24; i++) { hipEvent_t e = nullptr; okc = okc && hipEventCreate(&e) == hipSuccess; if (e) h->pev.push_back(e); }
     // (the chunk streams h->sub[] are created on first use, launch_batch: every stream that exists competes for one of the
     // runtime's four hardware queues, see the note there)
+    // (measurement aid: FT8RX_SUBS_FIRST=n creates n chunk streams BEFORE the copy streams, i.e. gives them hardware queues of their own
+    // -- for A/B runs of three or four chunk streams, profiles/r06_notes.md)
+    if (const char* e = getenv("FT8RX_SUBS_FIRST")) for (int i = 0; i < atoi(e) && i < 8; i++) pool_sub(device, i);
     okc = okc && (h->copy_s = pool_stream(device, &StreamPool::copy, false)) != nullptr;
     okc = okc && (h->h2d_s = pool_stream(device, &StreamPool::h2d, false)) != nullptr;
     for (int i = 0; i < 16; i++) okc = okc && hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
@@ -1144,6 +1151,42 @@ int ft8rx_valid77(ft8rx_handle* h, const uint64_t* msg_lo, const uint64_t* msg_h
 int16_t* ft8rx_staging_audio(ft8rx_handle* h) {
     if (!h || hipSetDevice(h->device) != hipSuccess || need_staging(h)) return nullptr;
     return h->d_audio;
+}
+
+// Asynchronous D2H copies for a consumer of device-side results (the gather on rank `dst`, pyft8_amd/distributed.py), on the handle's
+// RESULT-COPY stream: the one stream of the handle no decode kernel ever waits behind.  The runtime maps streams onto four hardware
+// queues and the commands of a queue execute in order, so a copy issued on any OTHER stream of the process (a torch side stream)
+// lands in a queue it shares with one of the decode streams and holds that stream's kernels back for as long as it runs -- 12 MB per
+// step (rank 0's load in an 8-GPU config-1 job) cost 4.7 % of the step that way (profiles/r06_notes.md).
+int ft8rx_d2h_async(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes, int32_t* ticket) {
+    if (!h || !dst || !d_src || !ticket) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint32_t id = h->d2h_next;
+    hipEvent_t& e = h->d2h_ev[id & 31];
+    if (!e) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    else if (id >= 32 && hipEventQuery(e) == hipErrorNotReady) { set_err(h, "ft8rx_d2h_async: 32 copies in flight"); return -3; }
+    if (bytes) HIPCHK(h, hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, h->copy_s));
+    HIPCHK(h, hipEventRecord(e, h->copy_s));
+    h->d2h_next = id + 1;
+    *ticket = (int32_t)(id & 0x7fffffffu);
+    return 0;
+}
+int ft8rx_d2h_query(ft8rx_handle* h, int32_t ticket) {              // 1 = the copy has landed, 0 = not yet, < 0 = error
+    if (!h || ticket < 0) return -1;
+    const uint32_t id = (uint32_t)ticket, next = h->d2h_next & 0x7fffffffu;
+    if (((next - id) & 0x7fffffffu) > 32u) return 1;               // its event has been reused since: long done
+    if (((next - id) & 0x7fffffffu) == 0u) return -1;              // never issued
+    const hipError_t r = hipEventQuery(h->d2h_ev[id & 31]);
+    if (r == hipSuccess) return 1;
+    if (r == hipErrorNotReady) return 0;
+    set_err(h, "ft8rx_d2h_query: %s", hipGetErrorString(r));
+    return -2;
+}
+void* ft8rx_d2h_event(ft8rx_handle* h, int32_t ticket) {            // the HIP event behind that copy (for ft8rx_packed_output_fence), or NULL
+    if (!h || ticket < 0) return nullptr;
+    const uint32_t id = (uint32_t)ticket, next = h->d2h_next & 0x7fffffffu;
+    const uint32_t age = (next - id) & 0x7fffffffu;
+    return (age >= 1u && age <= 32u) ? (void*)h->d2h_ev[id & 31] : nullptr;
 }
 
 int ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes) {

@@ -30,28 +30,17 @@ __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, fl
     __syncthreads();
     // T[r][f] = sum_{b<14} tile[r][f+b], accumulated in the contract's order (b ascending, fp64); every time offset that
     // touches row r reuses it, so the 98-tap correlation becomes 7 window sums + 14 tone-bin reads.
-    // LDS banks (round 6): a wave's 64 lanes are 16 columns x 4 rows, and with the tile's row stride of 29 words four ADJACENT rows
-    // put up to four lanes on one bank (29 q mod 32 = 0, 29, 26, 23).  Rows 16 apart differ by 464 words = 16 banks: the four rows
-    // then cover every bank exactly twice -- the minimum for 64 lanes -- in the window sums here and in the score loop below.  (Which
-    // thread forms which sum does not change any sum; in the score loop every thread still walks its h0 in ascending order and the
-    // reduction below breaks ties towards the smaller h0: the first strict maximum.)
-    for (int i = tid; i < ((nrows + 63) >> 6) * 1024; i += 256) {
-        const int col = i & 15, q = (i >> 4) & 3, rest = i >> 6;
-        const int r = (rest >> 4) * 64 + (rest & 15) + 16 * q;
-        if (r >= nrows) continue;
-        const float* row = tile + r * 29 + col;
+    for (int i = tid; i < nrows * 16; i += 256) {
+        const float* row = tile + (i >> 4) * 29 + (i & 15);
         double t = 0.0;
 #pragma unroll
         for (int b = 0; b < 14; b++) t += (double)row[b];
-        T[r * 16 + col] = t;
+        T[i] = t;
     }
     __syncthreads();
     const int f0l = tid & 15;
     float best = 0.0f; int bh = 0;
-    const int hq = (tid >> 6) + 16 * ((tid >> 4) & 3);               // wave w, row group q: h0 offsets w + 4 j + 16 q + 64 b, ascending in (b, j)
-    for (int it = 0; it < ((nh0 + 63) >> 6) * 4; it++) {
-        const int hi = (it >> 2) * 64 + (it & 3) * 4 + hq;           // it = 4 b + j
-        if (hi >= nh0) continue;
+    for (int hi = tid >> 4; hi < nh0; hi += 16) {
         double s1 = 0.0, tsum = 0.0;
 #pragma unroll
         for (int s = 0; s < 7; s++) {

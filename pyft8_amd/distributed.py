@@ -200,7 +200,8 @@ class PackedGather:
         self.row = 0
         self.row_history = []              # rank dst: every row size the receive sets have had (growth is visible to tests)
         self.recv = self.host = None       # rank dst: allocated by _room() from the first byte counts seen
-        self.d2h_copies = 0                # rank dst, device path: D2H copies made so far (one per batch)
+        self.d2h_copies = 0                # rank dst, device path: D2H copies issued so far (own part + one per run of landed parts)
+        self._local_reads = None
         # control messages travel on the host, through the store: a device-side exchange would make the host wait for the side stream,
         # which shares one of the runtime's few hardware queues with a chunk stream of the decode (135 ms per step at config 3, r04)
         PackedGather._instances += 1
@@ -306,7 +307,7 @@ class PackedGather:
         """Rank dst: `depth` receive sets with room for world x repeat parts of at least m bytes each.  Sized to twice the first part seen;
         a later part that needs more gets new, larger sets -- parts already received (or being received) keep their old memory alive.
         A set is ONE flat device buffer and ONE flat page-locked host buffer: a batch's parts are packed back to back in arrival order
-        (256-byte aligned), so that one D2H copy moves a whole batch (_close_segment)."""
+        (256-byte aligned), so that one D2H copy can move all of a batch's received parts (_copy_landed)."""
         if m <= self.row:
             return
         self.row = min(self.cap, max(2 * m, self.MIN_ROW))
@@ -323,31 +324,38 @@ class PackedGather:
     def _batch(self, k):
         if k not in self.batches:
             self.batches[k] = {"parts": [None] * (self.world * self.repeat), "left": self.world * self.repeat, "err": None, "open": [],
-                               "posted": 0, "seg": None}
+                               "posted": 0, "seg": None, "items": []}
         return self.batches[k]
 
-    def _close_segment(self, b):
-        """Device path: ONE D2H copy and ONE event for everything of this batch that has been received into the current segment of its
-        set (rounds 4-5 made a copy and an event per part: eight of each per step on rank dst of an 8-rank job, every one a command in
-        a hardware queue the decode streams share).  Called when the last part of the batch has been posted (the copy then waits, on
-        the side stream, for every receive of the batch) or when the sets are replaced by larger ones in the middle of a batch."""
-        seg, b["seg"] = b["seg"], None
-        if not seg or seg["hi"] == 0:
+    def _copy_landed(self, b):
+        """Device path, rank dst: move what has LANDED in device memory to the page-locked host buffer -- one D2H copy per run of
+        neighbouring parts (all remote parts of a batch in one copy when the peers run in lockstep), issued through the handle on ITS
+        result-copy stream (ft8rx_d2h_async).  Rounds 4-5 made a copy and an event per part on the torch side stream; the side stream
+        shares a hardware queue with one of the decode streams, whose kernels then waited behind every copy: 12 MB per step -- rank
+        dst's load in an 8-rank config-1 job -- cost 4.7 % of the step (profiles/r06_notes.md).  Nothing is copied while a receive of
+        this batch is still in flight (it lands within the millisecond and extends the run); a peer that has not even announced its
+        part holds nothing back."""
+        items = b["items"]
+        for it in items:
+            if it["state"] == "receiving" and it["ev"].query():
+                it["state"] = "landed"
+        if any(it["state"] == "receiving" for it in items):
             return
-        with torch.cuda.stream(self.stream):
-            if _DIAG != "nod2h":
-                seg["host"][:seg["hi"]].copy_(seg["dev"][:seg["hi"]], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self.d2h_copies += 1
-        for i, o, nbytes in seg["items"]:
-            b["open"].append((i, ev, seg["host"][o:o + nbytes], nbytes))
-
-    def _flush(self):
-        """Device path: close the segment of every batch whose parts have all been posted (one D2H + one event per batch)."""
-        for b in self.batches.values():
-            if b["seg"] is not None and b["posted"] >= self.world * self.repeat:
-                self._close_segment(b)
+        run = []
+        for it in items + [None]:
+            if it is not None and it["state"] == "landed" and (not run or (it["seg"] is run[-1]["seg"] and it["o"] == run[-1]["o"] + run[-1]["m"])):
+                run.append(it)
+                continue
+            if run:
+                seg, o0 = run[0]["seg"], run[0]["o"]
+                n = run[-1]["o"] + run[-1]["m"] - o0
+                t = self.h.d2h_async(seg["host"].data_ptr() + o0, seg["dev"].data_ptr() + o0, n)
+                self.d2h_copies += 1
+                for x in run:
+                    x["state"], x["ticket"] = "copying", t
+                run = []
+            if it is not None and it["state"] == "landed":
+                run = [it]
 
     def _set_free(self, k):
         """May parts of batch k be received now?  (a) Its receive set last held batch k - depth, which must be complete -- an uncollected
@@ -363,7 +371,7 @@ class PackedGather:
 
     def _receive(self, r, k, nbytes, flag, slot=None):
         """Rank dst: post the data receive(s) of peer r's batch k (or take the local copy for r == dst).  Device path: the part gets its
-        place in the batch's segment (flat buffer, parts back to back); _flush() copies a completely posted batch to the host."""
+        place in the batch's segment (flat buffer, parts back to back); _copy_landed() moves what has landed to the host."""
         b = self._batch(k)
         if flag:
             b["err"] = f"rank {r} reported a packed-buffer overflow for batch {k} ({nbytes} bytes needed; raise per_frame)"
@@ -376,24 +384,34 @@ class PackedGather:
         if self.nccl:
             seg = b["seg"]
             if seg is None or seg["dev"] is not self.recv[s]:       # first part of the batch, or the sets have just been replaced by larger ones
-                if seg is not None:
-                    self._close_segment(b)
-                seg = b["seg"] = {"dev": self.recv[s], "host": self.host[s], "hi": 0, "items": []}
+                seg = b["seg"] = {"dev": self.recv[s], "host": self.host[s], "hi": 0}
             for rep in range(self.repeat):
                 i = rep * self.world + r
                 o = seg["hi"]
                 seg["hi"] = o + m
-                drow = seg["dev"][o:o + m]
-                with torch.cuda.stream(self.stream):
-                    if r == self.dst:
-                        if _DIAG != "nocopies":
+                it = {"i": i, "seg": seg, "o": o, "m": m, "nbytes": nbytes, "state": "receiving", "ev": None, "ticket": None}
+                if r == self.dst and rep == 0:
+                    # this rank's own part: straight from the pack buffer to the host buffer on the handle's copy stream -- no device
+                    # copy, nothing on the side stream; the next pack into this buffer waits for the copy's event
+                    it["ticket"] = self.h.d2h_async(seg["host"].data_ptr() + o, self.src[slot].data_ptr(), m)
+                    it["state"] = "copying"
+                    self.d2h_copies += 1
+                    self.h.packed_fence(slot, self.h.d2h_event(it["ticket"]))
+                else:
+                    drow = seg["dev"][o:o + m]
+                    with torch.cuda.stream(self.stream):
+                        if r == self.dst:                               # repeat > 1 (measurement aid): a device copy stands in for a receive
                             drow.copy_(self.src[slot][:m], non_blocking=True)
-                    else:
-                        # a plain irecv per part, matching the peers' plain isend on the per-pair communicator _handshake created
-                        # (dist.batch_isend_irecv would move the receives to the group's collective communicator, where a
-                        # peer's plain isend never meets them)
-                        dist.irecv(drow, src=self._g(r), group=self.group).wait()      # (wait = the side stream waits; the host does not)
-                seg["items"].append((i, o, nbytes))
+                        else:
+                            # a plain irecv per part, matching the peers' plain isend on the per-pair communicator _handshake created
+                            # (dist.batch_isend_irecv would move the receives to the group's collective communicator, where a
+                            # peer's plain isend never meets them)
+                            dist.irecv(drow, src=self._g(r), group=self.group).wait()      # (wait = the side stream waits; the host does not)
+                        it["ev"] = torch.cuda.Event()
+                        it["ev"].record(self.stream)
+                    if r == self.dst:
+                        self._local_reads = it["ev"]
+                b["items"].append(it)
             b["posted"] += self.repeat
             return
         for rep in range(self.repeat):
@@ -431,14 +449,19 @@ class PackedGather:
             while q and self._set_free(q[0][0]):
                 k, nbytes, flag = q.pop(0)
                 self._receive(r, k, nbytes, flag)
-        if self.nccl:
-            self._flush()                  # complete batches: one D2H each
         for k in sorted(self.batches):
             b = self.batches[k]
+            if self.nccl:
+                self._copy_landed(b)
+                for it in b["items"]:
+                    if it["state"] == "copying" and self.h.d2h_done(it["ticket"]):
+                        it["state"] = "done"
+                        b["parts"][it["i"]] = self._lib.Packed(it["seg"]["host"].numpy()[it["o"]:it["o"] + it["nbytes"]])
+                        b["left"] -= 1
             still = []
             for i, comp, hrow, nbytes in b["open"]:
                 if self._done(comp):
-                    b["parts"][i] = self._lib.Packed(hrow.numpy()[:nbytes]) if not _DIAG else None
+                    b["parts"][i] = self._lib.Packed(hrow.numpy()[:nbytes])
                     b["left"] -= 1
                 else:
                     still.append((i, comp, hrow, nbytes))
@@ -528,11 +551,9 @@ class PackedGather:
         self._progress()
         mark("sizes")
         self._receive(self.dst, k, nbytes, 1 if overflow else 0, slot)
-        if self.nccl and not overflow:
-            # the local copy reads src[slot] on the side stream: fence the next pack into it, like a send
-            with torch.cuda.stream(self.stream):
-                ev = torch.cuda.Event()
-                ev.record(self.stream)
+        if self.nccl and not overflow and self.repeat > 1:
+            # (measurement aid) the stand-in copies read src[slot] on the side stream after the D2H was enqueued: fence on them instead
+            ev = self._local_reads
             self.h.packed_fence(slot, ev.cuda_event, keep=ev)
         self._progress()
         mark("issue")
