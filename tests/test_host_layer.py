@@ -491,6 +491,24 @@ def _dense_goldens(names):
     return np.stack(recs), np.array(cnts, np.int32), np.stack(evs), np.array(evcs, np.int32)
 
 
+def test_osd_dpp_stages_keep_their_wait_states():
+    """k_osd's sort network reads partner lanes through DPP operands inside inline-assembly blocks (csrc/kernels/osd.hpp); a VALU write
+    of a DPP source needs two wait states before the read, and the compiler's hazard recognizer does not look inside inline asm
+    (ADVICE r5).  tools/dpp_hazard_check.py scans the disassembly of both shipped builds: every one of the 360 DPP instructions per
+    kernel keeps its distance -- a rebuild with another hipcc that schedules a producer right in front of an asm block fails here."""
+    import importlib.util
+    from conftest import ROOT
+    from pyft8_amd import _lib
+    spec = importlib.util.spec_from_file_location("dpp_hazard_check", os.path.join(ROOT, "tools", "dpp_hazard_check.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    if not os.path.exists(os.path.join(m.LLVM, "llvm-objdump")):
+        pytest.skip("llvm-objdump not installed")
+    for lib in (_lib.LIB_PATH, _lib.LIB_PATH_WIDE):
+        n, bad = m.scan(lib)
+        assert n >= 360 and not bad, (lib, n, bad[:3])
+
+
 def test_host_layer_with_more_than_256_candidates():
     """max_cands is open-ended (receiver.py:311-313, 366-367): record arrays wider than 256 candidates are packaged by the copy of the
     host layer inside libft8rx_wide.so (FT8RX_MAX_CANDS = 2048).  Oracle records of one frame at max_cands = 600 / sync_score_min = 30:
