@@ -7,9 +7,16 @@
  *
  * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on
  * success and a negative code on failure (ft8rx_last_error() gives the text); nothing throws
- * across the ABI.  One handle == one HIP device + one stream; a handle is not thread-safe,
- * separate handles are.  All device workspaces are allocated at ft8rx_create(); the hot path
- * allocates nothing.  Pointers are host pointers unless the parameter is named d_*.
+ * across the ABI.  One handle == one HIP device + its workspaces; a handle is not thread-safe.
+ * Separate handles may be driven from separate threads, but the handles of one process on one
+ * device SHARE their HIP streams (a process-wide pool per device: main, second chunk stream, result
+ * copy, H2D -- the runtime maps streams onto four hardware queues when they are created, and a
+ * later handle's own streams could land two chunk streams on one queue): work of two handles
+ * on one device serialises on those streams, ft8rx_sync / ft8rx_destroy of one waits for the
+ * other's queued work, and ft8rx_set_profiling stage times include the other handle's kernels.
+ * For independent concurrent decoding use one process per GPU (the multi-GPU path does).
+ * All device workspaces are allocated at ft8rx_create(); the hot path allocates nothing.
+ * Pointers are host pointers unless the parameter is named d_*.
  */
 /* MAP OF THE ABI -- which entry points an adopter binds, and which exist for tests and measurements.
  *
@@ -312,7 +319,9 @@ int  ft8rx_synth_frames_ex(ft8rx_handle* h, uint64_t seed, int first_index, int 
  *   table != NULL : frames are replayed in order on the caller's thread against that persistent table, which they update --
  *                   the reference's process-global `call_hashes` (databases.py:8): a hashed / non-standard call heard in
  *                   cycle N resolves `<...>` in cycle N+1.  This is what the streaming receiver uses.
- * flags (optional, [n_frames]): FT8RX_PKG_* bits per frame. */
+ * flags (optional, [n_frames]): FT8RX_PKG_* bits per frame.
+ * The packager runs its frames on a persistent pool of worker threads owned by the library; ONE ft8rx_package_batch /
+ * ft8rx_package_packed call uses the pool at a time, concurrent callers of a process queue behind each other. */
 #define FT8RX_PKG_MSG_TRUNCATED    1   /* more than max_msgs messages: the list was cut (size max_msgs >= cfg.max_cands to rule it out) */
 #define FT8RX_PKG_EVENTS_TRUNCATED 2   /* event_counts[f] > FT8RX_EVENT_CAP: unpack() calls were dropped, `<...>` strings may differ */
 int  ft8rx_package_batch(const ft8rx_record* records, const int32_t* counts, const ft8rx_event* events, const int32_t* event_counts,

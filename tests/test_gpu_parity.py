@@ -1014,12 +1014,19 @@ def test_wide_time_window_clamped_symbols():
         rec, cnt, ev, evc = h.decode_batch(audio)
         h.close()
         ocfg = O.default_config(**_lib.fft_plans(), sync_score_min=70.0, max_cands=256, f0_lo=cfg.f0_lo, f0_hi=cfg.f0_hi, h0_lo=cfg.h0_lo, h0_hi=cfg.h0_hi)
-        n_edge = 0
+        n_edge = n_boundary = 0
         for i in range(3):
             _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
-            h0 = rec[i]["h0_idx"][:cnt[i]]
+            r = rec[i][:cnt[i]]
+            h0 = r["h0_idx"].astype(np.int64)
             n_edge += int(((h0 < -4) | (h0 > 84)).sum())
+            # a symbol starting EXACTLY at the clamp position 3168 with later symbols behind it (round 6: it takes the clamp row, bit-identical
+            # to theirs as in the reference): first sample of symbol 0 = 8 h0 (+ 1 for h0 < 0) + ttweak, a multiple of 32 beyond 672
+            tb = 8 * h0 + (h0 < 0) + r["ttweak"].astype(np.int64)
+            n_boundary += int(((r["nsync"] > 0) & (tb % 32 == 0) & (tb > 672) & (tb <= 3168)).sum())      # nsync > 0: the fine sync ran
         assert n_edge > 50, n_edge           # the window really produced candidates with clamped symbols
+        if tr[1] > 8.0:
+            assert n_boundary >= 3, n_boundary       # ... and some with the boundary symbol among them
 
 
 def test_candidate_cap_and_kwarg_limits():

@@ -17,7 +17,11 @@ from pyft8_amd.receiver import config_from_kwargs  # noqa: E402
 KW = [dict(), dict(), dict(sync_score_min=100, max_cands=150), dict(search_freq_range=[300, 2500], search_time_range=[-1.0, 2.0]),
       dict(search_freq_range=[100, 5900]), dict(search_freq_range=[1500, 4200], max_cands=90), dict(bp_iters_b=30, osd_single=40, osd_double=4),
       dict(osd_triple=20, osd_max_hd=34), dict(max_cands=256, sync_score_min=70),
-      dict(osd_single=91, osd_double=3)]
+      dict(osd_single=91, osd_double=3),
+      # round 6: wide time windows (symbols read clamped, among them the one that starts exactly at the clamp position) and more
+      # candidates than the default layouts hold (max_cands > 256: the deep layouts of libft8rx_wide.so)
+      dict(search_time_range=[-1.0, 8.2], sync_score_min=70), dict(search_time_range=[2.0, 8.0], sync_score_min=60, max_cands=256),
+      dict(search_time_range=[-6.0, 3.0], sync_score_min=70), dict(max_cands=600, sync_score_min=40)]
 KNOBS = ("bp_nc0_a", "bp_iters_a", "bp_nc0_b", "bp_iters_b", "osd_single", "osd_double", "osd_triple", "osd_max_hd", "llr_sd_min")
 
 
