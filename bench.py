@@ -71,7 +71,7 @@ PMC_PROFILES = {1: os.path.join(ROOT, "profiles", "pmc_latest.json"), 2: os.path
 
 SQ_PROFILE = os.path.join(ROOT, "profiles", "sq_latest.json")      # rocprofv3 --pmc SQ_* passes of `bench.py --streams 1 --subbatch 0` (tools/pmc_sq.sh)
 # vector-instruction issue ceiling: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD (a SIMD executes 32 lanes of a
-# plain fp32 / int32 operation per cycle: tools/ubench/valu_rate.hip, profiles/r02_valu_rate.txt), 2.4 GHz
+# plain fp32 / int32 operation per cycle: tools/ubench/valu_rate.hip, profiles/archive/r02_valu_rate.txt), 2.4 GHz
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
 STAGE_KERNELS = {"spectrogram": ["k_spectrogram"], "sync": ["k_sync"], "topk": ["k_topk"], "grid_llr": ["k_grid_llr", "k_worklist_att"], "bp_grid": ["k_bp"],
                  "select0": ["k_select0"], "cycle_fft": ["k_cyc_a", "k_cyc_bc"], "fine": ["k_fine", "k_worklist"], "bp_fine": ["k_bp", "k_select1"],
@@ -447,7 +447,7 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
     # (GPU_MAX_HW_QUEUES is deliberately left alone: eight hardware queues would give the gather's side stream a queue of its own, but
-    # they cost the decode kernels 9 % -- 53.9 k -> 49.1 k frames/s kernels only, profiles/r04_notes.md.  With the default four the gather's
+    # they cost the decode kernels 9 % -- 53.9 k -> 49.1 k frames/s kernels only, profiles/archive/r04_notes.md.  With the default four the gather's
     # copies may sit behind a chunk's kernel chain for up to one batch; nothing waits for them, the byte counts travel over gloo.)
     import torch
     import torch.distributed as dist

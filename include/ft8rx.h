@@ -240,7 +240,7 @@ int  ft8rx_packed_output_fence(ft8rx_handle* h, int which, void* hip_event);
 int  ft8rx_package_packed(const void* packed, uint64_t bytes, int frame_lo, int n_frames, ft8rx_message* out, int max_msgs,
                           int32_t* out_counts, int n_threads, ft8rx_hashes* table, int32_t* flags);
 /* per-kernel HIP-event timing of the most recent enqueue (enable before enqueue). names/ms: up to 16 */
-/* number of HIP streams a batch is cut across (1..8, default 2: measured best, profiles/r02_notes.md); profiling mode always uses one */
+/* number of HIP streams a batch is cut across (1..8, default 2: measured best, profiles/archive/r02_notes.md); profiling mode always uses one */
 int  ft8rx_set_streams(ft8rx_handle* h, int n);
 /* frames per kernel chain inside a stream's share of a batch (default FT8RX_SUBBATCH_DEFAULT; 0 = the whole share in one chain): a
  * large batch runs as a sequence of cache-sized sub-batches, each through the whole path before the next starts, so that a stage
@@ -353,7 +353,7 @@ int16_t* ft8rx_staging_audio(ft8rx_handle* h);
 int  ft8rx_copy_to_host(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes);
 /* Asynchronous device -> page-locked-host copies on the handle's result-copy stream (the one stream no decode kernel waits behind; a
  * copy on any other stream of the process shares a hardware queue with a decode stream and holds its kernels back while it runs).
- * For consumers of device-side results -- the gather on rank `dst` (pyft8_amd/distributed.py).  At most 32 in flight.
+ * For consumers of device-side results -- the gather on rank `dst` (pyft8_amd/distributed.py).  32 tickets: the 33rd call waits for the oldest.
  *   ft8rx_d2h_async: enqueue; *ticket identifies the copy     ft8rx_d2h_query: 1 landed, 0 not yet, < 0 error
  *   ft8rx_d2h_event: the hipEvent_t recorded behind the copy (valid until 32 more copies were issued), e.g. for ft8rx_packed_output_fence */
 int   ft8rx_d2h_async(ft8rx_handle* h, void* dst, const void* d_src, uint64_t bytes, int32_t* ticket);

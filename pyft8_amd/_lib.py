@@ -14,11 +14,11 @@ LIB_PATH = os.environ.get("FT8RX_LIB", os.path.join(HERE, "libft8rx.so"))   # FT
 LIB_PATH_WIDE = os.environ.get("FT8RX_LIB_WIDE", os.path.join(HERE, "libft8rx_wide.so"))
 SRC = os.path.join(HERE, "csrc", "ft8rx.hip")
 # second translation unit: the FFT kernels (k_fine, k_spectrogram), compiled with the ILP scheduling strategy -- 3.9 % / 3 % faster for
-# them, 56 % slower for k_bp, and the strategy is a per-translation-unit choice (csrc/ft8rx_ilp.hip, profiles/r03_notes.md)
+# them, 56 % slower for k_bp, and the strategy is a per-translation-unit choice (csrc/ft8rx_ilp.hip, profiles/archive/r03_notes.md)
 SRC_ILP = os.path.join(HERE, "csrc", "ft8rx_ilp.hip")
 ILP_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 # -fno-slp-vectorize: on gfx950 a v_pk_add/mul_f32 issues at exactly the cost of the two scalar ops it replaces (tools/ubench/valu_rate.hip,
-# profiles/r02_valu_rate.txt) while the packing costs ~1000 extra v_mov in k_fine: scalar code is 7 % faster there, bit-identical.
+# profiles/archive/r02_valu_rate.txt) while the packing costs ~1000 extra v_mov in k_fine: scalar code is 7 % faster there, bit-identical.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-result",
                "-Wno-unused-value", "-fPIC", "-shared"]
 

@@ -588,7 +588,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
 // A chunk's frames go through the WHOLE chain in cache-sized sub-batches, one after the other on the chunk's stream: a sub-batch's dB
 // grid (1.47 MB per frame) is then still in L2 / the 256 MB MALL when k_sync, k_topk and k_grid_llr read it, and the four-step scratch
 // and cycle spectrum that later overlay it are too when k_cyc_bc / k_fine read them -- a 4096-frame chunk's grid is 6 GB and every
-// stage of it came from HBM (k_spectrogram 0.36 -> 0.42 ms per 256 frames, profiles/r04_batch_sweep.txt).  Every workspace is indexed
+// stage of it came from HBM (k_spectrogram 0.36 -> 0.42 ms per 256 frames, profiles/archive/r04_batch_sweep.txt).  Every workspace is indexed
 // by frame and the chunk's work-list counters are re-zeroed by each chain's k_topk, so consecutive sub-batches on one stream need
 // nothing but stream order.  Results do not depend on the partition (tests/test_gpu_parity.py: test_subbatch_partition_invariance).
 static void enqueue_chunk(ft8rx_handle* h, const int16_t* d_audio, int f0, int n, hipStream_t s, int slot, int chunk) {
@@ -630,7 +630,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     // one execute in submission order: with a main stream that only forks and joins plus two chunk streams plus the two copy
     // streams (five), the H2D stream shared a queue with a chunk stream and its event markers waited behind that chunk's kernels --
     // in the rocprofv3 trace the second H2D chunk of the pipelined host entry started only when the previous batch's last kernel
-    // had finished (profiles/r03_notes.md).  Four streams in use = a queue each.
+    // had finished (profiles/archive/r03_notes.md).  Four streams in use = a queue each.
     const int ns = h->n_streams;
     for (int i = 1; i < ns && nc > 1; i++) if (!h->sub[i - 1]) {
         if (!(h->sub[i - 1] = pool_sub(h->device, i - 1))) { set_err(h, "cannot create a chunk stream"); return -2; }
@@ -643,7 +643,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
     // Without the per-batch fork / join a stream that finishes its half early starts on the next batch while the other one is still
     // in its tail.  Anything else that uses the workspaces (stage entry points, the synchronous entry, a different partition)
     // goes through quiesce() / need_barrier.
-    // (A/B on one box, profiles/r03_notes.md: 48 498 -> 49 001 frames/s end to end, 48 167 -> 48 894 including H2D.)
+    // (A/B on one box, profiles/archive/r03_notes.md: 48 498 -> 49 001 frames/s end to end, 48 167 -> 48 894 including H2D.)
     const bool free_run = !h->profiling && nc > 1 && nc == ns && !(host_audio && !pipelined);
     if (free_run) {
         for (int i = 0; i < ns; i++) for (int k = 0; k < 2; k++)
@@ -697,7 +697,7 @@ static int launch_batch(ft8rx_handle* h, const int16_t* d_audio, const int16_t* 
             // ONE copy for the whole batch and one event: it has the whole previous batch to hide behind, and a copy stream with
             // event markers BETWEEN its copies can stall on them (markers are queue packets: in a hardware queue shared with a
             // chunk stream they wait their turn behind that chunk's kernels -- the second of two chunk copies then started only
-            // at the end of the previous batch, rocprofv3 trace in profiles/r03_notes.md)
+            // at the end of the previous batch, rocprofv3 trace in profiles/archive/r03_notes.md)
             HIPCHK(h, hipMemcpyAsync(stage, host_audio, sizeof(int16_t) * (size_t)B * FT8RX_NSAMP, hipMemcpyHostToDevice, cs));
             HIPCHK(h, hipEventRecord(h->ev_chunk[0], cs));
             for (int i = 0; i < ns; i++) HIPCHK(h, hipStreamWaitEvent(chunk_stream(i), h->ev_chunk[0], 0));
@@ -1164,7 +1164,7 @@ int ft8rx_d2h_async(ft8rx_handle* h, void* dst, const void* d_src, uint64_t byte
     const uint32_t id = h->d2h_next;
     hipEvent_t& e = h->d2h_ev[id & 31];
     if (!e) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    else if (id >= 32 && hipEventQuery(e) == hipErrorNotReady) { set_err(h, "ft8rx_d2h_async: 32 copies in flight"); return -3; }
+    else if (id >= 32 && hipEventQuery(e) == hipErrorNotReady) HIPCHK(h, hipEventSynchronize(e));      // 32 copies in flight: wait for the oldest
     if (bytes) HIPCHK(h, hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, h->copy_s));
     HIPCHK(h, hipEventRecord(e, h->copy_s));
     h->d2h_next = id + 1;

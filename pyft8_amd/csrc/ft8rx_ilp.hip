@@ -3,7 +3,7 @@
 //
 // hipcc's default scheduler and `-mllvm -amdgpu-sched-strategy=iterative-ilp` produce the same arithmetic in a different order; on
 // gfx950 the ILP strategy is 3.9 % faster for k_fine (2.675 -> 2.570 ms per 256 frames) and 3 % for k_spectrogram, but 56 % SLOWER
-// for k_bp (profiles/r03_notes.md) -- and the strategy can only be chosen per translation unit.  So these kernels are built here,
+// for k_bp (profiles/archive/r03_notes.md) -- and the strategy can only be chosen per translation unit.  So these kernels are built here,
 // from the same headers as ft8rx.hip, and ft8rx.hip launches them through the three functions at the bottom.  FT8RX_ILP_UNIT selects
 // this unit's share of the headers: the FFT device code, the three kernels and the plain structs / constant tables they need -- no
 // other kernel and none of the run-time initialised device tables (those live in the main unit only), so every kernel exists exactly

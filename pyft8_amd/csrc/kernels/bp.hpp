@@ -14,9 +14,9 @@
 // The fine-stage attempts run in ladder order in three launches (receiver.py:84-98: GOOD91 ap 0,1; BP_A ap 0,1; BP_B ap 0..4, first
 // success wins): {GOOD91 x 2, BP ap 0} -> k_select1(0) -> {BP ap 1} -> k_select1(1) -> {BP ap 2,3,4} -> k_select1(2).  A candidate
 // that is decided leaves the lists; with all five variants in one launch 42 % of the candidates (the ones that decode here) ran
-// four BPs nobody reads, most of them 20 iterations on wrongly forced bits (profiles/r02_notes.md).
+// four BPs nobody reads, most of them 20 iterations on wrongly forced bits (profiles/archive/r02_notes.md).
 #ifndef BP_WV
-#define BP_WV 7          /* <= 72 VGPRs: 7 waves per SIMD; measured 1.76 -> 1.68 ms for both BP launches (profiles/r02_notes.md) */
+#define BP_WV 7          /* <= 72 VGPRs: 7 waves per SIMD; measured 1.76 -> 1.68 ms for both BP launches (profiles/archive/r02_notes.md) */
 #endif
 // Timing-only builds (-DBP_TIMING, tools/bp_timing.py): lane 0 of every attempt adds the shader cycles between consecutive marks to a
 // per-block slot of g_bp_t[] (spread over 65536 slots: the atomics do not meet).  Never defined in the product.
@@ -36,7 +36,7 @@ FT8_DEV void bp_attempt(int lane, int mode, int bid, const float* __restrict__ l
     __shared__ float tl[576];        // 9 x 64 edge slots: slots >= 522 are dummy edges (variable 174, check 83) so that the
     // per-edge code below is straight-line for all nine slots of a lane.  The message deltas overwrite the tanh values in place: a
     // lane reads tl[e] and writes dl[e] of its OWN slots only, after the barrier behind the check products (the only readers of other
-    // lanes' tanh values) -- 2.3 KB of LDS less per wave: bp_fine 0.719 -> 0.694 ms, bp_grid 0.171 -> 0.167 (profiles/r03_notes.md)
+    // lanes' tanh values) -- 2.3 KB of LDS less per wave: bp_fine 0.719 -> 0.694 ms, bp_grid 0.171 -> 0.167 (profiles/archive/r03_notes.md)
     float* dl = tl;
     __shared__ float P[84];
     int frame = 0, ci = 0, ap = 0; size_t vec;

@@ -44,7 +44,7 @@ FT8_DEV cpx fine_taper(cpx v, double t) { return make_float2((float)((double)v.x
 FT8_DEV cpx fine_conj(cpx v) { return make_float2(v.x, -v.y); }
 
 // forward FFT of the conjugated slice into z (unscaled, unconjugated), natural Stockham layout, in place.
-// (Measured alternatives, profiles/r01_notes.md: 256-thread blocks 7.96 ms, bank-conflict-free padded/transposed
+// (Measured alternatives, profiles/archive/r01_notes.md: 256-thread blocks 7.96 ms, bank-conflict-free padded/transposed
 // inter-stage layouts 6.92 ms, this version 6.36 ms per 256 frames: the kernel is latency/barrier bound.)
 //
 // Pass [8]: n = 3200, s = 1, m = 400: butterfly p reads bins p + 400 j, of which only j = 0, 1, (2 if p < 50), (7 if p >= 250) are

@@ -187,7 +187,7 @@ __device__ uint8_t d_NANPERM[192];
 
 // CRC syndrome of codeword bit v alone (v < 77: message bit, 77..90: the CRC field bit itself), bit-sliced: d_SYNM[k][w] bit b = bit k
 // of the syndrome of codeword bit 32 w + b.  Constant address space: wave-uniform reads become scalar loads (a uniform lookup in a
-// 16-bit __device__ table is a broadcast vector load -- 91 of them per attempt kept the texture-address path busy, profiles/r02_notes.md)
+// 16-bit __device__ table is a broadcast vector load -- 91 of them per attempt kept the texture-address path busy, profiles/archive/r02_notes.md)
 __device__ __constant__ uint32_t d_SYNM[14][3];
 __device__ uint32_t d_G0T[192][3];       // column v of G0 = [I | A^T]: row bits 0..31, 32..63, 64..90 (columns >= 174 are zero)
 FT8_DEV unsigned osd_syndrome(uint64_t w0, uint64_t w1) { return ft8_crc_syndrome(w0, w1); }     // table d_CRC_T: ft8_dev.h
@@ -287,7 +287,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
     // codeword / flip rows below are label-free); clearing the column's other 1s = adding row r to those rows = XORing (column
     // minus bit r) into every column that has a 1 in row r.  A column that already is a unit vector needs no update at all (the
     // still untouched systematic columns: about 40 % of the basis).  The scalar pipe issues one instruction per cycle per CU and
-    // is this kernel's bottleneck (profiles/r02_notes.md), so the bookkeeping is kept to lock words and one accepted-position bit
+    // is this kernel's bottleneck (profiles/archive/r02_notes.md), so the bookkeeping is kept to lock words and one accepted-position bit
     // per step; everything that can wait (hard-decision mask, flip rows, syndromes) is done afterwards on the vector side.
     OT(1);
     const int ord0 = (int)ix[0], ord1 = (int)ix[1], ord2 = (lane < 46) ? (int)ix[2] : 0;
@@ -609,7 +609,7 @@ FT8_DEV void osd_attempt(int lane, int mode, int bid, const float* __restrict__ 
 // LLRs, then the 5 saved BP outputs).
 // Eight waves per SIMD: the elimination is a serial chain of readlane -> scalar logic -> masked XOR per step (~280 cycles), hidden only
 // by other waves.  The kernel needs 59 VGPRs when told to fit eight (71 otherwise) and 4.5 KB of LDS since the flip rows share the
-// dead sort keys (5.6 KB allowed 7): 0.739 -> 0.710 ms per 256 frames (profiles/r03_notes.md; the attribute alone, LDS-bound at 7: 0.781)
+// dead sort keys (5.6 KB allowed 7): 0.739 -> 0.710 ms per 256 frames (profiles/archive/r03_notes.md; the attribute alone, LDS-bound at 7: 0.781)
 #ifndef OSD_ATTR
 #define OSD_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif

@@ -537,7 +537,7 @@ class Receiver:
                     self._h.close()
                 self._h = _lib.Handle(self.cfg, device=self.device, max_frames=n_frames)
             # small batches: latency over work -- see ft8rx_set_ladder_mode
-            self._h.set_ladder_mode(1 if n_frames < 128 else 0)       # crossover measured at 64..128 frames per call (profiles/r02_latency.txt)
+            self._h.set_ladder_mode(1 if n_frames < 128 else 0)       # crossover measured at 64..128 frames per call (profiles/archive/r02_latency.txt)
             return self._h
 
     def _live_handle(self):
