@@ -1174,8 +1174,9 @@ int ft8rx_d2h_async(ft8rx_handle* h, void* dst, const void* d_src, uint64_t byte
 int ft8rx_d2h_query(ft8rx_handle* h, int32_t ticket) {              // 1 = the copy has landed, 0 = not yet, < 0 = error
     if (!h || ticket < 0) return -1;
     const uint32_t id = (uint32_t)ticket, next = h->d2h_next & 0x7fffffffu;
-    if (((next - id) & 0x7fffffffu) > 32u) return 1;               // its event has been reused since: long done
-    if (((next - id) & 0x7fffffffu) == 0u) return -1;              // never issued
+    const uint32_t age = (next - id) & 0x7fffffffu;
+    if (age == 0u || age > 0x40000000u) { set_err(h, "ft8rx_d2h_query: ticket %d was never issued", ticket); return -1; }
+    if (age > 32u) return 1;                                        // its event has been reused since: long done
     const hipError_t r = hipEventQuery(h->d2h_ev[id & 31]);
     if (r == hipSuccess) return 1;
     if (r == hipErrorNotReady) return 0;

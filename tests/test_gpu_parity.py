@@ -137,6 +137,36 @@ def test_fine_sync_exact(H, ocfg):
                 assert bits_equal(r["llr"][k], w["llr"]) and np.float32(r["sd"][k]) == np.float32(w["sd"]) and r["snr"][k] == w["snr"]
 
 
+def test_fine_sync_clamp_rows_are_bit_identical(H, ocfg):
+    """receiver.py:189-195 reads symbol s at z[clip(tb + 32 s, 0, 3168) : +32]: every symbol that starts AT or beyond sample 3168 (or at
+    or before 0) reads the same 32 samples, so its grid row is bit-identical to the others' -- the exact |LLR| ties osd_012's argsort
+    then sees.  Stage entry ft8rx_fine on late / early candidates of a synthetic frame: GPU == oracle bit for bit, the clamped rows
+    (the boundary symbol included, round 6) are one and the same row, and the test set really holds boundary cases."""
+    from pyft8_amd import synth
+    audio = synth.make_frame(61000, n_signals=50, snr_range=(-10.0, 10.0))
+    spec = O.cycle_spectrum(audio, ocfg)
+    f0 = np.arange(100, 900, 8, dtype=np.int32)
+    trip = [(f, h) for h in (84, 88, 92, 96, 100, 120, 150, 180, 200, 216, -20, -60, -100, -136) for f in f0[:12]] + [(int(f), 88 + 4 * (i % 8)) for i, f in enumerate(f0)]
+    f0s, h0s = np.array([t[0] for t in trip], np.int32), np.array([t[1] for t in trip], np.int32)
+    r = H.fine(spec, np.zeros(len(trip), np.int32), f0s, h0s, want_sgrid=True)
+    n_boundary = n_clamped = 0
+    for k, (f, h) in enumerate(trip):
+        w = O.fine(spec, f, h, ocfg)
+        assert (r["ret"][k], r["ttweak"][k], r["ftweak"][k], r["nsync"][k]) == (w["ret"], w["ttweak"], w["ftweak"], w["nsync"]), (f, h)
+        assert bits_equal(r["sgrid"][k], w["sgrid"]), (f, h)
+        tb = 8 * h + (1 if h < 0 else 0) + int(w["ttweak"])
+        starts = tb + 32 * np.arange(79)
+        hi = np.nonzero(starts >= 3168)[0]
+        lo = np.nonzero(starts <= 0)[0]
+        g = r["sgrid"][k].reshape(79, 8)
+        for grp, strict in ((hi, (starts > 3168).any()), (lo, (starts < 0).any())):
+            if len(grp) >= 2 and strict:
+                n_clamped += 1
+                assert all(g[i].tobytes() == g[grp[0]].tobytes() for i in grp), (f, h, tb, grp[:3])
+                n_boundary += int((starts[grp] == 3168).any() or (starts[grp] == 0).any())
+    assert n_clamped > 40 and n_boundary >= 3, (n_clamped, n_boundary)
+
+
 def test_ldpc_exact(H):
     for name in GOLDEN_FRAMES:
         audio, gold, js = load_golden(name)
@@ -1322,6 +1352,34 @@ def test_streaming_incremental_delivery_like_manage_cycle():
     rx.close()
     assert rx._h is None
     print(f"incremental: {len(early)} of {len(ref_txt)} messages before the end of the cycle, at " + ", ".join(f"{t:.1f}" for t in sorted({t for t, _ in early})) + " s")
+
+
+def test_d2h_async_tickets():
+    """ft8rx_d2h_async / _query / _event (include/ft8rx.h): device -> page-locked host copies on the handle's result-copy stream, polled
+    by ticket -- what rank `dst` of the gather uses.  40 copies of device audio (more than the 32-event ring: the oldest tickets read as
+    complete, the 33rd call waits for the first), every byte equal to the synchronous copy; a ticket that was never issued is an error."""
+    import time
+    from pyft8_amd import _lib
+    h = _lib.Handle(max_frames=2)
+    ptr = h.staging_ptr()
+    h.synth_frames(ptr, 4242, 2, n_signals=5)
+    want = h.download_audio(ptr, 2)
+    n = want.nbytes
+    bufs = [h.pinned_bytes(n) for _ in range(4)]
+    tickets = []
+    for i in range(40):
+        bufs[i % 4][:] = 0
+        t = h.d2h_async(bufs[i % 4].ctypes.data, ptr, n)
+        tickets.append(t)
+        t0 = time.perf_counter()
+        while not h.d2h_done(t):
+            assert time.perf_counter() - t0 < 10.0
+        assert bufs[i % 4].tobytes() == want.tobytes(), i
+        assert h.d2h_event(t)
+    assert tickets == list(range(40)) and h.d2h_done(tickets[0]) and h.d2h_event(tickets[0]) is None      # reused since: long done, no event to hand out
+    with pytest.raises(_lib.Ft8rxError):
+        h.d2h_done(1000)
+    h.close()
 
 
 def test_error_paths_and_lifecycle():
