@@ -43,7 +43,7 @@
  * LIMITS of this build against the reference's open-ended kwargs (pyft8_amd.receiver.config_from_kwargs names the kwarg when one is
  * exceeded; ft8rx_create answers -1): max_cands <= FT8RX_MAX_CANDS = 256 (libft8rx.so) / 2048 (libft8rx_wide.so: more than any search
  * range has f0 bins, i.e. no limit -- a larger max_cands keeps the same candidates; reference: any, default 200), search_time_range inside
- * [-6.1, +8.3] s and at most 14.08 s wide (FT8RX_MIN_H0 / FT8RX_MAX_H0), search_freq_range 12.5 .. 3000 Hz (libft8rx.so) / .. 5900 Hz
+ * [-36.4, +22.6] s (FT8RX_MIN_H0 / FT8RX_MAX_H0: beyond it the reference's own search raises IndexError), search_freq_range 12.5 .. 3000 Hz (libft8rx.so) / .. 5900 Hz
  * (libft8rx_wide.so), OSD flip counts <= 91 and <= 16384 trials.
  */
 #ifndef FT8RX_H
@@ -74,9 +74,11 @@ extern "C" {
 #define FT8RX_MAX_F0     960
 #define FT8RX_MAX_CANDS  256      /* upper bound for config.max_cands (the reference's default is 200, receiver.py:311) */
 #endif
-#define FT8RX_MIN_H0     (-140)   /* bounds of config.h0_lo / h0_hi (search_time_range -6.1 .. +8.3 s; the reference's default is -2 .. +3 s): within them the */
-#define FT8RX_MAX_H0     220      /* middle Costas block of every candidate and time tweak lies inside the 3200-sample fine-sync series, where the     */
-                                  /* frequency-domain scores equal the reference's clamped reads (receiver.py:189-195) sample for sample                */
+#define FT8RX_MIN_H0     (-898)   /* bounds of config.h0_lo / h0_hi (search_time_range -36.4 .. +22.6 s; the reference's default is -2 .. +3 s): where the   */
+#define FT8RX_MAX_H0     578      /* reference's own search stops indexing its 750-row grid (rows h0 + 148 .. h0 + 172, receiver.py:322, 346-347)            */
+#define FT8RX_MIN_H0_FD  (-140)   /* candidates with h0 in [MIN_H0_FD, MAX_H0_FD] (-6.1 .. +8.3 s): the middle Costas block of every tweak lies inside the      */
+#define FT8RX_MAX_H0_FD  220      /* 3200-sample fine-sync series and the frequency-domain scores / grid apply; further out the reads are clamped (:189-195)   */
+                                  /* and the candidate is scored in the time domain, one series per tweak (kernels/fine_sync.hpp: k_fine_td)                 */
 #define FT8RX_EVENT_CAP  512      /* per-frame capacity of the CRC-pass event log */
 
 /* Receiver(...) kwargs (receiver.py:311-313) + module/decoder constants (receiver.py:30,78,91,95;

@@ -718,14 +718,26 @@ int ft8o_fine(const float* spec, const ft8o_config* c, int f0_idx, int h0_idx, i
     }
     int ft = 0;
     const float score_f0 = best;                                     /* f = 0: the time scan's own series and offset */
+    /* The frequency-domain identities (fine_fscore, fine_grid_freq) hold while the middle Costas block of every tweak lies inside the
+     * series, i.e. for h0 in [FT8O_MIN_H0_FD, FT8O_MAX_H0_FD] = [-140, 220] (search_time_range -6.1 .. +8.3 s).  A candidate further
+     * out -- the reference takes any search_time_range (receiver.py:312, 319) and clamps every read (:189-195) -- is scored as the
+     * reference scores it, in the time domain: one series per frequency tweak, the seven symbols of the block read at their clamped
+     * positions, and the final grid symbol by symbol from the series of the chosen tweak (round 6). */
+    const int far_out = h0_idx < FT8O_MIN_H0_FD || h0_idx > FT8O_MAX_H0_FD;
     for (int i = 0; i < 9; i++) {                                    /* range(-32,33,8) */
         int f = -32 + 8 * i;
-        float sc = (f == 0) ? score_f0 : fine_fscore(spec, fb0 + f, tb0 + tt + 32 * 36);
+        float sc;
+        if (f == 0) sc = score_f0;
+        else if (far_out) { fine_zsig(spec, c, fb0 + f, z); sc = fine_score(z, tb0 + tt); }
+        else sc = fine_fscore(spec, fb0 + f, tb0 + tt + 32 * 36);
         if (i == 0 || sc > best) { best = sc; ft = f; }
     }
-    free(z);
     float g[79 * 8];
-    fine_grid_freq(spec, fb0 + ft, tb0 + tt, g);
+    if (far_out) {
+        fine_zsig(spec, c, fb0 + ft, z);
+        for (int s = 0; s < 79; s++) fine_symbol(z, tb0 + tt, s, g + 8 * s);
+    } else fine_grid_freq(spec, fb0 + ft, tb0 + tt, g);
+    free(z);
     if (sgrid) memcpy(sgrid, g, sizeof(g));
     *ttweak = tt; *ftweak = ft;
     int nm = 0;

@@ -23,6 +23,11 @@ extern "C" {
 /* Mirrors Receiver.__init__ kwargs (reference receiver.py:311-313) + decoder constants
  * (receiver.py:30,78,91,95; decoders.py:223).  Extension knobs are the same fields with
  * other values (BASELINE configs 2/4). */
+/* candidates with h0 in this range take the frequency-domain fine sync (the middle Costas block of every tweak lies inside the
+ * 3200-sample series); the others the reference's own time-domain form with clamped reads (ft8o_fine) */
+#define FT8O_MIN_H0_FD (-140)
+#define FT8O_MAX_H0_FD 220
+
 typedef struct {
     float sync_score_min;   /* 85 */
     int32_t max_cands;      /* 200 */

@@ -23,7 +23,9 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-Wno-unused-value", "-fPIC", "-shared"]
 
 NSAMP, GRID_ROWS, GRID_COLS, SPEC_BINS, MAX_CANDS, EVENT_CAP = 180000, 376, 976, 49152, 256, 512
-MIN_H0, MAX_H0 = -140, 220                          # FT8RX_MIN_H0 / FT8RX_MAX_H0: bounds of config.h0_lo / h0_hi (search_time_range -6.1 .. +8.3 s)
+MIN_H0, MAX_H0 = -898, 578                          # FT8RX_MIN_H0 / FT8RX_MAX_H0: bounds of config.h0_lo / h0_hi = where the reference's own search stops
+                                                    # indexing its 750-row grid (search_time_range -36.4 .. +22.6 s, receiver.py:346-347)
+MIN_H0_FD, MAX_H0_FD = -140, 220                    # FT8RX_MIN_H0_FD / _MAX_H0_FD: candidates inside take the frequency-domain fine sync
 MAX_F0, GRID_COLS_WIDE, SPEC_BINS_WIDE, MAX_F0_WIDE = 960, 1920, 96000, 1888      # Handle.grid_cols / .spec_bins hold the loaded variant's
 MAX_CANDS_WIDE = 2048                               # FT8RX_MAX_CANDS of the wide build: more than any search range has f0 bins
 

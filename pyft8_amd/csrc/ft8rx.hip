@@ -71,7 +71,15 @@ static int osd_nflip(int S, int T) { return S > T ? S : T; }
 
 struct ft8rx_hashes { hostmsg::Hashes H; };      // persistent call-hash table (databases.py:8): ft8rx_hashes_* in include/ft8rx.h
 
-static size_t sync_lds_bytes(const ft8rx_config& c) { const size_t nrows = (size_t)(c.h0_hi - c.h0_lo + 24); return nrows * 16 * sizeof(double) + (nrows * 29 + 512) * sizeof(float); }
+// k_sync holds every grid row its h0 window can touch in LDS (244 B per row): windows of at most SYNC_WIN time offsets per launch.  A
+// wider search_time_range runs as consecutive windows in ascending h0, each launch keeping the earlier windows' maximum unless it
+// finds a strictly larger one -- the first strict maximum of the whole range (receiver.py:350-351), as one launch gives it.
+#define SYNC_WIN 352
+static size_t sync_lds_bytes(const ft8rx_config& c) {
+    const int nh0 = c.h0_hi - c.h0_lo;
+    const size_t nrows = (size_t)((nh0 < SYNC_WIN ? nh0 : SYNC_WIN) + 24);
+    return nrows * 16 * sizeof(double) + (nrows * 29 + 512) * sizeof(float);
+}
 static std::string g_create_err;
 
 struct ft8rx_handle {
@@ -314,7 +322,7 @@ void ft8rx_destroy(ft8rx_handle* h) {
 int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_handle** out) {
     if (!cfg || !out || max_frames < 1) { set_err(nullptr, "ft8rx_create: bad arguments"); return -1; }
     if (cfg->max_cands < 1 || cfg->max_cands > MAXC || cfg->f0_lo < 4 || cfg->f0_hi > FT8RX_MAX_F0 || cfg->f0_lo >= cfg->f0_hi ||
-        cfg->h0_hi <= cfg->h0_lo || cfg->h0_hi - cfg->h0_lo > 352 || cfg->h0_lo < FT8RX_MIN_H0 || cfg->h0_hi > FT8RX_MAX_H0 || cfg->bp_nc0_a > cfg->bp_nc0_b || cfg->bp_iters_a > cfg->bp_iters_b ||
+        cfg->h0_hi <= cfg->h0_lo || cfg->h0_lo < FT8RX_MIN_H0 || cfg->h0_hi > FT8RX_MAX_H0 || cfg->bp_nc0_a > cfg->bp_nc0_b || cfg->bp_iters_a > cfg->bp_iters_b ||
         cfg->osd_single < 0 || cfg->osd_single > OSD_MAXFLIP || cfg->osd_double < 0 || cfg->osd_double > OSD_MAXFLIP ||
         cfg->osd_triple < 0 || cfg->osd_triple > 40 || cfg->osd_max_hd < 0 || cfg->osd_max_hd > 174 ||
         osd_trial_table(cfg->osd_single, cfg->osd_double, cfg->osd_triple).size() > OSD_MAXTRIALS) {
@@ -520,6 +528,16 @@ int ft8rx_get_stage_times(ft8rx_handle* h, int* n, const char** names, float* ms
 // chip four times over, never more than there can be items
 static int ladder_grid(int max_items) { const int cap = LADDER_GRID_CAP; return max_items < cap ? max_items : cap; }
 
+// the sync search of frames [.., B) over the configured h0 range, in windows of SYNC_WIN offsets (one launch for any range up to 14 s)
+static void launch_sync(const float* grid, float* bs, int32_t* bh, const ft8rx_config& c, int B, hipStream_t s) {
+    const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
+    for (int lo = c.h0_lo; lo < c.h0_hi; lo += SYNC_WIN) {
+        ft8rx_config w = c;
+        w.h0_lo = lo; w.h0_hi = lo + SYNC_WIN < c.h0_hi ? lo + SYNC_WIN : c.h0_hi;
+        k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, w, lo != c.h0_lo);
+    }
+}
+
 static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B, hipStream_t s, bool prof, int slot, int chunk) {
     const ft8rx_config& c = h->cfg;
     const size_t F = (size_t)f0;
@@ -538,8 +556,7 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     STAGE("spectrogram");
     ft8rx_ilp_spectrogram(B, s, audio, grid, h->T);
     STAGE("sync");
-    const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
-    k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, c);
+    launch_sync(grid, bs, bh, c, B, s);
     STAGE("topk");
     k_topk<<<B, 1024, 0, s>>>(bs, bh, rec, ncand, c, evc, wc, h->use_mask ? h->d_colmask + F * NF0MAX : nullptr);
     STAGE("grid_llr");
@@ -554,6 +571,8 @@ static void enqueue_chain(ft8rx_handle* h, const int16_t* d_audio, int f0, int B
     k_cyc_bc<<<dim3(CYC_BC_GRID, B), 256, 0, s>>>(A, spec, h->T);
     STAGE("fine");
     ft8rx_ilp_fine(ladder_grid(B * c.max_cands), s, spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
+    if (c.h0_lo < FT8RX_MIN_H0_FD || c.h0_hi > FT8RX_MAX_H0_FD + 1)      // a search_time_range beyond -6.1 .. +8.3 s: the candidates k_fine leaves out
+        k_fine_td<<<ladder_grid(B * c.max_cands), FINE_NT, 0, s>>>(spec, rec, ncand, llr0, h->T, c, nullptr, nullptr, nullptr, nullptr, wl[WL_FINE]);
     k_worklist<<<(B * MAXC + 255) / 256, 256, 0, s>>>(rec, ncand, B, wl[WL_BP1]);
     STAGE("bp_fine");
     // fine-stage BP: in ladder order (three launches; decided candidates drop out), or -- ft8rx_set_ladder_mode(h, 1), for small
@@ -976,7 +995,7 @@ int ft8rx_sync_search(ft8rx_handle* h, const float* grid, int B, int32_t* f0_idx
     const ft8rx_config& c = h->cfg;
     HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
     const int ntile = (c.f0_hi - c.f0_lo + 15) / 16;
-    k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), h->stream>>>(h->d_grid, h->d_best_score, h->d_best_h0, c);
+    launch_sync(h->d_grid, h->d_best_score, h->d_best_h0, c, B, h->stream);
     k_topk<<<B, 1024, 0, h->stream>>>(h->d_best_score, h->d_best_h0, h->d_rec, h->d_ncand, c, nullptr, nullptr, nullptr);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<ft8rx_record> rec((size_t)B * MAXC);
@@ -1000,7 +1019,7 @@ int ft8rx_sync_scores(ft8rx_handle* h, const float* grid, int B, int f0_lo, int 
     c.f0_lo = f0_lo; c.f0_hi = f0_hi;
     HIPCHK(h, hipMemcpy(h->d_grid, grid, sizeof(float) * (size_t)B * FT8RX_GRID_ROWS * FT8RX_GRID_COLS, hipMemcpyHostToDevice));
     const int nf0 = f0_hi - f0_lo, ntile = (nf0 + 15) / 16;
-    k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), h->stream>>>(h->d_grid, h->d_best_score, h->d_best_h0, c);
+    launch_sync(h->d_grid, h->d_best_score, h->d_best_h0, c, B, h->stream);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpy2DAsync(score, sizeof(float) * nf0, h->d_best_score, sizeof(float) * NF0MAX, sizeof(float) * nf0, B, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpy2DAsync(h0_idx, sizeof(int32_t) * nf0, h->d_best_h0, sizeof(int32_t) * NF0MAX, sizeof(int32_t) * nf0, B, hipMemcpyDeviceToHost, h->stream));
@@ -1055,6 +1074,7 @@ int ft8rx_fine(ft8rx_handle* h, const float* spec, int B, int n, const int32_t* 
     int32_t* d_out = S.get<int32_t>((size_t)n * 5); NEED(d_out);
     float* d_sg = sgrid ? S.get<float>((size_t)n * 632) : nullptr; if (sgrid) NEED(d_sg);
     ft8rx_ilp_fine(n, h->stream, h->d_spec, nullptr, nullptr, d_llr, h->T, h->cfg, d_trip, d_out, d_sd, d_sg, WorkList{nullptr, nullptr});
+    k_fine_td<<<n, FINE_NT, 0, h->stream>>>(h->d_spec, nullptr, nullptr, d_llr, h->T, h->cfg, d_trip, d_out, d_sd, d_sg, WorkList{nullptr, nullptr});   // triples k_fine leaves out
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<int32_t> o((size_t)n * 5);
     HIPCHK(h, hipMemcpy(o.data(), d_out, sizeof(int32_t) * o.size(), hipMemcpyDeviceToHost));

@@ -435,6 +435,7 @@ FT8_DEV void fine_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8r
         if (r.status != FT8RX_ST_ACTIVE) return;
         f0 = r.f0_idx; h0 = r.h0_idx;
     }
+    if (h0 < FT8RX_MIN_H0_FD || h0 > FT8RX_MAX_H0_FD) return;        // the middle Costas block leaves the series: k_fine_td's candidate
     const cpx w32v = T.W32[tid & 31];                             // requested with the twiddle loads below, stored before the barrier
     const int fb0 = 50 * f0;                                      // int(0.5 + fHz*16)
     {
@@ -682,5 +683,169 @@ __global__ __launch_bounds__(FINE_NT, FINE_WV) void k_fine(const cpx* __restrict
     }
 }
 #endif  // FT8RX_ILP_UNIT
+
+#ifndef FT8RX_ILP_UNIT
+// ------------------------------------------------------------------------------------ fine sync of FAR-OUT candidates, in the time domain
+// The frequency-domain scores and grid of k_fine are identities of the reference's IFFT + symbol DFTs as long as the middle Costas
+// block of every tweak lies inside the 3200-sample series: h0 in [FT8RX_MIN_H0_FD, FT8RX_MAX_H0_FD].  The reference takes any
+// search_time_range (receiver.py:312, 319) and clamps every symbol read to [0, 3168] (:189-195); a candidate further out is scored here
+// the way the reference scores it (contract: oracle/ft8_oracle.c ft8o_fine, `far_out`): ONE series per tweak -- the time scan's, then one
+// per non-zero frequency tweak, then the chosen one in full for the 79 x 8 grid -- and every symbol's 32-sample DFT at its clamped
+// position.  Ten transforms per candidate (round 3's kernel did that for every candidate); such candidates only exist with a
+// search_time_range beyond -6.1 .. +8.3 s, the launch is skipped otherwise.  Main translation unit (default scheduler).
+FT8_DEV int fine_clamp_pos(int i0) { return i0 < 0 ? 0 : (i0 > 3168 ? 3168 : i0); }
+FT8_DEV void fine_td_candidate(int tid, int bid, const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
+                               const int32_t* __restrict__ ncand, float* __restrict__ llr0, const Tables& T, const ft8rx_config& cfg,
+                               const int32_t* __restrict__ trip, int32_t* __restrict__ t_out, float* __restrict__ t_sd, float* __restrict__ t_sgrid) {
+    __shared__ cpx z[3200];
+    __shared__ cpx w400[400];
+    __shared__ cpx w32[32];
+    __shared__ float mg[640];
+    __shared__ double dsum[8 * 7 * 2];
+    __shared__ float p[464], llr[176], sq[176], sc[16];
+    __shared__ int ish[4];
+    int frame, ci = 0, f0, h0;
+    if (trip) { frame = trip[3 * bid]; f0 = trip[3 * bid + 1]; h0 = trip[3 * bid + 2]; }
+    else {
+        frame = bid / MAXC; ci = bid % MAXC;
+        if (ci >= ncand[frame]) return;
+        const ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
+        if (r.status != FT8RX_ST_ACTIVE) return;
+        f0 = r.f0_idx; h0 = r.h0_idx;
+        if (h0 >= FT8RX_MIN_H0_FD && h0 <= FT8RX_MAX_H0_FD) return;  // k_fine's candidate
+    }
+    for (int i = tid; i < 400; i += FINE_NT) w400[i] = T.W3200[8 * i];
+    if (tid < 32) w32[tid] = T.W32[tid];
+    __syncthreads();
+    const int fb0 = 50 * f0;
+    const cpx* __restrict__ Sg = spec + (size_t)frame * FT8RX_SPEC_BINS + (fb0 - 182);
+    cpx wq[8];
+    sym32_twiddles(w32, tid & 3, wq);
+    const int tb0 = 8 * h0 + (h0 < 0 ? 1 : 0);
+    // --- time tweaks at ftweak 0 (8 x 7 symbols, 4 lanes each); only the samples the clamped reads touch are produced
+    fine_fft(Sg, 182, z, w400, T, tid, fine_clamp_pos(tb0 - 8 + 32 * 36), fine_clamp_pos(tb0 + 6 + 32 * 42) + 32);
+#pragma unroll 1
+    for (int r = 0; r < (224 + FINE_NT - 1) / FINE_NT; r++) {
+        const int task = tid + FINE_NT * r, qd = task >> 2, n2 = task & 3;
+        const bool valid = qd < 56;
+        const int ti = valid ? qd / 7 : 0, a = valid ? qd - 7 * ti : 0;
+        float mag[8];
+        fine_sym_quad<7>(z, tb0 - 8 + 2 * ti + 32 * (36 + a), n2, wq, mag);
+        if (valid && n2 == 0) {
+            const int c = d_COSTAS[a];
+            double off = 0.0, on = 0.0;
+#pragma unroll
+            for (int b = 0; b < 7; b++) { const double m = (double)mag[b]; on = (b == c) ? m : on; off += (b == c) ? 0.0 : m; }
+            dsum[(ti * 7 + a) * 2] = on; dsum[(ti * 7 + a) * 2 + 1] = off;
+        }
+    }
+    __syncthreads();
+    int tt = -8; float score_f0 = 0.0f;
+    for (int u = 0; u < 8; u++) {                                   // every thread: the same sums in the same order (a ascending, fp64)
+        double s1 = 0.0, s2 = 0.0;
+        for (int a = 0; a < 7; a++) { s1 += dsum[(u * 7 + a) * 2]; s2 += dsum[(u * 7 + a) * 2 + 1]; }
+        const float v = (float)(s1 + W6 * s2);
+        if (u == 0 || v > score_f0) { score_f0 = v; tt = -8 + 2 * u; }
+    }
+    // --- frequency tweaks range(-32, 33, 8): one series each, the block at the chosen time tweak; f = 0 is the time scan's winner
+    float best = 0.0f; int ft = 0;
+    const int tb = tb0 + tt;
+#pragma unroll 1
+    for (int i = 0; i < 9; i++) {
+        const int f = -32 + 8 * i;
+        float v = score_f0;
+        if (f != 0) {
+            __syncthreads();                                        // everybody is done with the previous series / sums
+            fine_fft(Sg, 182 + f, z, w400, T, tid, fine_clamp_pos(tb + 32 * 36), fine_clamp_pos(tb + 32 * 42) + 32);
+            {
+                const int a = tid >> 2, n2 = tid & 3;
+                const bool valid = a < 7;
+                float mag[8];
+                fine_sym_quad<7>(z, tb + 32 * (36 + (valid ? a : 0)), n2, wq, mag);
+                if (valid && n2 == 0) {
+                    const int c = d_COSTAS[a];
+                    double off = 0.0, on = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 7; b++) { const double m = (double)mag[b]; on = (b == c) ? m : on; off += (b == c) ? 0.0 : m; }
+                    dsum[a * 2] = on; dsum[a * 2 + 1] = off;
+                }
+            }
+            __syncthreads();
+            double s1 = 0.0, s2 = 0.0;
+            for (int a = 0; a < 7; a++) { s1 += dsum[a * 2]; s2 += dsum[a * 2 + 1]; }
+            v = (float)(s1 + W6 * s2);
+        }
+        if (i == 0 || v > best) { best = v; ft = f; }
+    }
+    // --- the 79 x 8 grid from the series of the chosen tweaks, symbol by symbol at the clamped positions
+    __syncthreads();
+    fine_fft(Sg, 182 + ft, z, w400, T, tid, 0, 3200);
+#pragma unroll 1
+    for (int r = 0; r < (316 + FINE_NT - 1) / FINE_NT; r++) {
+        const int task = tid + FINE_NT * r, sy = task >> 2, n2 = task & 3;
+        const bool valid = sy < 79;
+        float mag[8];
+        fine_sym_quad<8>(z, tb + 32 * (valid ? sy : 0), n2, wq, mag);
+        if (valid && n2 == 0) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) mg[sy * 8 + b] = mag[b];
+        }
+    }
+    __syncthreads();
+    // --- Costas gate, LLRs, record: as k_fine (receiver.py:164-173)
+    bool match = false;
+    if (tid < 21) {
+        int blk = tid / 7, a = tid - blk * 7;
+        const float* q = mg + 8 * (36 * blk + a);
+        int am = 0; for (int t = 1; t < 8; t++) if (q[t] > q[am]) am = t;
+        match = (am == d_COSTAS[a]);
+    }
+    if (tid < 64) { int nm = __popcll(__ballot(match)); if (tid == 0) ish[1] = nm; }
+    __syncthreads();
+    const int nsync = ish[1];
+    if (trip && t_sgrid) for (int i = tid; i < 632; i += FINE_NT) t_sgrid[(size_t)bid * 632 + i] = mg[i];
+    int ret = 1; float sd = 0.0f; int snr = 0;
+    if (nsync <= 6) ret = 0;
+    else {
+        for (int i = tid; i < 464; i += FINE_NT) p[i] = 20.0f * ft8_log10f(mg[8 * (int)d_PAYSYM[i >> 3] + (i & 7)]);
+        __syncthreads();
+        llr_from_p(p, llr, sq, tid, tid < 64, &sd, &snr);
+        if (tid == 0) { sc[10] = sd; ish[2] = snr; }
+        __syncthreads();
+        sd = sc[10]; snr = ish[2];
+        if (sd <= cfg.llr_sd_min) ret = -1;
+        float* out = llr0 + (size_t)bid * 174;
+        for (int i = tid; i < 174; i += FINE_NT) out[i] = llr[i];
+    }
+    if (tid == 0) {
+        if (trip) { int32_t* o = t_out + 5 * (size_t)bid; o[0] = ret; o[1] = tt; o[2] = ft; o[3] = nsync; o[4] = snr; t_sd[bid] = sd; }
+        else {
+            ft8rx_record& r = rec[(size_t)frame * MAXC + ci];
+            r.ttweak = (int8_t)tt; r.ftweak = (int8_t)ft; r.nsync = (uint8_t)nsync;
+            if (ret == 0) r.status = FT8RX_ST_STOP_COSTAS;
+            else { r.fine_sd = sd; r.snr_fine = (int8_t)snr; if (ret < 0) r.status = FT8RX_ST_STOP_FINE_SD; }
+        }
+    }
+}
+// test entry (trip != nullptr): one block per triple, triples inside the frequency-domain range are left to k_fine.  Pipeline: blocks
+// stride over the fine-sync work list and take the candidates k_fine skips.
+__global__ __launch_bounds__(FINE_NT) void k_fine_td(const cpx* __restrict__ spec, ft8rx_record* __restrict__ rec,
+                                                     const int32_t* __restrict__ ncand, float* __restrict__ llr0, Tables T, ft8rx_config cfg,
+                                                     const int32_t* __restrict__ trip, int32_t* __restrict__ t_out,
+                                                     float* __restrict__ t_sd, float* __restrict__ t_sgrid, WorkList work) {
+    if (trip) {
+        const int h0 = trip[3 * blockIdx.x + 2];
+        if (h0 >= FT8RX_MIN_H0_FD && h0 <= FT8RX_MAX_H0_FD) return;
+        fine_td_candidate(threadIdx.x, blockIdx.x, spec, rec, ncand, llr0, T, cfg, trip, t_out, t_sd, t_sgrid);
+        return;
+    }
+    const int n = *work.count;
+#pragma unroll 1
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        fine_td_candidate(threadIdx.x, work.items[item], spec, rec, ncand, llr0, T, cfg, nullptr, nullptr, nullptr, nullptr);
+        __syncthreads();
+    }
+}
+#endif  // !FT8RX_ILP_UNIT
 
 #endif

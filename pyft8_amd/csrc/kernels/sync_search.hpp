@@ -5,8 +5,10 @@
 
 // ------------------------------------------------------------------------------------ K2 sync search
 // block = 16 consecutive f0 of one frame; LDS tile = every grid row any h0 can touch x 29 columns.
+// accumulate != 0: a later window of a wide search_time_range (ft8rx.hip: launch_sync) -- the stored result of the earlier windows stays
+// unless this window holds a strictly larger score (windows come in ascending h0: the first strict maximum of the whole range).
 __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, float* __restrict__ best_score,
-                                              int32_t* __restrict__ best_h0, ft8rx_config cfg) {
+                                              int32_t* __restrict__ best_h0, ft8rx_config cfg, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nh0 = cfg.h0_hi - cfg.h0_lo;
     const int nrows = nh0 + 24;
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, fl
         }
         int f0 = f0base + tid;
         if (f0 < cfg.f0_hi) {
-            best_score[(size_t)f * NF0MAX + (f0 - cfg.f0_lo)] = bs;
-            best_h0[(size_t)f * NF0MAX + (f0 - cfg.f0_lo)] = h;
+            const size_t o = (size_t)f * NF0MAX + (f0 - cfg.f0_lo);
+            if (!accumulate || bs > best_score[o]) { best_score[o] = bs; best_h0[o] = h; }
         }
     }
 }

@@ -46,10 +46,14 @@ def config_from_kwargs(sync_score_min=85, max_cands=200, search_freq_range=(100,
     # number of bins of the search range keeps exactly the same list; more than 256 select the build with the deep candidate
     # layouts (libft8rx_wide.so: FT8RX_MAX_CANDS = 2048 > 1884 bins of the widest range).
     cfg.max_cands = min(cfg.max_cands, max(1, cfg.f0_hi - cfg.f0_lo))
-    if cfg.h0_lo < _lib.MIN_H0 or cfg.h0_hi > _lib.MAX_H0 or not 0 < cfg.h0_hi - cfg.h0_lo <= 352:
-        raise _lib.Ft8rxError(f"search_time_range={list(search_time_range)}: supported are windows inside [{_lib.MIN_H0 / 25 - 0.5:.1f}, "
-                              f"{_lib.MAX_H0 / 25 - 0.5:.1f}] s of at most {352 / 25:.2f} s (FT8RX_MIN_H0 / FT8RX_MAX_H0: the middle Costas block of "
-                              "every candidate must lie inside the 16-s fine-sync series; the reference's default is [-2, 3])")
+    # search_time_range: any window the reference itself can search.  Its search reads grid rows h0 + 148 .. h0 + 172 of a 750-row grid
+    # (receiver.py:322, 346-347; negative rows wrap, rows >= 750 are an IndexError), i.e. h0 in [-898, 577]; candidates whose middle
+    # Costas block leaves the fine-sync series (h0 outside [-140, 220]: beyond -6.1 .. +8.3 s) are scored in the time domain with
+    # clamped reads, as the reference does (kernels/fine_sync.hpp: k_fine_td).
+    if cfg.h0_lo < _lib.MIN_H0 or cfg.h0_hi > _lib.MAX_H0 or cfg.h0_hi <= cfg.h0_lo:
+        raise _lib.Ft8rxError(f"search_time_range={list(search_time_range)}: a non-empty window inside [{_lib.MIN_H0 / 25 - 0.5:.1f}, "
+                              f"{_lib.MAX_H0 / 25 - 0.5:.2f}] s (FT8RX_MIN_H0 / FT8RX_MAX_H0: beyond it the reference's own search indexes "
+                              "outside its 750-row grid, receiver.py:346-347; its default is [-2, 3])")
     if cfg.f0_lo < 4 or cfg.f0_hi > _lib.MAX_F0_WIDE or cfg.f0_lo >= cfg.f0_hi:
         raise _lib.Ft8rxError(f"search_freq_range={list(search_freq_range)}: supported are 12.5 .. {_lib.MAX_F0_WIDE * df:.0f} Hz, low < high "
                               "(above 3000 Hz the wide build libft8rx_wide.so is used; the reference fails beyond ~5940 Hz, receiver.py:181-182)")

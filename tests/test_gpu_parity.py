@@ -147,6 +147,8 @@ def test_fine_sync_clamp_rows_are_bit_identical(H, ocfg):
     spec = O.cycle_spectrum(audio, ocfg)
     f0 = np.arange(100, 900, 8, dtype=np.int32)
     trip = [(f, h) for h in (84, 88, 92, 96, 100, 120, 150, 180, 200, 216, -20, -60, -100, -136) for f in f0[:12]] + [(int(f), 88 + 4 * (i % 8)) for i, f in enumerate(f0)]
+    # ... and far-out candidates (k_fine_td: the time-domain form with clamped reads, one series per tweak)
+    trip += [(int(f), h) for h in (221, 230, 252, 300, 372, 400, 577, -141, -150, -168, -200, -312, -600, -898) for f in f0[:6]]
     f0s, h0s = np.array([t[0] for t in trip], np.int32), np.array([t[1] for t in trip], np.int32)
     r = H.fine(spec, np.zeros(len(trip), np.int32), f0s, h0s, want_sgrid=True)
     n_boundary = n_clamped = 0
@@ -1059,6 +1061,33 @@ def test_wide_time_window_clamped_symbols():
             assert n_boundary >= 3, n_boundary       # ... and some with the boundary symbol among them
 
 
+def test_search_time_range_beyond_the_fine_sync_series():
+    """The reference takes any search_time_range its 750-row grid can be indexed with (receiver.py:312, 319, 346-347: -36.4 .. +22.6 s) and
+    clamps every symbol read (:189-195).  Candidates whose middle Costas block leaves the 3200-sample series (h0 outside [-140, 220]) are
+    scored in the time domain with clamped reads (k_fine_td; oracle: ft8o_fine's far_out branch, pinned to the live reference by the
+    'far' set of tests/test_reference_crosscheck.py); windows wider than 352 hops run the sync search in several launches.  Four windows
+    up to the reference's own limits: every record, event and message equals the oracle's, and the batches really hold far-out
+    candidates on both sides, some of which pass the Costas gate."""
+    from pyft8_amd import _lib, synth
+    from pyft8_amd.receiver import config_from_kwargs
+    audio = synth.make_batch(61500, 3)
+    n_far = n_far_alive = 0
+    for tr in ((-20.0, 20.0), (-30.0, 3.0), (0.0, 22.5), (-36.4, 22.6)):
+        cfg = config_from_kwargs(sync_score_min=70, search_time_range=tr)
+        assert _lib.MIN_H0 <= cfg.h0_lo < cfg.h0_hi <= _lib.MAX_H0
+        h = _lib.Handle(cfg, max_frames=3)
+        rec, cnt, ev, evc = h.decode_batch(audio)
+        h.close()
+        ocfg = O.default_config(**_lib.fft_plans(), sync_score_min=70.0, f0_lo=cfg.f0_lo, f0_hi=cfg.f0_hi, h0_lo=cfg.h0_lo, h0_hi=cfg.h0_hi)
+        for i in range(3):
+            _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
+            r = rec[i][:cnt[i]]
+            far = (r["h0_idx"] < _lib.MIN_H0_FD) | (r["h0_idx"] > _lib.MAX_H0_FD)
+            n_far += int(far.sum())
+            n_far_alive += int((far & (r["nsync"] > 6)).sum())
+    assert n_far > 100 and n_far_alive >= 1, (n_far, n_far_alive)
+
+
 def test_candidate_cap_and_kwarg_limits():
     """The build's boundary limits against the reference's open-ended kwargs (receiver.py:311-313, 319, 366-367):
     max_cands = 256, the most the default layouts hold -- with sync_score_min = 40 the threshold admits far more than 256 maxima, the
@@ -1078,7 +1107,8 @@ def test_candidate_cap_and_kwarg_limits():
         _check_frame(rec[i], cnt[i], ev[i], evc[i], audio[i], None, ocfg)
     assert float(rec[0]["score"][255]) > 40.0 + 1.0                        # the list ends at the cut, not at the threshold
     for kw, word in ((dict(max_cands=0), "max_cands=0"),
-                     (dict(search_time_range=[-7.0, 3.0]), "search_time_range"), (dict(search_time_range=[-6.0, 8.2]), "search_time_range"),
+                     (dict(search_time_range=[-37.0, 3.0]), "search_time_range"), (dict(search_time_range=[-6.0, 22.7]), "search_time_range"),
+                     (dict(search_time_range=[3.0, 3.0]), "search_time_range"),
                      (dict(search_freq_range=[0, 3000]), "search_freq_range"), (dict(search_freq_range=[100, 6000]), "search_freq_range")):
         with pytest.raises(_lib.Ft8rxError, match=word):
             Receiver("x", None, **kw)
