@@ -21,7 +21,9 @@ KW = [dict(), dict(), dict(sync_score_min=100, max_cands=150), dict(search_freq_
       # round 6: wide time windows (symbols read clamped, among them the one that starts exactly at the clamp position) and more
       # candidates than the default layouts hold (max_cands > 256: the deep layouts of libft8rx_wide.so)
       dict(search_time_range=[-1.0, 8.2], sync_score_min=70), dict(search_time_range=[2.0, 8.0], sync_score_min=60, max_cands=256),
-      dict(search_time_range=[-6.0, 3.0], sync_score_min=70), dict(max_cands=600, sync_score_min=40)]
+      dict(search_time_range=[-6.0, 3.0], sync_score_min=70), dict(max_cands=600, sync_score_min=40),
+      # ... and windows beyond the fine-sync series (k_fine_td, the sync search in several launches), up to the reference's own limits
+      dict(search_time_range=[-20.0, 20.0], sync_score_min=70), dict(search_time_range=[-36.4, 22.6], sync_score_min=80)]
 KNOBS = ("bp_nc0_a", "bp_iters_a", "bp_nc0_b", "bp_iters_b", "osd_single", "osd_double", "osd_triple", "osd_max_hd", "llr_sd_min")
 
 
