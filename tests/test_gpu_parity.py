@@ -325,7 +325,9 @@ def test_decode_batch_golden_frames(H, ocfg):
 
 
 def test_light_goldens_on_the_gpu():
-    """28 more frames pinned to the REAL reference (tests/golden/light_frames.json, oracle/gen_golden_light.py): every Receiver kwargs
+    """33 more frames pinned to the REAL reference (tests/golden/light_frames.json, oracle/gen_golden_light.py; round 6 added two
+    wide-time-window frames whose OSD outcome hangs on the clamp-boundary symbol, one at max_cands = 400 on the deep layouts and two with
+    a search_time_range far beyond the fine-sync series): every Receiver kwargs
     set of the live cross-check, the four frames whose OSD outcome hangs on how np.argsort orders equal keys (plain goldens since round
     5: the kernel sorts as the reference's numpy does) and the one frame where the build knowingly deviates (last-ulp LLR) with its
     expected-difference marker -- candidate lists, per-candidate (ipass, text) and all message dict fields, through the C ABI."""
