@@ -9,7 +9,7 @@ def jsonline(src, dst):
     d = json.loads(l); open(P + dst, "w").write(l); return d
 d = jsonline("r06_bench_b256_default.json", "r06_bench_b256_default.json")
 d5 = jsonline("r06_bench_b256_5min.json", "r06_bench_b256_5min.json")
-for f in ["r06_gpu_tests.log", "r06_parity_sweep_8320frames.txt", "r06_multipass_vs_reference_sandbox.txt", "r06_fine_timing.txt", "r06_osd_timing.txt", "r06_bp_timing.txt", "r06_kernel_stats_b256.txt",
+for f in ["r06_gpu_tests.log", "r06_parity_sweep_8448frames.txt", "r06_multipass_vs_reference_sandbox.txt", "r06_soak.txt", "r06_fine_timing.txt", "r06_osd_timing.txt", "r06_bp_timing.txt", "r06_kernel_stats_b256.txt",
           "r06_pmc_b256.txt", "r06_pmc_b4096_config2.txt", "r06_pmc_config3.txt", "r06_pmc_config4.txt", "r06_sq.txt", "r06_kernel_resources.txt"]:
     shutil.copy(G + f, P + f)
 shutil.copy(G + "r06_pmc.json", P + "pmc_latest.json"); shutil.copy(G + "r06_sq.json", P + "sq_latest.json")

@@ -7,7 +7,8 @@ TAG=r06
 OUT=$PWD/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
 timeout 1500 python3 -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.log" 2>&1; tail -3 "$OUT/${TAG}_gpu_tests.log"
 timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 2400 python3 tools/parity_sweep.py 520 16 > "$OUT/${TAG}_parity_sweep_8320frames.txt" 2>&1; tail -2 "$OUT/${TAG}_parity_sweep_8320frames.txt"
+timeout 2400 python3 tools/parity_sweep.py 528 16 > "$OUT/${TAG}_parity_sweep_8448frames.txt" 2>&1; tail -2 "$OUT/${TAG}_parity_sweep_8448frames.txt"
+timeout 400 python3 tools/soak.py 120 > "$OUT/${TAG}_soak.txt" 2>&1; tail -2 "$OUT/${TAG}_soak.txt"
 timeout 300 python3 tools/sandbox_overlap.py > "$OUT/${TAG}_multipass_vs_reference_sandbox.txt" 2>&1; tail -3 "$OUT/${TAG}_multipass_vs_reference_sandbox.txt"
 timeout 900 python3 bench.py --min-seconds 300 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_b256_5min.json" 2> /dev/null
 python3 - "$OUT/${TAG}_bench_b256_5min.json" <<'PY'
