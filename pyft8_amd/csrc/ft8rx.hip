@@ -483,7 +483,10 @@ int ft8rx_create(const ft8rx_config* cfg, int device, int max_frames, ft8rx_hand
         if (upload(h, &h->d_trials, tr)) ok = false;
     }
     if (!ok) { set_err(nullptr, "ft8rx_create: device table upload failed"); ft8rx_destroy(h); return -2; }
-    if (sync_lds_bytes(*cfg) > 65536) ok &= hipFuncSetAttribute((const void*)k_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sync_lds_bytes(*cfg)) == hipSuccess;
+    if (sync_lds_bytes(*cfg) > 65536) {
+        ok &= hipFuncSetAttribute((const void*)k_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sync_lds_bytes(*cfg)) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)k_sync_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sync_lds_bytes(*cfg)) == hipSuccess;
+    }
     if (!ok) { set_err(nullptr, "ft8rx_create: cannot reserve LDS for k_sync"); ft8rx_destroy(h); return -2; }
     // the never-written grid row 0 (receiver.py:240)
     int nfill = (int)B * FT8RX_GRID_COLS;
@@ -534,7 +537,8 @@ static void launch_sync(const float* grid, float* bs, int32_t* bh, const ft8rx_c
     for (int lo = c.h0_lo; lo < c.h0_hi; lo += SYNC_WIN) {
         ft8rx_config w = c;
         w.h0_lo = lo; w.h0_hi = lo + SYNC_WIN < c.h0_hi ? lo + SYNC_WIN : c.h0_hi;
-        k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, w, lo != c.h0_lo);
+        if (lo == c.h0_lo) k_sync<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, w);
+        else k_sync_acc<<<dim3(ntile, B), 256, sync_lds_bytes(c), s>>>(grid, bs, bh, w);
     }
 }
 

@@ -7,8 +7,8 @@
 // block = 16 consecutive f0 of one frame; LDS tile = every grid row any h0 can touch x 29 columns.
 // accumulate != 0: a later window of a wide search_time_range (ft8rx.hip: launch_sync) -- the stored result of the earlier windows stays
 // unless this window holds a strictly larger score (windows come in ascending h0: the first strict maximum of the whole range).
-__global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, float* __restrict__ best_score,
-                                              int32_t* __restrict__ best_h0, ft8rx_config cfg, int accumulate) {
+template <bool accumulate>
+FT8_DEV void sync_block(const float* __restrict__ grid, float* __restrict__ best_score, int32_t* __restrict__ best_h0, const ft8rx_config& cfg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nh0 = cfg.h0_hi - cfg.h0_lo;
     const int nrows = nh0 + 24;
@@ -70,6 +70,12 @@ __global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, fl
         }
     }
 }
+
+__global__ __launch_bounds__(256) void k_sync(const float* __restrict__ grid, float* __restrict__ best_score,
+                                              int32_t* __restrict__ best_h0, ft8rx_config cfg) { sync_block<false>(grid, best_score, best_h0, cfg); }
+// a later window of a search_time_range wider than SYNC_WIN offsets
+__global__ __launch_bounds__(256) void k_sync_acc(const float* __restrict__ grid, float* __restrict__ best_score,
+                                                  int32_t* __restrict__ best_h0, ft8rx_config cfg) { sync_block<true>(grid, best_score, best_h0, cfg); }
 
 // ------------------------------------------------------------------------------------ K3 top-K
 // threshold, stable sort by score descending (ties: f0 ascending = original order), keep max_cands.
