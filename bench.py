@@ -198,8 +198,9 @@ def cpu_all_cores(frames, plans):
     return {"value": n / dt, "unit": "frames/s", "cores": cores, "sample": f"{n} frame decodes over {cores} processes, {dt:.1f} s"}
 
 
-def cpu_baseline(frames, budget_s=15.0):
-    """The CPU oracle (single thread) on a bounded sample of the same frames."""
+def cpu_baseline(frames, budget_s=15.0, gpu_texts=None):
+    """The CPU oracle (single thread) on a bounded sample of the same frames.  gpu_texts (the GPU's message texts per frame, emit order, for
+    the same frames at the same -- reference -- knobs): the metric's "decode-set match vs CPU ref" on the frames the baseline decodes anyway."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     from pyft8_amd import _lib
@@ -207,12 +208,17 @@ def cpu_baseline(frames, budget_s=15.0):
     O.decode_frame(frames[0], cfg)
     t0 = time.perf_counter()
     n = 0
+    texts = []
     while n < len(frames) and time.perf_counter() - t0 < budget_s:
-        O.decode_frame(frames[n], cfg)
+        texts.append([" ".join(m["msg_tuple"]) for m in O.decode_frame(frames[n], cfg)["msgs"]])
         n += 1
     dt = time.perf_counter() - t0
     out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"first {n} frames of this rank-0 batch, oracle/ft8_oracle.c single-threaded, {dt:.1f} s"}
+    if gpu_texts is not None:
+        same = sum(1 for i in range(n) if i < len(gpu_texts) and gpu_texts[i] == texts[i])
+        out["decode_set_match"] = {"frames_compared": n, "frames_identical": same, "messages": sum(len(t) for t in texts),
+                                   "what": "message texts in emit order, GPU (last timed batch) vs this CPU oracle, frame by frame"}
     try:
         out["all_cores"] = cpu_all_cores(frames, _lib.fft_plans())
     except Exception as e:                          # informational: never lose the line over it
@@ -892,7 +898,10 @@ def main():
         if not args.no_cpu_baseline:
             # the CPU oracle timed on this box's host cores: rank 0 at N = 1 only (the contract); null in multi-GPU runs
             os.sched_setaffinity(0, orig_affinity)      # the CPU baseline may use every host core, not this rank's slice
-            line["cpu_baseline"] = cpu_baseline(frames) if world == 1 else None
+            gpu_texts = None
+            if world == 1 and reference_knobs and not args.host_synth:           # the same frames, the reference's knobs on both sides
+                gpu_texts = [[" ".join(x.decode() for x in msgs_[f, i]["f"] if x) for i in range(int(mc_[f]))] for f in range(min(B, len(frames)))]
+            line["cpu_baseline"] = cpu_baseline(frames, gpu_texts=gpu_texts) if world == 1 else None
         try:                                  # whatever native libraries hold in their stdio buffers (RCCL's version banner) goes out first:
             import ctypes                     # the JSON line is the LAST line of stdout
             ctypes.CDLL(None).fflush(None)

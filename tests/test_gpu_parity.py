@@ -1664,4 +1664,6 @@ def test_bench_contract_line():
                                                                  and abs(r["counter_frac"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-9))
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s"
+    m = c["decode_set_match"]                 # BASELINE's metric: "... decode-set match vs CPU ref" -- on the frames the baseline decodes anyway
+    assert m["frames_compared"] > 0 and m["frames_identical"] == m["frames_compared"] and m["messages"] > 0
     assert d["value"] > 1000
