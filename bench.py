@@ -900,7 +900,7 @@ def main():
             os.sched_setaffinity(0, orig_affinity)      # the CPU baseline may use every host core, not this rank's slice
             gpu_texts = None
             if world == 1 and reference_knobs and not args.host_synth:           # the same frames, the reference's knobs on both sides
-                gpu_texts = [[" ".join(x.decode() for x in msgs_[f, i]["f"] if x) for i in range(int(mc_[f]))] for f in range(min(B, len(frames)))]
+                gpu_texts = [[" ".join(x.decode() for x in msgs_[f, i]["f"]) for i in range(int(mc_[f]))] for f in range(min(B, len(frames)))]      # (all three fields: an empty third one keeps its separator, as " ".join(msg_tuple) does)
             line["cpu_baseline"] = cpu_baseline(frames, gpu_texts=gpu_texts) if world == 1 else None
         try:                                  # whatever native libraries hold in their stdio buffers (RCCL's version banner) goes out first:
             import ctypes                     # the JSON line is the LAST line of stdout
